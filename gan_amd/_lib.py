@@ -1,0 +1,116 @@
+"""ctypes binding of libgan_amd.so (the C ABI declared in include/gan_amd.h).
+
+The product path has NO CPU fallback: importing this module without the built library, or calling any
+op when the library is missing, raises.  Build with ``python -c "import __graft_entry__ as g; g.build()"``
+or ``make -C gan_amd/csrc``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgan_amd.so")
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_LRELU, ACT_RELU, ACT_TANH = 0, 1, 2, 3
+ACTS = {None: ACT_NONE, 'none': ACT_NONE, 'lrelu': ACT_LRELU, 'relu': ACT_RELU, 'tanh': ACT_TANH}
+
+
+class GanTensor(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("c", C.c_int32),
+                ("pitch", C.c_int32)]
+
+
+class GanConvDesc(C.Structure):
+    _fields_ = [("dtype", C.c_int32), ("stride", C.c_int32), ("x", GanTensor), ("y", GanTensor), ("w", C.c_void_p),
+                ("w_rows", C.c_int32), ("bias", C.c_void_p), ("act", C.c_int32), ("slope", C.c_float),
+                ("y_f32", C.c_int32), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
+
+
+class GanWgradDesc(C.Structure):
+    _fields_ = [("dtype", C.c_int32), ("stride", C.c_int32), ("big", GanTensor), ("small", GanTensor),
+                ("dw", C.c_void_p), ("big_c", C.c_int32), ("small_c", C.c_int32), ("accumulate", C.c_int32),
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
+
+
+class GanNormDesc(C.Structure):
+    _fields_ = [("dtype", C.c_int32), ("y", GanTensor), ("a", GanTensor), ("groups", C.c_int32), ("eps", C.c_float),
+                ("gamma", C.c_void_p), ("beta", C.c_void_p), ("mean", C.c_void_p), ("rstd", C.c_void_p),
+                ("moving_mean", C.c_void_p), ("moving_var", C.c_void_p), ("momentum", C.c_float),
+                ("dropmask", C.c_void_p), ("act", C.c_int32), ("slope", C.c_float), ("workspace", C.c_void_p),
+                ("workspace_bytes", C.c_size_t)]
+
+
+class GanNormBwdDesc(C.Structure):
+    _fields_ = [("dtype", C.c_int32), ("y", GanTensor), ("da", GanTensor), ("da2", GanTensor), ("dy", GanTensor),
+                ("groups", C.c_int32), ("gamma", C.c_void_p), ("beta", C.c_void_p), ("mean", C.c_void_p),
+                ("rstd", C.c_void_p), ("dropmask", C.c_void_p), ("act", C.c_int32), ("slope", C.c_float),
+                ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("accumulate", C.c_int32), ("workspace", C.c_void_p),
+                ("workspace_bytes", C.c_size_t)]
+
+
+class GanActBwdDesc(C.Structure):
+    _fields_ = [("dtype", C.c_int32), ("a", GanTensor), ("da", GanTensor), ("da2", GanTensor), ("dy", GanTensor),
+                ("act", C.c_int32), ("slope", C.c_float), ("dbias", C.c_void_p), ("accumulate", C.c_int32),
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
+
+
+# name -> (restype, argtypes); every symbol include/gan_amd.h declares
+SYMBOLS = {
+    "gan_conv2d_fwd": (C.c_int, [C.POINTER(GanConvDesc), C.c_void_p]),
+    "gan_conv2d_dgrad": (C.c_int, [C.POINTER(GanConvDesc), C.c_void_p]),
+    "gan_convT2d_fwd": (C.c_int, [C.POINTER(GanConvDesc), C.c_void_p]),
+    "gan_convT2d_dgrad": (C.c_int, [C.POINTER(GanConvDesc), C.c_void_p]),
+    "gan_conv_workspace_bytes": (C.c_size_t, [C.POINTER(GanConvDesc), C.c_int]),
+    "gan_conv_wgrad": (C.c_int, [C.POINTER(GanWgradDesc), C.c_void_p]),
+    "gan_wgrad_workspace_bytes": (C.c_size_t, [C.POINTER(GanWgradDesc)]),
+    "gan_weights_prepare": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gan_norm_stats": (C.c_int, [C.POINTER(GanNormDesc), C.c_void_p]),
+    "gan_norm_act_fwd": (C.c_int, [C.POINTER(GanNormDesc), C.c_void_p]),
+    "gan_norm_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int64]),
+    "gan_norm_act_bwd": (C.c_int, [C.POINTER(GanNormBwdDesc), C.c_void_p]),
+    "gan_act_bwd": (C.c_int, [C.POINTER(GanActBwdDesc), C.c_void_p]),
+    "gan_bce_logits": (C.c_int, [C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_int32, C.c_void_p, C.c_float,
+                                 C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
+    "gan_l1": (C.c_int, [C.c_int32, C.POINTER(GanTensor), C.POINTER(GanTensor), C.c_float, C.c_int32, C.c_void_p,
+                         C.c_float, C.POINTER(GanTensor), C.c_void_p, C.c_void_p]),
+    "gan_adam_begin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_void_p]),
+    "gan_adam_tf": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_float,
+                              C.c_float, C.c_float, C.c_float, C.c_void_p]),
+    "gan_dropout_mask": (C.c_int, [C.c_void_p, C.c_int64, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p]),
+    "gan_pack": (C.c_int, [C.c_int32, C.c_void_p, C.POINTER(GanTensor), C.c_void_p]),
+    "gan_unpack": (C.c_int, [C.c_int32, C.POINTER(GanTensor), C.c_void_p, C.c_void_p]),
+    "gan_copy_view": (C.c_int, [C.c_int32, C.POINTER(GanTensor), C.POINTER(GanTensor), C.c_void_p]),
+    "gan_bias_grad": (C.c_int, [C.c_int32, C.POINTER(GanTensor), C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "gan_version": (C.c_char_p, []),
+}
+
+_lib = None
+
+
+class GanAmdError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library (once) and bind every declared symbol; raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GanAmdError(f"{LIB_PATH} not built: the MI355X HIP extension is required (no CPU fallback). "
+                          "Run `make -C gan_amd/csrc` or __graft_entry__.build().")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)       # AttributeError if the library does not export it
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        kind = {-1: "invalid argument", -2: "unsupported shape", -3: "workspace too small"}.get(rc, f"hipError {rc}")
+        raise GanAmdError(f"{what} failed: {kind}")

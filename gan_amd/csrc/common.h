@@ -1,0 +1,90 @@
+// Shared device helpers for the gfx950 kernels.  wave = 64 lanes; all block sizes are multiples of 64.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/gan_amd.h"
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+#define GAN_CHECK_LAUNCH()                                   \
+  do {                                                       \
+    hipError_t e__ = hipGetLastError();                      \
+    if (e__ != hipSuccess) return (int)e__;                  \
+  } while (0)
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return (float)v; }
+__device__ __forceinline__ float ld_f(const float* p) { return *p; }
+__device__ __forceinline__ float ld_f(const bf16_t* p) { return (float)*p; }
+__device__ __forceinline__ void st_f(float* p, float v) { *p = v; }
+__device__ __forceinline__ void st_f(bf16_t* p, float v) { *p = (bf16_t)v; }
+
+template <typename T> struct VecOf;  // elements per 16-byte vector
+template <> struct VecOf<float> { static constexpr int N = 4; };
+template <> struct VecOf<bf16_t> { static constexpr int N = 8; };
+
+// unpack a 16-byte vector of T into floats
+template <typename T> __device__ __forceinline__ void unpack16(const uint4& v, float* out);
+template <> __device__ __forceinline__ void unpack16<float>(const uint4& v, float* out) {
+  out[0] = __uint_as_float(v.x); out[1] = __uint_as_float(v.y);
+  out[2] = __uint_as_float(v.z); out[3] = __uint_as_float(v.w);
+}
+template <> __device__ __forceinline__ void unpack16<bf16_t>(const uint4& v, float* out) {
+  out[0] = __uint_as_float(v.x << 16); out[1] = __uint_as_float(v.x & 0xffff0000u);
+  out[2] = __uint_as_float(v.y << 16); out[3] = __uint_as_float(v.y & 0xffff0000u);
+  out[4] = __uint_as_float(v.z << 16); out[5] = __uint_as_float(v.z & 0xffff0000u);
+  out[6] = __uint_as_float(v.w << 16); out[7] = __uint_as_float(v.w & 0xffff0000u);
+}
+__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
+  bf16_t a = (bf16_t)lo, b = (bf16_t)hi;
+  return (uint32_t)(*(uint16_t*)&a) | ((uint32_t)(*(uint16_t*)&b) << 16);
+}
+template <typename T> __device__ __forceinline__ uint4 pack16(const float* in);
+template <> __device__ __forceinline__ uint4 pack16<float>(const float* in) {
+  return make_uint4(__float_as_uint(in[0]), __float_as_uint(in[1]), __float_as_uint(in[2]), __float_as_uint(in[3]));
+}
+template <> __device__ __forceinline__ uint4 pack16<bf16_t>(const float* in) {
+  return make_uint4(pack_bf2(in[0], in[1]), pack_bf2(in[2], in[3]), pack_bf2(in[4], in[5]), pack_bf2(in[6], in[7]));
+}
+
+__device__ __forceinline__ float apply_act(float v, int act, float slope) {
+  if (act == GAN_ACT_LRELU) return v > 0.f ? v : v * slope;
+  if (act == GAN_ACT_RELU) return v > 0.f ? v : 0.f;
+  if (act == GAN_ACT_TANH) return tanhf(v);
+  return v;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+static inline int ilog2_exact(int v) {  // -1 if not a power of two
+  if (v <= 0 || (v & (v - 1))) return -1;
+  int l = 0;
+  while ((1 << l) < v) ++l;
+  return l;
+}
+static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// Division by a launch-invariant divisor (Granlund-Montgomery): q = (t + ((n - t) >> s1)) >> s2, t = mulhi(mp, n)
+struct FastDiv {
+  uint32_t mp, s1, s2, d;
+};
+static inline FastDiv make_fastdiv(uint32_t d) {
+  FastDiv f;
+  f.d = d;
+  uint32_t l = 0;
+  while ((1ull << l) < d) ++l;
+  f.mp = (uint32_t)(((1ull << 32) * ((1ull << l) - d)) / d + 1);
+  f.s1 = l < 1 ? l : 1;
+  f.s2 = l > 0 ? l - 1 : 0;
+  return f;
+}
+__device__ __forceinline__ uint32_t fdiv(uint32_t n, const FastDiv& f) {
+  uint32_t t = __umulhi(f.mp, n);
+  return (t + ((n - t) >> f.s1)) >> f.s2;
+}

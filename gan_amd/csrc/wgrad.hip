@@ -1,0 +1,331 @@
+// Kernel-gradient (wgrad) of Conv2D / Conv2DTranspose k4 for gfx950:
+//
+//   dW[tap][ca][cb] = sum_m  BIG[src(m, tap), ca] * SMALL[m, cb]        m = (image, gy, gx) on the coarse grid
+//   src(m, tap=(kh,kw)) = (gy*S + kh - 1, gx*S + kw - 1), zero outside the fine map.
+//
+// Conv2D: BIG = layer input, SMALL = dy  -> dW is HWIO.   Conv2DTranspose: BIG = dy, SMALL = layer input
+// -> dW is (kh,kw,cout,cin).  Both are the Keras master layouts, so gradients land byte-for-byte where
+// Adam reads them.
+//
+// The reduction index m is the NHWC *row* index, i.e. the MFMA K dimension is strided in memory for both
+// operands.  Tiles are staged row-major [m][channel] in LDS (coalesced 16-B global loads, 16-B LDS stores)
+// and the K-major fragments are produced by gfx950's transposing LDS read ds_read_b64_tr_b16 (bf16) or by
+// plain ds_read_b32 (fp32, one element per lane per v_mfma_f32_16x16x4_f32).  "fold" mode handles 8-channel
+// (zero-padded C=1..6) BIG tensors by folding the 16 taps into the tile's channel axis, so the SMALL
+// tensor is read once instead of 16 times.  Large reductions split M across blockIdx.z into fp32 slabs.
+#include "common.h"
+
+struct WgradParams {
+  const void* big; const void* small; float* dw; float* slab;
+  int Hb, Wb, bpitch, Ca;
+  int spitch, Cb;
+  int S, M;
+  FastDiv divW, divH;        // coarse-grid width / height
+  int CaReal, CbReal;
+  int tilesB;
+  int splits, kchunks;
+  int accumulate, fold;
+};
+
+template <typename T, int TA, int TB, int WAVES_A, int WAVES_B, bool TR>
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
+  constexpr int VEC = VecOf<T>::N;
+  constexpr int ES = sizeof(T);
+  constexpr int BKM = 128 / ES;                 // rows (m) per K chunk: 64 bf16 / 32 fp32
+  constexpr int RSA = TA * ES + 16, RSB = TB * ES + 16;   // LDS row strides in bytes
+  constexpr int WTA = TA / WAVES_A, WTB = TB / WAVES_B, MT = WTA / 16, NT = WTB / 16;
+  constexpr int VPA = TA / VEC, VPB = TB / VEC;  // vectors per row
+  constexpr int AI = (BKM * VPA + 255) / 256, BI = (BKM * VPB + 255) / 256;
+  static_assert(WAVES_A * WAVES_B == 4, "4 waves");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* As = smem;                      // [2][BKM][RSA]
+  unsigned char* Bs = smem + 2 * BKM * RSA;      // [2][BKM][RSB]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wa = wave / WAVES_B, wb = wave % WAVES_B;
+  const int r = lane & 15, q = lane >> 4;
+  const int ta = blockIdx.x / p.tilesB, tb = blockIdx.x % p.tilesB;
+  const int ca0 = ta * TA, cb0 = tb * TB;
+  const int tap = blockIdx.y, split = blockIdx.z;
+  const int kh = tap >> 2, kw = tap & 3;
+  const T* bg = (const T*)p.big;
+  const T* sg = (const T*)p.small;
+
+  uint4 ra[AI], rb[BI];
+  auto gload = [&](int kc) {
+    const int mbase = kc * BKM;
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      int idx = tid + 256 * i;
+      int row = idx / VPA, cvi = idx % VPA;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      unsigned m = mbase + row;
+      if (idx < BKM * VPA && m < (unsigned)p.M) {
+        unsigned t = fdiv(m, p.divW);
+        int gx = m - t * p.divW.d;
+        unsigned img = fdiv(t, p.divH);
+        int gy = t - img * p.divH.d;
+        int akh = kh, akw = kw, c = ca0 + cvi * VEC;
+        if (p.fold) {                       // channel axis = (tap, 8 padded channels)
+          int ft = (cvi * VEC) >> 3;
+          akh = ft >> 2; akw = ft & 3; c = (cvi * VEC) & 7;
+        }
+        int sy = gy * p.S + akh - 1, sx = gx * p.S + akw - 1;
+        if ((unsigned)sy < (unsigned)p.Hb && (unsigned)sx < (unsigned)p.Wb && c < p.Ca)
+          v = *(const uint4*)(bg + ((size_t)(img * p.Hb + sy) * p.Wb + sx) * (size_t)p.bpitch + c);
+      }
+      ra[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+      int idx = tid + 256 * i;
+      int row = idx / VPB, cvi = idx % VPB;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      unsigned m = mbase + row;
+      int c = cb0 + cvi * VEC;
+      if (idx < BKM * VPB && m < (unsigned)p.M && c < p.Cb)
+        v = *(const uint4*)(sg + (size_t)m * p.spitch + c);
+      rb[i] = v;
+    }
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      int idx = tid + 256 * i;
+      int row = idx / VPA, cvi = idx % VPA;
+      if (idx < BKM * VPA) *(uint4*)(As + (buf * BKM + row) * RSA + cvi * 16) = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+      int idx = tid + 256 * i;
+      int row = idx / VPB, cvi = idx % VPB;
+      if (idx < BKM * VPB) *(uint4*)(Bs + (buf * BKM + row) * RSB + cvi * 16) = rb[i];
+    }
+  };
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int kc_begin = (int)((long long)p.kchunks * split / p.splits);
+  const int kc_end = (int)((long long)p.kchunks * (split + 1) / p.splits);
+  int buf = 0;
+  if (kc_begin < kc_end) { gload(kc_begin); lstore(0); }
+  __syncthreads();
+  for (int kc = kc_begin; kc < kc_end; ++kc) {
+    const bool more = kc + 1 < kc_end;
+    if (more) gload(kc + 1);
+    const unsigned char* Ab = As + buf * BKM * RSA + (wa * WTA) * ES;
+    const unsigned char* Bb = Bs + buf * BKM * RSB + (wb * WTB) * ES;
+    if constexpr (sizeof(T) == 4) {
+#pragma unroll 2
+      for (int kk = 0; kk < BKM / 4; ++kk) {
+        float af[MT], bf[NT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) af[i] = *(const float*)(Ab + (kk * 4 + q) * RSA + (i * 16 + r) * 4);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) bf[j] = *(const float*)(Bb + (kk * 4 + q) * RSB + (j * 16 + r) * 4);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < BKM / 32; ++ks) {
+        bf16x8 af[MT], bf[NT];
+        if constexpr (TR) {
+          // 16-lane group q reads rows ks*32+8q+{0..3} then {4..7}; lane i of the group supplies the address
+          // of row (i>>2), columns 4*(i&3).. and receives column i of the 4 rows.
+          const int rr = ks * 32 + 8 * q + (r >> 2), cc = 4 * (r & 3);
+#pragma unroll
+          for (int i = 0; i < MT; ++i) {
+            const unsigned char* a0 = Ab + rr * RSA + (i * 16 + cc) * 2;
+            s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0));
+            s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0 + 4 * RSA));
+            typedef __attribute__((ext_vector_type(8))) short s16x8;
+            s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            af[i] = *(bf16x8*)&v;
+          }
+#pragma unroll
+          for (int j = 0; j < NT; ++j) {
+            const unsigned char* b0 = Bb + rr * RSB + (j * 16 + cc) * 2;
+            s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(b0));
+            s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(b0 + 4 * RSB));
+            typedef __attribute__((ext_vector_type(8))) short s16x8;
+            s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            bf[j] = *(bf16x8*)&v;
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+              af[i][e] = *(const bf16_t*)(Ab + (ks * 32 + 8 * q + e) * RSA + (i * 16 + r) * 2);
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+              bf[j][e] = *(const bf16_t*)(Bb + (ks * 32 + 8 * q + e) * RSB + (j * 16 + r) * 2);
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+      }
+    }
+    if (more) lstore(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+
+  // D[row = ca][col = cb]; row = q*4 + e, col = r
+  const size_t per_split = (size_t)16 * p.CaReal * p.CbReal;
+  float* out = p.splits > 1 ? p.slab + (size_t)split * per_split : p.dw;
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      int a = ca0 + wa * WTA + i * 16 + q * 4 + e;
+      int otap = tap, oc = a;
+      if (p.fold) { otap = a >> 3; oc = a & 7; if (a >= 128) oc = p.CaReal; }
+      if (oc < p.CaReal) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          int cb = cb0 + wb * WTB + j * 16 + r;
+          if (cb < p.CbReal) {
+            size_t o = ((size_t)otap * p.CaReal + oc) * p.CbReal + cb;
+            if (p.splits == 1 && p.accumulate) out[o] += acc[i][j][e];
+            else out[o] = acc[i][j][e];
+          }
+        }
+      }
+    }
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* slab, float* dw, long long count, int splits, int accumulate) {
+  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= count) return;
+  float s = 0.f;
+  for (int k = 0; k < splits; ++k) s += slab[(size_t)k * count + i];
+  dw[i] = accumulate ? dw[i] + s : s;
+}
+
+struct WgradPlan { WgradParams p; int TA, TB; dim3 grid; size_t slab_bytes; };
+
+static int plan_wgrad(const GanWgradDesc* d, WgradPlan* pl) {
+  if (!d || !d->big.ptr || !d->small.ptr || !d->dw) return GAN_E_ARG;
+  if (d->dtype != GAN_F32 && d->dtype != GAN_BF16) return GAN_E_ARG;
+  const GanTensor &b = d->big, &s = d->small;
+  if (b.c % 8 || s.c % 8 || b.pitch % 8 || s.pitch % 8 || b.pitch < b.c || s.pitch < s.c) return GAN_E_SHAPE;
+  if (d->big_c > b.c || d->small_c > s.c || d->big_c <= 0 || d->small_c <= 0 || b.n != s.n) return GAN_E_SHAPE;
+  if (d->stride != 1 && d->stride != 2) return GAN_E_SHAPE;
+  if (s.h != (b.h + 2 - 4) / d->stride + 1 || s.w != (b.w + 2 - 4) / d->stride + 1) return GAN_E_SHAPE;
+  long long M = (long long)s.n * s.h * s.w;
+  if (M <= 0 || M > 0x7fffffffLL) return GAN_E_SHAPE;
+  WgradParams& p = pl->p;
+  p.big = b.ptr; p.small = s.ptr; p.dw = d->dw; p.slab = (float*)d->workspace;
+  p.Hb = b.h; p.Wb = b.w; p.bpitch = b.pitch; p.Ca = b.c; p.spitch = s.pitch; p.Cb = s.c;
+  p.S = d->stride; p.M = (int)M; p.divW = make_fastdiv(s.w); p.divH = make_fastdiv(s.h);
+  p.CaReal = d->big_c; p.CbReal = d->small_c; p.accumulate = d->accumulate;
+  p.fold = (b.c == 8) ? 1 : 0;
+  int TA, TB, tilesA, taps;
+  if (p.fold) { TA = 128; tilesA = 1; taps = 1; TB = s.c >= 128 ? 128 : (s.c >= 64 ? 64 : 16); if (TB == 16) return GAN_E_SHAPE; }
+  else {
+    taps = 16;
+    TB = s.c >= 128 ? 128 : (s.c >= 64 ? 64 : 16);
+    TA = b.c >= 128 ? 128 : (b.c >= 64 ? 64 : 16);
+    if (TB == 16) TA = TA == 16 ? 64 : TA;   // supported: (128|64, 16)
+    if (TA == 64 && TB == 16) {}
+    if (TA == 16 && TB == 16) return GAN_E_SHAPE;
+    tilesA = (b.c + TA - 1) / TA;
+  }
+  int tilesB = (s.c + TB - 1) / TB;
+  p.tilesB = tilesB;
+  const int bkm = d->dtype == GAN_F32 ? 32 : 64;
+  p.kchunks = (int)((M + bkm - 1) / bkm);
+  long long blocks = (long long)tilesA * tilesB * taps;
+  int splits = 1;
+  if (blocks < 256) {
+    splits = (int)((256 + blocks - 1) / blocks);
+    int maxs = p.kchunks / 4; if (maxs < 1) maxs = 1;
+    if (splits > maxs) splits = maxs;
+    if (splits > 64) splits = 64;
+  }
+  p.splits = splits;
+  pl->TA = TA; pl->TB = TB;
+  pl->grid = dim3((unsigned)(tilesA * tilesB), (unsigned)taps, (unsigned)splits);
+  pl->slab_bytes = splits > 1 ? (size_t)splits * 16 * p.CaReal * p.CbReal * sizeof(float) : 0;
+  return 0;
+}
+
+template <typename T, int TA, int TB, int WA, int WB, bool TR>
+static int launch_wcfg(const WgradPlan& pl, hipStream_t st) {
+  static bool attr_set = false;
+  constexpr int ES = sizeof(T);
+  constexpr size_t smem = 2 * (128 / ES) * ((TA * ES + 16) + (TB * ES + 16));
+  auto kern = wgrad_kernel<T, TA, TB, WA, WB, TR>;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, pl.grid, dim3(256), smem, st, pl.p);
+  GAN_CHECK_LAUNCH();
+  return 0;
+}
+
+template <typename T, bool TR>
+static int launch_wgrad(const WgradPlan& pl, hipStream_t st) {
+  const int key = pl.TA * 1000 + pl.TB;
+  switch (key) {
+    case 128128: return launch_wcfg<T, 128, 128, 2, 2, TR>(pl, st);
+    case 128064: return launch_wcfg<T, 128, 64, 2, 2, TR>(pl, st);
+    case 64128: return launch_wcfg<T, 64, 128, 2, 2, TR>(pl, st);
+    case 64064: return launch_wcfg<T, 64, 64, 2, 2, TR>(pl, st);
+    case 16128: return launch_wcfg<T, 16, 128, 1, 4, TR>(pl, st);
+    case 16064: return launch_wcfg<T, 16, 64, 1, 4, TR>(pl, st);
+    case 128016: return launch_wcfg<T, 128, 16, 4, 1, TR>(pl, st);
+    case 64016: return launch_wcfg<T, 64, 16, 4, 1, TR>(pl, st);
+    default: return GAN_E_SHAPE;
+  }
+}
+
+static bool wgrad_use_tr() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("GAN_AMD_WGRAD_NO_TR"); v = (e && e[0] == '1') ? 0 : 1; }
+  return v == 1;
+}
+
+extern "C" {
+int gan_conv_wgrad(const GanWgradDesc* d, gan_stream_t stream) {
+  WgradPlan pl;
+  int rc = plan_wgrad(d, &pl);
+  if (rc) return rc;
+  if (pl.slab_bytes > d->workspace_bytes || (pl.slab_bytes && !d->workspace)) return GAN_E_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  if (d->dtype == GAN_F32) rc = launch_wgrad<float, false>(pl, st);
+  else rc = wgrad_use_tr() ? launch_wgrad<bf16_t, true>(pl, st) : launch_wgrad<bf16_t, false>(pl, st);
+  if (rc) return rc;
+  if (pl.p.splits > 1) {
+    long long count = (long long)16 * pl.p.CaReal * pl.p.CbReal;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st,
+                       (const float*)pl.p.slab, pl.p.dw, count, pl.p.splits, pl.p.accumulate);
+    GAN_CHECK_LAUNCH();
+  }
+  return 0;
+}
+size_t gan_wgrad_workspace_bytes(const GanWgradDesc* d) {
+  WgradPlan pl;
+  GanWgradDesc t = *d;
+  if (!t.big.ptr) t.big.ptr = (void*)16;
+  if (!t.small.ptr) t.small.ptr = (void*)16;
+  if (!t.dw) t.dw = (float*)16;
+  if (plan_wgrad(&t, &pl)) return 0;
+  return pl.slab_bytes;
+}
+}

@@ -1,0 +1,573 @@
+"""Device-side U-Net generator and PatchGAN discriminator built from the C-ABI ops (include/gan_amd.h).
+
+Follows the topology of the reference's builders (base_gan.py:63-225): `GAN.downsample`, `GAN.upsample`,
+`GAN.Generator`, `GAN.Discriminator`.  PyTorch is used only for device memory and streams; every
+arithmetic op is a hand-written HIP kernel reached through ctypes.  Each "call" object owns the
+activation / gradient buffers of ONE forward invocation of a network and a pre-built list of C calls, so
+running it is a plain loop of enqueue calls (capturable in a hipGraph).
+
+Skip-concat (base_gan.py:219-221) is zero-copy: the up-layer's activation and the down-layer's
+activation are written by their producers straight into channel slices of one NHWC "cat" buffer.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+G_DOWN = [64, 128, 256, 512, 512, 512, 512, 512]     # base_gan.py:179-188
+G_UP = [512, 512, 512, 512, 256, 128, 64]            # base_gan.py:190-198
+LEAKY_ALPHA = 0.3                                    # Keras LeakyReLU() default (base_gan.py:87,155)
+BN_EPS, IN_EPS, BN_MOMENTUM = 1e-3, 1e-5, 0.99       # Keras BatchNormalization defaults; utils.py:9
+
+
+def pad8(c):
+    return (c + 7) // 8 * 8
+
+
+class Ctx:
+    """Device, dtype, library handle and the shared split-K / reduction workspace."""
+
+    def __init__(self, device='cuda:0', dtype='bf16', workspace_mb=256):
+        self.lib = L.load()
+        if not torch.cuda.is_available():
+            raise L.GanAmdError("gan_amd needs an MI355X (no CPU fallback)")
+        self.device = torch.device(device)
+        self.dtype = dtype
+        self.dt = L.BF16 if dtype == 'bf16' else L.F32
+        self.tdtype = torch.bfloat16 if dtype == 'bf16' else torch.float32
+        self.ws = torch.empty(workspace_mb << 20, dtype=torch.uint8, device=self.device)
+        self.ws_ptr, self.ws_bytes = self.ws.data_ptr(), self.ws.numel()
+
+    def stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def run(self, ops):
+        st = self.stream()
+        for fn, args, what in ops:
+            rc = fn(*args, st)
+            if rc:
+                L.check(rc, what)
+
+
+class Buf:
+    """Zero-initialised NHWC device buffer; view() makes a GanTensor channel/batch slice."""
+
+    def __init__(self, ctx, n, h, w, c, tdtype=None):
+        self.n, self.h, self.w, self.c = n, h, w, c
+        self.t = torch.zeros((n, h, w, c), dtype=tdtype or ctx.tdtype, device=ctx.device)
+
+    def view(self, c0=0, c=None, n0=0, n=None):
+        c = self.c - c0 if c is None else c
+        n = self.n - n0 if n is None else n
+        off = (n0 * self.h * self.w * self.c + c0) * self.t.element_size()
+        return L.GanTensor(self.t.data_ptr() + off, n, self.h, self.w, c, self.c)
+
+
+# --------------------------------------------------------------------------------------------------
+class ParamSet:
+    """Flat fp32 master / grad / Adam-m / Adam-v buffers of one network (Keras layouts: HWIO kernels for
+    Conv2D, (kh,kw,cout,cin) for Conv2DTranspose) plus the typed NK copies the GEMM kernels consume."""
+
+    ALIGN = 64
+
+    def __init__(self, ctx, spec):
+        """spec: list of (name, shape, is_trainable)"""
+        self.ctx = ctx
+        self.entries = {}
+        off = 0
+        for name, shape, trainable in spec:
+            if not trainable:
+                continue
+            n = int(np.prod(shape))
+            self.entries[name] = (off, tuple(shape))
+            off += (n + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+        self.total = off
+        dev = ctx.device
+        self.master = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.m = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.v = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.state = {name: torch.zeros(shape, dtype=torch.float32, device=dev) if 'mean' in name
+                      else torch.ones(shape, dtype=torch.float32, device=dev)
+                      for name, shape, trainable in spec if not trainable}
+        self.step = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.lr_t = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.nat, self.tr = {}, {}
+        for name, (o, shape) in self.entries.items():
+            if name.endswith('.kernel'):
+                A, B = shape[2], shape[3]
+                self.nat[name] = torch.zeros((16, A, pad8(B)), dtype=ctx.tdtype, device=dev)
+                self.tr[name] = torch.zeros((16, B, pad8(A)), dtype=ctx.tdtype, device=dev)
+        self._prep_ops = []
+        for name in self.nat:
+            o, shape = self.entries[name]
+            self._prep_ops.append((ctx.lib.gan_weights_prepare,
+                                   (self.master.data_ptr() + 4 * o, shape[2], shape[3], ctx.dt,
+                                    self.nat[name].data_ptr(), self.tr[name].data_ptr()), f"weights_prepare({name})"))
+
+    def ptr(self, name, which='master'):
+        return getattr(self, which).data_ptr() + 4 * self.entries[name][0]
+
+    def tensor(self, name, which='master'):
+        o, shape = self.entries[name]
+        return getattr(self, which)[o:o + int(np.prod(shape))].view(shape)
+
+    def trainable_count(self):
+        return int(sum(np.prod(s) for _, s in self.entries.values()))
+
+    def load_numpy(self, P):
+        for name, (o, shape) in self.entries.items():
+            self.tensor(name).copy_(torch.from_numpy(np.ascontiguousarray(P[name], dtype=np.float32)).view(shape))
+        for name, t in self.state.items():
+            if name in P:
+                t.copy_(torch.from_numpy(np.asarray(P[name], dtype=np.float32)))
+        self.prepare()
+
+    def to_numpy(self, which='master'):
+        out = {name: self.tensor(name, which).detach().cpu().numpy().copy() for name in self.entries}
+        if which == 'master':
+            out.update({k: v.cpu().numpy().copy() for k, v in self.state.items()})
+        return out
+
+    def prepare(self):
+        """(Re)build the typed NK weight copies from the fp32 master."""
+        self.ctx.run(self._prep_ops)
+
+    def adam(self, lr, b1, b2, eps=1e-7, grad_scale=1.0):
+        """Keras Adam (base_gan.py:247-252), one launch over the whole flat buffer, then refresh NK copies."""
+        lib = self.ctx.lib
+        ops = [(lib.gan_adam_begin, (self.step.data_ptr(), self.lr_t.data_ptr(), lr, b1, b2), "adam_begin"),
+               (lib.gan_adam_tf, (self.master.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), self.grad.data_ptr(),
+                                  self.total, self.lr_t.data_ptr(), b1, b2, eps, grad_scale), "adam_tf")]
+        self.ctx.run(ops)
+        self.prepare()
+
+
+def _norm_spec(spec, name, c, norm):
+    if norm == 'batchnorm':
+        spec += [(name + '.gamma', (c,), True), (name + '.beta', (c,), True),
+                 (name + '.moving_mean', (c,), False), (name + '.moving_variance', (c,), False)]
+    elif norm == 'instancenorm':
+        spec += [(name + '.scale', (c,), True), (name + '.offset', (c,), True)]
+
+
+def generator_spec(channels, norm):
+    spec = []
+    cin = channels
+    for i, co in enumerate(G_DOWN):
+        spec.append((f'down{i}.kernel', (4, 4, cin, co), True))
+        if i > 0:
+            _norm_spec(spec, f'down{i}', co, norm)
+        cin = co
+    for i, co in enumerate(G_UP):
+        spec.append((f'up{i}.kernel', (4, 4, co, cin), True))
+        _norm_spec(spec, f'up{i}', co, norm)
+        cin = co + G_DOWN[6 - i]
+    spec += [('last.kernel', (4, 4, channels, cin), True), ('last.bias', (channels,), True)]
+    return spec
+
+
+def discriminator_spec(channels, target, norm):
+    spec = []
+    cin = channels * (2 if target else 1)
+    for i, co in enumerate([64, 128, 256]):
+        spec.append((f'down{i}.kernel', (4, 4, cin, co), True))
+        if i > 0:
+            _norm_spec(spec, f'down{i}', co, norm)
+        cin = co
+    spec.append(('conv.kernel', (4, 4, 256, 512), True))
+    _norm_spec(spec, 'conv', 512, norm)
+    spec += [('last.kernel', (4, 4, 512, 1), True), ('last.bias', (1,), True)]
+    return spec
+
+
+def init_params_numpy(spec, seed):
+    """N(0, 0.02) kernels (base_gan.py:74,103,132,200), gamma=1/beta=0, IN scale N(1,0.02) (utils.py:14-24)."""
+    rng = np.random.default_rng(seed)
+    P = {}
+    for name, shape, trainable in spec:
+        if name.endswith('.kernel'):
+            P[name] = (0.02 * rng.standard_normal(shape)).astype(np.float32)
+        elif name.endswith('.gamma') or name.endswith('.moving_variance'):
+            P[name] = np.ones(shape, np.float32)
+        elif name.endswith('.scale'):
+            P[name] = (1.0 + 0.02 * rng.standard_normal(shape)).astype(np.float32)
+        else:
+            P[name] = np.zeros(shape, np.float32)
+    return P
+
+
+# --------------------------------------------------------------------------------------------------
+class _Builder:
+    """Helpers that turn layer descriptions into (fn, args, label) C calls."""
+
+    def __init__(self, ctx, params, norm):
+        self.ctx, self.P, self.norm = ctx, params, norm
+        self.lib = ctx.lib
+        self.keep = []       # ctypes structs must outlive the op list
+
+    def _desc(self, d):
+        self.keep.append(d)
+        return C.byref(d)
+
+    def conv(self, op, x, y, w, w_rows, stride=2, bias=None, act=None, y_f32=0):
+        d = L.GanConvDesc(self.ctx.dt, stride, x, y, w, w_rows, bias, L.ACTS[act], LEAKY_ALPHA, y_f32,
+                          self.ctx.ws_ptr, self.ctx.ws_bytes)
+        opi = {'conv_fwd': 0, 'conv_dgrad': 1, 'convT_fwd': 2, 'convT_dgrad': 3}[op]
+        fn = [self.lib.gan_conv2d_fwd, self.lib.gan_conv2d_dgrad, self.lib.gan_convT2d_fwd, self.lib.gan_convT2d_dgrad][opi]
+        need = self.lib.gan_conv_workspace_bytes(C.byref(d), opi)
+        if need > self.ctx.ws_bytes:
+            raise L.GanAmdError(f"workspace too small for {op}: need {need}")
+        return (fn, (self._desc(d),), op)
+
+    def wgrad(self, big, small, dw_ptr, big_c, small_c, stride, accumulate):
+        d = L.GanWgradDesc(self.ctx.dt, stride, big, small, dw_ptr, big_c, small_c, int(accumulate),
+                           self.ctx.ws_ptr, self.ctx.ws_bytes)
+        need = self.lib.gan_wgrad_workspace_bytes(C.byref(d))
+        if need > self.ctx.ws_bytes:
+            raise L.GanAmdError(f"workspace too small for wgrad: need {need}")
+        return (self.lib.gan_conv_wgrad, (self._desc(d),), "conv_wgrad")
+
+    def norm_names(self):
+        return ('.gamma', '.beta') if self.norm == 'batchnorm' else ('.scale', '.offset')
+
+    def norm_fwd(self, name, y, a, groups, mean, rstd, act, mask_ptr, stat_groups_update=True):
+        gk, bk = self.norm_names()
+        eps = BN_EPS if self.norm == 'batchnorm' else IN_EPS
+        mm = mv = None
+        if self.norm == 'batchnorm' and stat_groups_update:
+            mm = self.P.state[name + '.moving_mean'].data_ptr()
+            mv = self.P.state[name + '.moving_variance'].data_ptr()
+        d = L.GanNormDesc(self.ctx.dt, y, a, groups, eps, self.P.ptr(name + gk), self.P.ptr(name + bk),
+                          mean.data_ptr(), rstd.data_ptr(), mm, mv, BN_MOMENTUM, mask_ptr, L.ACTS[act], LEAKY_ALPHA,
+                          self.ctx.ws_ptr, self.ctx.ws_bytes)
+        r = self._desc(d)
+        return [(self.lib.gan_norm_stats, (r,), f"norm_stats({name})"),
+                (self.lib.gan_norm_act_fwd, (r,), f"norm_act_fwd({name})")]
+
+    def norm_bwd(self, name, y, da, da2, dy, groups, mean_ptr, rstd_ptr, act, mask_ptr, want_param_grads, accumulate):
+        gk, bk = self.norm_names()
+        z = L.GanTensor(None, 0, 0, 0, 0, 0)
+        d = L.GanNormBwdDesc(self.ctx.dt, y, da, da2 if da2 is not None else z, dy, groups,
+                             self.P.ptr(name + gk), self.P.ptr(name + bk), mean_ptr, rstd_ptr, mask_ptr,
+                             L.ACTS[act], LEAKY_ALPHA,
+                             self.P.ptr(name + gk, 'grad') if want_param_grads else None,
+                             self.P.ptr(name + bk, 'grad') if want_param_grads else None,
+                             int(accumulate), self.ctx.ws_ptr, self.ctx.ws_bytes)
+        return (self.lib.gan_norm_act_bwd, (self._desc(d),), f"norm_act_bwd({name})")
+
+    def act_bwd(self, a, da, da2, dy, act):
+        z = L.GanTensor(None, 0, 0, 0, 0, 0)
+        d = L.GanActBwdDesc(self.ctx.dt, a, da, da2 if da2 is not None else z, dy, L.ACTS[act], LEAKY_ALPHA, None, 0,
+                            self.ctx.ws_ptr, self.ctx.ws_bytes)
+        return (self.lib.gan_act_bwd, (self._desc(d),), "act_bwd")
+
+    def bias_grad(self, dy, dbias_ptr, accumulate):
+        self.keep.append(dy)
+        return (self.lib.gan_bias_grad, (self.ctx.dt, C.byref(dy), dbias_ptr, int(accumulate), self.ctx.ws_ptr,
+                                         self.ctx.ws_bytes), "bias_grad")
+
+
+class GeneratorNet:
+    """`GAN.Generator(norm_type, shape)` (base_gan.py:168-225): parameters + factory of call objects."""
+
+    def __init__(self, ctx, channels, norm='batchnorm', seed=0):
+        self.ctx, self.channels, self.norm = ctx, channels, norm
+        self.spec = generator_spec(channels, norm)
+        self.params = ParamSet(ctx, self.spec)
+        self.params.load_numpy(init_params_numpy(self.spec, seed))
+
+    def new_call(self, batch, size, dropout=True, seed=1234, stream_id=0):
+        return GenCall(self, batch, size, dropout, seed, stream_id)
+
+
+class GenCall:
+    """Buffers + op lists for one invocation `generator(x, training=True)` and its backward."""
+
+    def __init__(self, net, B, S, dropout, seed, stream_id):
+        ctx, P = net.ctx, net.params
+        self.net, self.ctx, self.B, self.S, self.C = net, ctx, B, S, net.channels
+        bd = _Builder(ctx, P, net.norm)
+        self._bd = bd
+        C_ = net.channels
+        groups = 1 if net.norm == 'batchnorm' else B
+        self.groups = groups
+        hs = [S >> (i + 1) for i in range(8)]                       # spatial size of down i output
+        self.xin = Buf(ctx, B, S, S, 8)
+        self.out = Buf(ctx, B, S, S, 8)                             # tanh output, channels [0, C)
+        self.cat = [Buf(ctx, B, hs[6 - j], hs[6 - j], G_UP[j] + G_DOWN[6 - j]) for j in range(7)]
+        self.a7 = Buf(ctx, B, hs[7], hs[7], 512)
+        self.y_down = [None] + [Buf(ctx, B, hs[i], hs[i], G_DOWN[i]) for i in range(1, 8)]
+        self.y_up = [Buf(ctx, B, hs[6 - j], hs[6 - j], G_UP[j]) for j in range(7)]
+        dev = ctx.device
+        f32 = torch.float32
+        self.stats = {}
+
+        def stat(name, c):
+            self.stats[name] = (torch.zeros(groups * c, dtype=f32, device=dev), torch.zeros(groups * c, dtype=f32, device=dev))
+            return self.stats[name]
+
+        self.masks = [torch.ones((B, hs[6 - j], hs[6 - j], 512), dtype=torch.uint8, device=dev) for j in range(3)] if dropout else None
+        self.mask_ops = []
+        if dropout:
+            for j in range(3):
+                self.mask_ops.append((ctx.lib.gan_dropout_mask, (self.masks[j].data_ptr(), self.masks[j].numel(), seed,
+                                                                 P.step.data_ptr(), stream_id * 8 + j), "dropout_mask"))
+        self.auto_masks = dropout
+
+        def a_down(i):      # activation view of down i
+            if i == 7:
+                return self.a7.view()
+            j = 6 - i
+            return self.cat[j].view(G_UP[j], G_DOWN[i])
+
+        # ---------------- forward ----------------
+        fwd = []
+        x = self.xin.view()
+        for i in range(8):
+            name = f'down{i}'
+            w = P.tr[name + '.kernel']
+            if i == 0:      # conv -> LeakyReLU fused in the GEMM epilogue (apply_norm=False, base_gan.py:180)
+                fwd.append(bd.conv('conv_fwd', x, a_down(0), w.data_ptr(), G_DOWN[0], 2, None, 'lrelu'))
+            else:
+                fwd.append(bd.conv('conv_fwd', x, self.y_down[i].view(), w.data_ptr(), G_DOWN[i], 2))
+                mean, rstd = stat(name, G_DOWN[i])
+                fwd += bd.norm_fwd(name, self.y_down[i].view(), a_down(i), groups, mean, rstd, 'lrelu', None)
+            x = a_down(i)
+        for j in range(7):
+            name = f'up{j}'
+            xin = self.a7.view() if j == 0 else self.cat[j - 1].view()
+            w = P.nat[name + '.kernel']
+            fwd.append(bd.conv('convT_fwd', xin, self.y_up[j].view(), w.data_ptr(), G_UP[j], 2))
+            mean, rstd = stat(name, G_UP[j])
+            mptr = self.masks[j].data_ptr() if (dropout and j < 3) else None
+            fwd += bd.norm_fwd(name, self.y_up[j].view(), self.cat[j].view(0, G_UP[j]), groups, mean, rstd, 'relu', mptr)
+        fwd.append(bd.conv('convT_fwd', self.cat[6].view(), self.out.view(0, C_), P.nat['last.kernel'].data_ptr(), C_, 2,
+                           P.ptr('last.bias'), 'tanh'))
+        self.fwd_ops = fwd
+
+        # ---------------- backward ----------------
+        self.dcat = [Buf(ctx, B, hs[6 - j], hs[6 - j], G_UP[j] + G_DOWN[6 - j]) for j in range(7)]
+        self.da7 = Buf(ctx, B, hs[7], hs[7], 512)
+        self.dA = [Buf(ctx, B, hs[i], hs[i], G_DOWN[i]) for i in range(7)]     # grad wrt a_i from down i+1
+        self.dy_down = [Buf(ctx, B, hs[i], hs[i], G_DOWN[i]) for i in range(8)]
+        self.dy_up = [Buf(ctx, B, hs[6 - j], hs[6 - j], G_UP[j]) for j in range(7)]
+        self.dpre = Buf(ctx, B, S, S, 8)
+        self.dgen = Buf(ctx, B, S, S, 8)      # upstream gradient slot 1 (e.g. L1 term), channels [0, C)
+        self.dgen2 = Buf(ctx, B, S, S, 8)     # upstream gradient slot 2 (e.g. from the discriminator)
+        self.dxin = Buf(ctx, B, S, S, 8)
+        self._bwd_cache = {}
+
+    def _build_bwd(self, use_dgen2, need_dx, accumulate):
+        bd, P, C_, groups = self._bd, self.net.params, self.C, self.groups
+        ops = []
+        ops.append(bd.act_bwd(self.out.view(), self.dgen.view(), self.dgen2.view() if use_dgen2 else None,
+                              self.dpre.view(), 'tanh'))
+        ops.append(bd.wgrad(self.dpre.view(), self.cat[6].view(), P.ptr('last.kernel', 'grad'), C_, 128, 2, accumulate))
+        ops.append(bd.bias_grad(self.dpre.view(), P.ptr('last.bias', 'grad'), accumulate))
+        ops.append(bd.conv('convT_dgrad', self.dpre.view(), self.dcat[6].view(), P.tr['last.kernel'].data_ptr(), 128, 2))
+        for j in range(6, -1, -1):
+            name = f'up{j}'
+            mean, rstd = self.stats[name]
+            mptr = self.masks[j].data_ptr() if (self.masks is not None and j < 3) else None
+            ops.append(bd.norm_bwd(name, self.y_up[j].view(), self.dcat[j].view(0, G_UP[j]), None, self.dy_up[j].view(),
+                                   groups, mean.data_ptr(), rstd.data_ptr(), 'relu', mptr, True, accumulate))
+            xin = self.a7 if j == 0 else self.cat[j - 1]
+            dxin = self.da7 if j == 0 else self.dcat[j - 1]
+            cin = xin.c
+            ops.append(bd.wgrad(self.dy_up[j].view(), xin.view(), P.ptr(name + '.kernel', 'grad'), G_UP[j], cin, 2, accumulate))
+            ops.append(bd.conv('convT_dgrad', self.dy_up[j].view(), dxin.view(), P.tr[name + '.kernel'].data_ptr(), cin, 2))
+        for i in range(7, -1, -1):
+            name = f'down{i}'
+            if i == 7:
+                da, da2 = self.da7.view(), None
+            else:
+                j = 6 - i
+                da, da2 = self.dcat[j].view(G_UP[j], G_DOWN[i]), self.dA[i].view()
+            if i == 0:
+                ops.append(bd.act_bwd(self.cat[6].view(G_UP[6], 64), da, da2, self.dy_down[0].view(), 'lrelu'))
+            else:
+                mean, rstd = self.stats[name]
+                ops.append(bd.norm_bwd(name, self.y_down[i].view(), da, da2, self.dy_down[i].view(), groups,
+                                       mean.data_ptr(), rstd.data_ptr(), 'lrelu', None, True, accumulate))
+            if i == 0:
+                xin, cin_real = self.xin.view(), C_
+            elif i == 1:
+                xin, cin_real = self.cat[6].view(G_UP[6], 64), 64
+            else:
+                jj = 6 - (i - 1)
+                xin, cin_real = self.cat[jj].view(G_UP[jj], G_DOWN[i - 1]), G_DOWN[i - 1]
+            ops.append(bd.wgrad(xin, self.dy_down[i].view(), P.ptr(name + '.kernel', 'grad'), cin_real, G_DOWN[i], 2, accumulate))
+            if i > 0:
+                ops.append(bd.conv('conv_dgrad', self.dy_down[i].view(), self.dA[i - 1].view(),
+                                   P.nat[name + '.kernel'].data_ptr(), G_DOWN[i - 1], 2))
+            elif need_dx:
+                ops.append(bd.conv('conv_dgrad', self.dy_down[0].view(), self.dxin.view(0, C_),
+                                   P.nat[name + '.kernel'].data_ptr(), C_, 2))
+        return ops
+
+    # public API ------------------------------------------------------------------------------
+    def set_dropmasks(self, masks):
+        """Explicit 0/1 masks (parity tests); disables the per-step generator."""
+        for t, m in zip(self.masks, masks):
+            t.copy_(torch.from_numpy(np.asarray(m)).to(torch.uint8))
+        self.auto_masks = False
+
+    def set_input(self, x_f32):
+        """x: dense fp32 NHWC [B,S,S,C] device tensor -> typed, 8-channel-padded input buffer."""
+        dst = self.xin.view(0, self.C)
+        rc = self.ctx.lib.gan_pack(self.ctx.dt, x_f32.data_ptr(), C.byref(dst), self.ctx.stream())
+        L.check(rc, "pack")
+
+    def set_input_view(self, src_view):
+        dst = self.xin.view(0, self.C)
+        L.check(self.ctx.lib.gan_copy_view(self.ctx.dt, C.byref(src_view), C.byref(dst), self.ctx.stream()), "copy_view")
+
+    def forward(self):
+        if self.auto_masks:
+            self.ctx.run(self.mask_ops)
+        self.ctx.run(self.fwd_ops)
+
+    def out_view(self):
+        return self.out.view(0, self.C)
+
+    def backward(self, use_dgen2=False, need_dx=False, accumulate=False):
+        """Upstream gradient(s) w.r.t. the tanh output must be in self.dgen (and self.dgen2)."""
+        key = (use_dgen2, need_dx, accumulate)
+        if key not in self._bwd_cache:
+            self._bwd_cache[key] = self._build_bwd(*key)
+        self.ctx.run(self._bwd_cache[key])
+
+    def output_f32(self):
+        o = torch.empty((self.B, self.S, self.S, self.C), dtype=torch.float32, device=self.ctx.device)
+        v = self.out_view()
+        L.check(self.ctx.lib.gan_unpack(self.ctx.dt, C.byref(v), o.data_ptr(), self.ctx.stream()), "unpack")
+        return o
+
+
+# --------------------------------------------------------------------------------------------------
+class DiscriminatorNet:
+    """`GAN.Discriminator(norm_type, target)` (base_gan.py:124-166)."""
+
+    def __init__(self, ctx, channels, target=True, norm='batchnorm', seed=1):
+        self.ctx, self.channels, self.target, self.norm = ctx, channels, target, norm
+        self.cin = channels * (2 if target else 1)
+        self.spec = discriminator_spec(channels, target, norm)
+        self.params = ParamSet(ctx, self.spec)
+        self.params.load_numpy(init_params_numpy(self.spec, seed))
+
+    def new_call(self, batch, size, calls=2):
+        return DiscCall(self, batch, size, calls)
+
+
+class DiscCall:
+    """`calls` invocations of the discriminator batched along N (e.g. D(real) ++ D(fake), pix2pix.py:202-203);
+    BatchNormalization statistics stay per invocation (groups = calls).  Backward pass "A" covers the whole
+    batch with parameter gradients (discriminator loss); pass "B" is the input-gradient-only chain over the
+    last invocation (generator's adversarial loss through D(fake), pix2pix.py:210)."""
+
+    LAYERS = [('down0', 64, 2), ('down1', 128, 2), ('down2', 256, 2), ('conv', 512, 1), ('last', 1, 1)]
+
+    def __init__(self, net, B, S, calls):
+        ctx, P = net.ctx, net.params
+        self.net, self.ctx, self.B, self.S, self.calls = net, ctx, B, S, calls
+        N = B * calls
+        self.N = N
+        bd = _Builder(ctx, P, net.norm)
+        self._bd = bd
+        bn = net.norm == 'batchnorm'
+        groups = calls if bn else N
+        self.groups = groups
+        self.gper = 1 if bn else B           # stat groups per invocation
+        s1, s2, s3 = S // 2, S // 4, S // 8
+        s4, s5 = s3 - 1, s3 - 2
+        self.xin = Buf(ctx, N, S, S, 8)
+        self.a0 = Buf(ctx, N, s1, s1, 64)
+        self.y = {'down1': Buf(ctx, N, s2, s2, 128), 'down2': Buf(ctx, N, s3, s3, 256), 'conv': Buf(ctx, N, s4, s4, 512)}
+        self.a = {'down0': self.a0, 'down1': Buf(ctx, N, s2, s2, 128), 'down2': Buf(ctx, N, s3, s3, 256),
+                  'conv': Buf(ctx, N, s4, s4, 512)}
+        self.logits = Buf(ctx, N, s5, s5, 1, torch.float32)
+        dev, f32 = ctx.device, torch.float32
+        self.stats = {k: (torch.zeros(groups * c, dtype=f32, device=dev), torch.zeros(groups * c, dtype=f32, device=dev))
+                      for k, c in [('down1', 128), ('down2', 256), ('conv', 512)]}
+        fwd = [bd.conv('conv_fwd', self.xin.view(), self.a0.view(), P.tr['down0.kernel'].data_ptr(), 64, 2, None, 'lrelu')]
+        prev = self.a0
+        for name, co, stride in self.LAYERS[1:4]:
+            fwd.append(bd.conv('conv_fwd', prev.view(), self.y[name].view(), P.tr[name + '.kernel'].data_ptr(), co, stride))
+            mean, rstd = self.stats[name]
+            fwd += bd.norm_fwd(name, self.y[name].view(), self.a[name].view(), groups, mean, rstd, 'lrelu', None)
+            prev = self.a[name]
+        fwd.append(bd.conv('conv_fwd', prev.view(), self.logits.view(), P.tr['last.kernel'].data_ptr(), 1, 1,
+                           P.ptr('last.bias'), None, 1))
+        self.fwd_ops = fwd
+        # backward buffers (pass B reuses the first B samples' worth of them)
+        self.dlogits = Buf(ctx, N, s5, s5, 8)        # pass A: all invocations (channel 0 real)
+        self.dlogits_b = Buf(ctx, B, s5, s5, 8)      # pass B: one invocation
+        self.dA = {'conv': Buf(ctx, N, s4, s4, 512), 'down2': Buf(ctx, N, s3, s3, 256), 'down1': Buf(ctx, N, s2, s2, 128),
+                   'down0': Buf(ctx, N, s1, s1, 64)}
+        self.dy = {'conv': Buf(ctx, N, s4, s4, 512), 'down2': Buf(ctx, N, s3, s3, 256), 'down1': Buf(ctx, N, s2, s2, 128),
+                   'down0': Buf(ctx, N, s1, s1, 64)}
+        self.dxin = Buf(ctx, B, S, S, 8)
+        self._cache = {}
+
+    def forward(self):
+        self.ctx.run(self.fwd_ops)
+
+    def logits_view(self, call):
+        """fp32 logits of invocation `call`: (ptr, count)."""
+        per = self.B * self.logits.h * self.logits.w
+        return self.logits.t.data_ptr() + 4 * call * per, per
+
+    def dlogits_ptr(self, call):
+        per = self.B * self.dlogits.h * self.dlogits.w * 8
+        return self.dlogits.t.data_ptr() + call * per * self.dlogits.t.element_size()
+
+    def _chain(self, n0, n, groups, stat_off, wgrads, need_dx, accumulate):
+        """Backward over samples [n0, n0+n).  Scratch gradients always live at samples [0, n) of the dA/dy
+        buffers; saved forward tensors are read at [n0, n0+n)."""
+        bd, P = self._bd, self.net.params
+        ops = []
+        sv = lambda buf: buf.view(0, None, n0, n)          # saved forward tensors
+        gv = lambda buf: buf.view(0, None, 0, n)           # gradient scratch
+        dl = self.dlogits.view(0, None, n0, n) if wgrads else self.dlogits_b.view()
+        # last: conv s1 with bias, no activation
+        if wgrads:
+            ops.append(bd.wgrad(sv(self.a['conv']), dl, P.ptr('last.kernel', 'grad'), 512, 1, 1, accumulate))
+            ops.append(bd.bias_grad(dl, P.ptr('last.bias', 'grad'), accumulate))
+        ops.append(bd.conv('conv_dgrad', dl, gv(self.dA['conv']), P.nat['last.kernel'].data_ptr(), 512, 1))
+        order = [('conv', 'down2', 1, 256), ('down2', 'down1', 2, 128), ('down1', 'down0', 2, 64)]
+        for name, prev, stride, cprev in order:
+            mean, rstd = self.stats[name]
+            c = self.y[name].c
+            ops.append(bd.norm_bwd(name, sv(self.y[name]), gv(self.dA[name]), None, gv(self.dy[name]), groups,
+                                   mean.data_ptr() + 4 * stat_off * c, rstd.data_ptr() + 4 * stat_off * c, 'lrelu', None,
+                                   wgrads, accumulate))
+            if wgrads:
+                ops.append(bd.wgrad(sv(self.a[prev]), gv(self.dy[name]), P.ptr(name + '.kernel', 'grad'), cprev, c, stride, accumulate))
+            ops.append(bd.conv('conv_dgrad', gv(self.dy[name]), gv(self.dA[prev]), P.nat[name + '.kernel'].data_ptr(), cprev, stride))
+        ops.append(bd.act_bwd(sv(self.a0), gv(self.dA['down0']), None, gv(self.dy['down0']), 'lrelu'))
+        if wgrads:
+            ops.append(bd.wgrad(sv(self.xin), gv(self.dy['down0']), P.ptr('down0.kernel', 'grad'), self.net.cin, 64, 2, accumulate))
+        if need_dx:
+            ops.append(bd.conv('conv_dgrad', gv(self.dy['down0']), self.dxin.view(0, self.net.cin, 0, n),
+                               P.nat['down0.kernel'].data_ptr(), self.net.cin, 2))
+        return ops
+
+    def backward_params(self, accumulate=False):
+        """Pass A: dlogits (all invocations, written by the loss kernels) -> parameter gradients."""
+        key = ('A', accumulate)
+        if key not in self._cache:
+            self._cache[key] = self._chain(0, self.N, self.groups, 0, True, False, accumulate)
+        self.ctx.run(self._cache[key])
+
+    def backward_input(self, call):
+        """Pass B: gradient w.r.t. the input of invocation `call`; its dlogits must be in self.dlogits_b.
+        Result in self.dxin (8-channel padded)."""
+        key = ('B', call)
+        if key not in self._cache:
+            self._cache[key] = self._chain(call * self.B, self.B, self.gper, call * self.gper, False, True, False)
+        self.ctx.run(self._cache[key])

@@ -1,0 +1,193 @@
+"""Device-side train steps: the whole of `Pix2Pix.train_step` (pix2pix.py:190-218) and
+`CycleGAN.train_step` (cycle_gan.py:206-276) as sequences of C-ABI kernel launches — forward, losses,
+explicit backward and TF-form Adam all on the GPU, optionally captured once into a hipGraph and replayed.
+
+Semantics kept from the reference: both gradients are taken at the pre-update weights from a single
+forward (simultaneous update); D(real) and D(fake) are separate BatchNormalization invocations (separate
+batch statistics, two moving-average updates); dropout is active in every generator call; `training=False`
+computes forward + losses only (pix2pix.py:208, :291-292).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+from .nets import Ctx, DiscriminatorNet, GeneratorNet
+
+
+class _StepBase:
+    def _bce(self, logits_ptr, count, target, loss_idx, loss_scale, acc, grad_scale, dx_ptr):
+        lib, ctx = self.ctx.lib, self.ctx
+        rc = lib.gan_bce_logits(logits_ptr, count, target, loss_scale, int(acc), self.losses.data_ptr() + 4 * loss_idx,
+                                grad_scale, ctx.dt, dx_ptr, 8, ctx.stream())
+        L.check(rc, "bce_logits")
+
+    def _l1(self, a, b, loss_idx, loss_scale, acc, grad_scale, da):
+        lib, ctx = self.ctx.lib, self.ctx
+        rc = lib.gan_l1(ctx.dt, C.byref(a), C.byref(b), loss_scale, int(acc), self.losses.data_ptr() + 4 * loss_idx,
+                        grad_scale, C.byref(da) if da is not None else None, self.l1_ws.data_ptr(), ctx.stream())
+        L.check(rc, "l1")
+
+    def _pack(self, src_f32, dst_view):
+        L.check(self.ctx.lib.gan_pack(self.ctx.dt, src_f32.data_ptr(), C.byref(dst_view), self.ctx.stream()), "pack")
+
+    def _copy(self, src_view, dst_view):
+        L.check(self.ctx.lib.gan_copy_view(self.ctx.dt, C.byref(src_view), C.byref(dst_view), self.ctx.stream()), "copy_view")
+
+    # ---- hipGraph capture of a whole step --------------------------------------------------------
+    def capture(self, training=True):
+        """Capture one full step on static input buffers; returns a callable replaying it."""
+        self._static_in = [torch.zeros_like(t) for t in self._example_inputs()]
+        torch.cuda.synchronize()
+        s = torch.cuda.Stream(device=self.ctx.device)
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):           # warm-up outside capture (lazy inits, func attributes)
+            self._run(*self._static_in, training=training)
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            self._run(*self._static_in, training=training)
+        self._graph = graph
+
+        def replay(*inputs):
+            for dst, src in zip(self._static_in, inputs):
+                if src is not dst:
+                    dst.copy_(src, non_blocking=True)
+            graph.replay()
+            return self.losses
+        return replay
+
+
+class Pix2PixStep(_StepBase):
+    def __init__(self, ctx: Ctx, batch, size, channels=1, lam=100.0, lr=2e-4, beta_1=0.5, beta_2=0.999,
+                 seed=123, dropout=True):
+        self.ctx, self.B, self.S, self.C = ctx, batch, size, channels
+        self.lam, self.lr, self.b1, self.b2 = float(lam), lr, beta_1, beta_2
+        self.G = GeneratorNet(ctx, channels, 'batchnorm', seed=seed)          # pix2pix.py:29
+        self.D = DiscriminatorNet(ctx, channels, True, 'batchnorm', seed=seed + 1)   # pix2pix.py:30
+        self.g = self.G.new_call(batch, size, dropout=dropout, seed=seed)
+        self.d = self.D.new_call(batch, size, calls=2)
+        self.losses = torch.zeros(8, dtype=torch.float32, device=ctx.device)
+        self.l1_ws = torch.zeros(4096, dtype=torch.float32, device=ctx.device)
+        self.grad_hook = None        # set by the data-parallel wrapper: called between backward and Adam
+
+    def _example_inputs(self):
+        sh = (self.B, self.S, self.S, self.C)
+        return [torch.zeros(sh, dtype=torch.float32, device=self.ctx.device) for _ in range(2)]
+
+    def _run(self, inp, tar, training=True):
+        B, Cc, g, d = self.B, self.C, self.g, self.d
+        # inputs -> typed, channel-padded buffers.  D input = concat([inp, tar|gen]) (base_gan.py:139)
+        self._pack(inp, g.xin.view(0, Cc))
+        self._pack(inp, d.xin.view(0, Cc, 0, B))
+        self._pack(inp, d.xin.view(0, Cc, B, B))
+        self._pack(tar, d.xin.view(Cc, Cc, 0, B))
+        g.forward()                                                   # pix2pix.py:200
+        self._copy(g.out_view(), d.xin.view(Cc, Cc, B, B))
+        d.forward()                                                   # pix2pix.py:202-203 (real ++ fake)
+        real_ptr, cnt = d.logits_view(0)
+        fake_ptr, _ = d.logits_view(1)
+        # generator loss (pix2pix.py:167-188): BCE(1, D(fake)) + lambda * mean|target - gen|
+        self._bce(fake_ptr, cnt, 1.0, 1, 1.0, False, 1.0, d.dlogits_b.t.data_ptr())
+        self._l1(g.out_view(), d.xin.view(Cc, Cc, 0, B), 2, 1.0, False, self.lam, g.dgen.view(0, Cc))
+        self.losses[0:1] = self.losses[1:2] + self.lam * self.losses[2:3]
+        # discriminator loss (base_gan.py:233-245, factor 0.5 at pix2pix.py:206)
+        self._bce(real_ptr, cnt, 1.0, 3, 0.5, False, 0.5, d.dlogits_ptr(0))
+        self._bce(fake_ptr, cnt, 0.0, 3, 0.5, True, 0.5, d.dlogits_ptr(1))
+        if training:
+            d.backward_input(1)                                       # dL_G/d gen through D(fake), pre-update D
+            self._copy(d.dxin.view(Cc, Cc), g.dgen2.view(0, Cc))
+            g.backward(use_dgen2=True)                                # pix2pix.py:210
+            d.backward_params()                                       # pix2pix.py:211
+            if self.grad_hook is not None:
+                self.grad_hook()
+            self.G.params.adam(self.lr, self.b1, self.b2)             # pix2pix.py:213-216
+            self.D.params.adam(self.lr, self.b1, self.b2)
+        return self.losses
+
+    def train_step(self, input_image, target, training=True):
+        """(gen_total_loss, gen_gan_loss, gen_l1_loss, disc_loss) as a 4-element device tensor view."""
+        return self._run(input_image, target, training)[:4]
+
+
+class CycleGANStep(_StepBase):
+    def __init__(self, ctx: Ctx, batch, size, channels=1, lam=10.0, lr=2e-4, beta_1=0.5, beta_2=0.999,
+                 seed=123, dropout=True):
+        self.ctx, self.B, self.S, self.C = ctx, batch, size, channels
+        self.lam, self.lr, self.b1, self.b2 = float(lam), lr, beta_1, beta_2
+        n = 'instancenorm'                                                    # cycle_gan.py:30-33
+        self.Gg = GeneratorNet(ctx, channels, n, seed=seed)
+        self.Gf = GeneratorNet(ctx, channels, n, seed=seed + 1)
+        self.Dx = DiscriminatorNet(ctx, channels, False, n, seed=seed + 2)
+        self.Dy = DiscriminatorNet(ctx, channels, False, n, seed=seed + 3)
+        mk = lambda net, sid: net.new_call(batch, size, dropout=dropout, seed=seed, stream_id=sid)
+        self.fy, self.cx = mk(self.Gg, 0), mk(self.Gf, 1)      # fake_y = G_g(x); cycled_x = G_f(fake_y)
+        self.fx, self.cy = mk(self.Gf, 2), mk(self.Gg, 3)      # fake_x = G_f(y); cycled_y = G_g(fake_x)
+        self.sx, self.sy = mk(self.Gf, 4), mk(self.Gg, 5)      # same_x = G_f(x); same_y = G_g(y)
+        self.dx = self.Dx.new_call(batch, size, calls=2)       # D_x(real_x) ++ D_x(fake_x)
+        self.dy = self.Dy.new_call(batch, size, calls=2)
+        self.losses = torch.zeros(12, dtype=torch.float32, device=ctx.device)
+        self.l1_ws = torch.zeros(4096, dtype=torch.float32, device=ctx.device)
+        self.grad_hook = None
+
+    def gen_calls(self):
+        return dict(fake_y=self.fy, cycled_x=self.cx, fake_x=self.fx, cycled_y=self.cy, same_x=self.sx, same_y=self.sy)
+
+    def _example_inputs(self):
+        sh = (self.B, self.S, self.S, self.C)
+        return [torch.zeros(sh, dtype=torch.float32, device=self.ctx.device) for _ in range(2)]
+
+    def _run(self, real_x, real_y, training=True):
+        B, Cc, lam = self.B, self.C, self.lam
+        fy, cx, fx, cy, sx, sy, dx, dy = self.fy, self.cx, self.fx, self.cy, self.sx, self.sy, self.dx, self.dy
+        self._pack(real_x, fy.xin.view(0, Cc)); self._pack(real_x, sx.xin.view(0, Cc)); self._pack(real_x, dx.xin.view(0, Cc, 0, B))
+        self._pack(real_y, fx.xin.view(0, Cc)); self._pack(real_y, sy.xin.view(0, Cc)); self._pack(real_y, dy.xin.view(0, Cc, 0, B))
+        fy.forward()                                                  # cycle_gan.py:220
+        self._copy(fy.out_view(), cx.xin.view(0, Cc)); self._copy(fy.out_view(), dy.xin.view(0, Cc, B, B))
+        cx.forward()                                                  # :221
+        fx.forward()                                                  # :223
+        self._copy(fx.out_view(), cy.xin.view(0, Cc)); self._copy(fx.out_view(), dx.xin.view(0, Cc, B, B))
+        cy.forward()                                                  # :224
+        sx.forward(); sy.forward()                                    # :227-228
+        dx.forward(); dy.forward()                                    # :230-234
+        rx_ptr, cnt = dx.logits_view(0); fxl_ptr, _ = dx.logits_view(1)
+        ry_ptr, _ = dy.logits_view(0); fyl_ptr, _ = dy.logits_view(1)
+        xv, yv = fy.xin.view(0, Cc), fx.xin.view(0, Cc)               # typed real_x / real_y
+        self._bce(fyl_ptr, cnt, 1.0, 0, 1.0, False, 1.0, dy.dlogits_b.t.data_ptr())      # gen_g_loss :237
+        self._bce(fxl_ptr, cnt, 1.0, 1, 1.0, False, 1.0, dx.dlogits_b.t.data_ptr())      # gen_f_loss :238
+        self._l1(cx.out_view(), xv, 2, lam, False, lam, cx.dgen.view(0, Cc))              # total_cycle_loss :240
+        self._l1(cy.out_view(), yv, 2, lam, True, lam, cy.dgen.view(0, Cc))
+        self._l1(sy.out_view(), yv, 7, lam * 0.5, False, lam * 0.5, sy.dgen.view(0, Cc))  # identity :243
+        self._l1(sx.out_view(), xv, 8, lam * 0.5, False, lam * 0.5, sx.dgen.view(0, Cc))  # identity :244
+        self.losses[3:4] = self.losses[0:1] + self.losses[2:3] + self.losses[7:8]
+        self.losses[4:5] = self.losses[1:2] + self.losses[2:3] + self.losses[8:9]
+        self._bce(rx_ptr, cnt, 1.0, 5, 0.5, False, 0.5, dx.dlogits_ptr(0))                # disc_x_loss :246
+        self._bce(fxl_ptr, cnt, 0.0, 5, 0.5, True, 0.5, dx.dlogits_ptr(1))
+        self._bce(ry_ptr, cnt, 1.0, 6, 0.5, False, 0.5, dy.dlogits_ptr(0))                # disc_y_loss :247
+        self._bce(fyl_ptr, cnt, 0.0, 6, 0.5, True, 0.5, dy.dlogits_ptr(1))
+        if training:
+            # cycle terms: backward through the second generator of each cycle yields BOTH its parameter
+            # gradients and the gradient w.r.t. fake_y / fake_x (computed once, used twice)
+            cx.backward(need_dx=True, accumulate=False)               # G_f grads (cycle_x), d/d fake_y
+            cy.backward(need_dx=True, accumulate=False)               # G_g grads (cycle_y), d/d fake_x
+            dy.backward_input(1)                                      # adversarial term through D_y(fake_y)
+            self._copy(dy.dxin.view(0, Cc), fy.dgen.view(0, Cc)); self._copy(cx.dxin.view(0, Cc), fy.dgen2.view(0, Cc))
+            fy.backward(use_dgen2=True, accumulate=True)              # G_g
+            dx.backward_input(1)
+            self._copy(dx.dxin.view(0, Cc), fx.dgen.view(0, Cc)); self._copy(cy.dxin.view(0, Cc), fx.dgen2.view(0, Cc))
+            fx.backward(use_dgen2=True, accumulate=True)              # G_f
+            sy.backward(accumulate=True)                              # identity_y -> G_g
+            sx.backward(accumulate=True)                              # identity_x -> G_f
+            dx.backward_params(); dy.backward_params()                # :257-260
+            if self.grad_hook is not None:
+                self.grad_hook()
+            for net in (self.Gg, self.Gf, self.Dx, self.Dy):          # :263-273
+                net.params.adam(self.lr, self.b1, self.b2)
+        return self.losses
+
+    def train_step(self, real_x, real_y, training=True):
+        """7 losses in the reference's order (cycle_gan.py:275-276)."""
+        return self._run(real_x, real_y, training)[:7]

@@ -1,0 +1,195 @@
+/* gan_amd.h — C ABI of the MI355X (gfx950) Pix2Pix / CycleGAN training hot path.
+ *
+ * The reference (kingjosephm/GAN) has no FFI / plugin interface: its hot path is Python calling
+ * tf.keras layers.  Each entry point below replaces one Keras layer invocation
+ * (or its autodiff counterpart) that the reference instantiates; the reference file:line it
+ * replaces is cited per function.  INTEGRATION.md shows the ctypes binding a maintainer would add.
+ *
+ * Conventions
+ *  - plain C, raw device pointers, POD structs; no torch / hip types in signatures
+ *    (gan_stream_t is a hipStream_t passed as void*).
+ *  - every call only ENQUEUES work on `stream` (hipGraph-capturable, no allocation, no sync).
+ *  - return: 0 ok; <0 invalid argument / unsupported shape (GAN_E_*); >0 a hipError_t.
+ *  - activations NHWC; a GanTensor may be a channel slice of a wider buffer (pitch > c), which is
+ *    how skip-concat (base_gan.py:206,221) and the discriminator input concat (base_gan.py:139)
+ *    are realised without a copy.
+ *  - dtype GAN_F32: fp32 storage, exact-fp32 MFMA (v_mfma_f32_16x16x4_f32) — the parity path.
+ *    dtype GAN_BF16: bf16 storage, v_mfma_f32_16x16x32_bf16, fp32 accumulate — the fast path.
+ *  - convolution weights are consumed in "NK" layout [16 taps][rows][k] (k contiguous), produced
+ *    from the fp32 Keras-layout master by gan_weights_prepare().
+ */
+#ifndef GAN_AMD_H
+#define GAN_AMD_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* gan_stream_t;
+
+enum { GAN_F32 = 0, GAN_BF16 = 1 };
+enum { GAN_ACT_NONE = 0, GAN_ACT_LRELU = 1, GAN_ACT_RELU = 2, GAN_ACT_TANH = 3 };
+enum { GAN_E_ARG = -1, GAN_E_SHAPE = -2, GAN_E_WORKSPACE = -3 };
+
+typedef struct GanTensor {
+  void* ptr;          /* element (n=0,h=0,w=0,channel 0 of this view) */
+  int32_t n, h, w, c; /* c: channels the op touches */
+  int32_t pitch;      /* elements between consecutive pixels (>= c) */
+} GanTensor;
+
+/* ---- convolutions ------------------------------------------------------------------------- */
+typedef struct GanConvDesc {
+  int32_t dtype;
+  int32_t stride;        /* Conv2D: 1 or 2 (k4, zero pad 1 each side); Conv2DTranspose: 2 */
+  GanTensor x;           /* GEMM-K side tensor; x.c must be a multiple of 8 (zero-padded channels) */
+  GanTensor y;           /* produced tensor; y.c = channels written (pitch may be larger) */
+  const void* w;         /* NK weights [16][w_rows][x.c], dtype */
+  int32_t w_rows;        /* >= y.c */
+  const float* bias;     /* optional [y.c] */
+  int32_t act;           /* epilogue activation (GAN_ACT_*) applied after bias */
+  float slope;           /* LeakyReLU alpha */
+  int32_t y_f32;         /* 1: write y as fp32 whatever dtype is (used for logits) */
+  void* workspace;       /* split-K slabs; size from gan_conv_workspace_bytes() */
+  size_t workspace_bytes;
+} GanConvDesc;
+
+/* Conv2D(k4, strides=s, no bias | bias) — base_gan.py:77-79 ('same', s=2), :145-148 and :157-161
+ * (ZeroPadding2D + 'valid', s=1).  w = prepared from HWIO master with gan_weights_prepare(transposed). */
+int gan_conv2d_fwd(const GanConvDesc* d, gan_stream_t stream);
+/* Gradient of the above w.r.t. its input (tf.GradientTape, pix2pix.py:210-211): x := dy, y := dx,
+ * w = native NK copy of the HWIO master ([tap][cin][cout]). */
+int gan_conv2d_dgrad(const GanConvDesc* d, gan_stream_t stream);
+/* Conv2DTranspose(k4, strides=2, 'same') — base_gan.py:106-110, :201-204 (bias + tanh head).
+ * w = native NK copy of the (kh,kw,cout,cin) master. */
+int gan_convT2d_fwd(const GanConvDesc* d, gan_stream_t stream);
+/* Gradient of Conv2DTranspose w.r.t. its input: x := dy (2h x 2w), y := dx (h x w),
+ * w = transposed NK copy ([tap][cin][cout]). */
+int gan_convT2d_dgrad(const GanConvDesc* d, gan_stream_t stream);
+size_t gan_conv_workspace_bytes(const GanConvDesc* d, int op /*0 conv_fwd,1 conv_dgrad,2 convT_fwd,3 convT_dgrad*/);
+
+typedef struct GanWgradDesc {
+  int32_t dtype;
+  int32_t stride;        /* 1 or 2 */
+  GanTensor big;         /* tensor on the fine grid  (Conv2D: layer input x;  Conv2DTranspose: dy) */
+  GanTensor small;       /* tensor on the coarse grid (Conv2D: dy;            Conv2DTranspose: layer input x) */
+  float* dw;             /* fp32 [16][big_c][small_c]: HWIO for Conv2D, (kh,kw,cout,cin) for Conv2DTranspose */
+  int32_t big_c, small_c;/* real channel counts written (<= big.c, small.c which are 8-padded) */
+  int32_t accumulate;    /* 1: dw += result (a net called several times per step, cycle_gan.py:252-255) */
+  void* workspace;
+  size_t workspace_bytes;
+} GanWgradDesc;
+/* Kernel gradient of Conv2D / Conv2DTranspose (GradientTape.gradient w.r.t. trainable_variables,
+ * pix2pix.py:210-211, cycle_gan.py:252-260). */
+int gan_conv_wgrad(const GanWgradDesc* d, gan_stream_t stream);
+size_t gan_wgrad_workspace_bytes(const GanWgradDesc* d);
+
+/* Produce typed NK copies from a fp32 Keras-layout master [16][A][B]:
+ * nk_native [16][A][pad8(B)] and nk_transposed [16][B][pad8(A)] (either may be NULL). */
+int gan_weights_prepare(const float* master, int32_t A, int32_t B, int32_t dtype,
+                        void* nk_native, void* nk_transposed, gan_stream_t stream);
+
+/* ---- normalisation + activation ------------------------------------------------------------- */
+typedef struct GanNormDesc {
+  int32_t dtype;
+  GanTensor y;              /* raw convolution output */
+  GanTensor a;              /* out: act(dropout(gamma * (y - mean) * rstd + beta)) */
+  int32_t groups;           /* statistics groups over the batch dimension: 1 = BatchNormalization over the
+                               whole batch (base_gan.py:83,113,151); y.n = InstanceNormalization
+                               (utils.py:26-30); 2 = two BatchNormalization calls (D(real), D(fake),
+                               pix2pix.py:202-203) batched into one launch */
+  float eps;                /* 1e-3 Keras BN default; 1e-5 utils.py:9 */
+  const float* gamma;       /* [c] gamma / scale */
+  const float* beta;        /* [c] beta / offset */
+  float* mean;              /* [groups][c] */
+  float* rstd;              /* [groups][c] */
+  float* moving_mean;       /* optional [c]: BN moving averages, updated once per group in order */
+  float* moving_var;
+  float momentum;           /* 0.99 */
+  const uint8_t* dropmask;  /* optional [n*h*w*c] 0/1; survivors x2 (Dropout(0.5), base_gan.py:117-118) */
+  int32_t act;
+  float slope;
+  void* workspace;          /* >= gan_norm_workspace_bytes() */
+  size_t workspace_bytes;
+} GanNormDesc;
+int gan_norm_stats(const GanNormDesc* d, gan_stream_t stream);
+int gan_norm_act_fwd(const GanNormDesc* d, gan_stream_t stream);
+size_t gan_norm_workspace_bytes(int32_t groups, int32_t c, int64_t rows_per_group);
+
+typedef struct GanNormBwdDesc {
+  int32_t dtype;
+  GanTensor y;              /* raw convolution output saved by forward */
+  GanTensor da;             /* upstream gradient w.r.t. a */
+  GanTensor da2;            /* optional second upstream (ptr NULL if absent): skip-connection gradient */
+  GanTensor dy;             /* out: gradient w.r.t. y */
+  int32_t groups;
+  const float* gamma;
+  const float* beta;
+  const float* mean;
+  const float* rstd;
+  const uint8_t* dropmask;
+  int32_t act;
+  float slope;
+  float* dgamma;            /* optional [c] */
+  float* dbeta;
+  int32_t accumulate;       /* dgamma/dbeta += */
+  void* workspace;
+  size_t workspace_bytes;
+} GanNormBwdDesc;
+int gan_norm_act_bwd(const GanNormBwdDesc* d, gan_stream_t stream);
+
+typedef struct GanActBwdDesc { /* layers without normalisation: conv -> [bias] -> act */
+  int32_t dtype;
+  GanTensor a;              /* saved activation output (sign for LeakyReLU, value for tanh) */
+  GanTensor da;
+  GanTensor da2;            /* optional */
+  GanTensor dy;             /* out */
+  int32_t act;
+  float slope;
+  float* dbias;             /* optional [c] (sum of dy over n,h,w) */
+  int32_t accumulate;
+  void* workspace;
+  size_t workspace_bytes;
+} GanActBwdDesc;
+int gan_act_bwd(const GanActBwdDesc* d, gan_stream_t stream);
+
+/* ---- losses --------------------------------------------------------------------------------- */
+/* tf.keras.losses.BinaryCrossentropy(from_logits=True) against a constant target (base_gan.py:227-245).
+ * x: fp32 logits [count]. loss_out[0] (+)= loss_scale * mean(bce). If dx != NULL:
+ * dx[i*dx_pitch] = grad_scale * (sigmoid(x)-target)/count in `dtype`. */
+int gan_bce_logits(const float* x, int64_t count, float target, float loss_scale, int32_t loss_accumulate,
+                   float* loss_out, float grad_scale, int32_t dtype, void* dx, int32_t dx_pitch,
+                   gan_stream_t stream);
+/* tf.reduce_mean(tf.abs(a - b)) (pix2pix.py:181, cycle_gan.py:167,176). loss_out (+)= loss_scale*mean.
+ * da (optional, dtype, own pitch) = grad_scale * sign(a-b)/count. workspace >= 4096 floats. */
+int gan_l1(int32_t dtype, const GanTensor* a, const GanTensor* b, float loss_scale, int32_t loss_accumulate,
+           float* loss_out, float grad_scale, const GanTensor* da, float* workspace, gan_stream_t stream);
+
+/* ---- optimiser ------------------------------------------------------------------------------ */
+/* tf.keras.optimizers.Adam (base_gan.py:247-252), TF form: lr_t = lr*sqrt(1-b2^t)/(1-b1^t);
+ * m += (g-m)(1-b1); v += (g*g-v)(1-b2); p -= lr_t*m/(sqrt(v)+eps).  `step` is a device counter:
+ * gan_adam_begin increments it and writes lr_t, so a captured graph advances correctly on replay. */
+int gan_adam_begin(int32_t* step, float* lr_t, float lr, float beta1, float beta2, gan_stream_t stream);
+int gan_adam_tf(float* param, float* m, float* v, const float* grad, int64_t count, const float* lr_t,
+                float beta1, float beta2, float eps, float grad_scale, gan_stream_t stream);
+
+/* ---- misc ----------------------------------------------------------------------------------- */
+/* Bernoulli(0.5) keep-mask from a counter hash of (seed, *step, stream_id, index). */
+int gan_dropout_mask(uint8_t* mask, int64_t count, uint64_t seed, const int32_t* step, uint32_t stream_id,
+                     gan_stream_t stream);
+/* dst(dtype, pitch view) <- src fp32 dense [n,h,w,c]  /  dst fp32 dense <- src(dtype, pitch view) */
+int gan_pack(int32_t dtype, const float* src, const GanTensor* dst, gan_stream_t stream);
+int gan_unpack(int32_t dtype, const GanTensor* src, float* dst, gan_stream_t stream);
+/* typed view -> typed view (same n,h,w,c; pitches / channel offsets may differ): places the generator
+ * output into the discriminator's concat input (base_gan.py:139) and routes its gradient back. */
+int gan_copy_view(int32_t dtype, const GanTensor* src, const GanTensor* dst, gan_stream_t stream);
+/* bias gradient: dbias[c] (+)= sum over n,h,w of dy[...,c]; dy.c 8-padded, dbias has dy.c entries.
+ * workspace >= gan_norm_workspace_bytes(1, dy.c, n*h*w). */
+int gan_bias_grad(int32_t dtype, const GanTensor* dy, float* dbias, int32_t accumulate, void* workspace,
+                  size_t workspace_bytes, gan_stream_t stream);
+const char* gan_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,387 @@
+"""GPU parity of every C-ABI op against the CPU oracle (same seeded inputs), fp32 (exact-MFMA parity path)
+and bf16 (fast path).  Calls go through the C ABI (ctypes), never through a torch op."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import gan_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+TOL = {'f32': 2e-5, 'bf16': 2.5e-2}   # max-abs error relative to max|ref|
+
+
+@pytest.fixture(scope="module", params=['f32', 'bf16'])
+def ctx(request):
+    from gan_amd.nets import Ctx
+    return Ctx('cuda:0', request.param)
+
+
+def rel(a, b):
+    return float(np.abs(a.astype(np.float64) - b).max() / (np.abs(b).max() + 1e-30))
+
+
+def dev(ctx, x, pitch=None, c0=0):
+    """numpy NHWC -> Buf with `pitch` channels, data at [c0, c0+c); returns (buf, view)."""
+    from gan_amd.nets import Buf
+    n, h, w, c = x.shape
+    pitch = pitch or ((c + 7) // 8 * 8)
+    b = Buf(ctx, n, h, w, pitch)
+    b.t[..., c0:c0 + c] = torch.from_numpy(np.ascontiguousarray(x)).to(b.t.dtype).to(ctx.device)
+    return b, b.view(c0, c)
+
+
+def host(buf, c0=0, c=None):
+    c = buf.c - c0 if c is None else c
+    return buf.t[..., c0:c0 + c].float().cpu().numpy().astype(np.float64)
+
+
+def q(ctx, x):
+    """round inputs to the storage dtype so the oracle sees what the kernel sees"""
+    if ctx.dtype == 'bf16':
+        return torch.from_numpy(x.astype(np.float32)).to(torch.bfloat16).float().numpy().astype(np.float64)
+    return x.astype(np.float32).astype(np.float64)
+
+
+def prep(ctx, w):
+    """fp32 Keras-layout kernel (4,4,A,B) -> (nat [16,A,B8], tr [16,B,A8]) typed device tensors"""
+    A, B = w.shape[2], w.shape[3]
+    m = torch.from_numpy(np.ascontiguousarray(w, dtype=np.float32)).to(ctx.device)
+    nat = torch.zeros((16, A, (B + 7) // 8 * 8), dtype=ctx.tdtype, device=ctx.device)
+    tr = torch.zeros((16, B, (A + 7) // 8 * 8), dtype=ctx.tdtype, device=ctx.device)
+    rc = ctx.lib.gan_weights_prepare(m.data_ptr(), A, B, ctx.dt, nat.data_ptr(), tr.data_ptr(), ctx.stream())
+    assert rc == 0
+    torch.cuda.synchronize()
+    return nat, tr
+
+
+def conv_call(ctx, op, x, y, w, w_rows, stride=2, bias=None, act=0, y_f32=0):
+    from gan_amd import _lib as L
+    d = L.GanConvDesc(ctx.dt, stride, x, y, w.data_ptr(), w_rows, bias.data_ptr() if bias is not None else None, act, 0.3,
+                      y_f32, ctx.ws_ptr, ctx.ws_bytes)
+    fn = getattr(ctx.lib, {'conv_fwd': 'gan_conv2d_fwd', 'conv_dgrad': 'gan_conv2d_dgrad', 'convT_fwd': 'gan_convT2d_fwd',
+                           'convT_dgrad': 'gan_convT2d_dgrad'}[op])
+    rc = fn(C.byref(d), ctx.stream())
+    assert rc == 0, (op, rc)
+    torch.cuda.synchronize()
+
+
+CONV_CASES = [  # (N, H, Cin, Cout, stride)
+    (2, 16, 1, 64, 2),      # first layer, C=1 padded to 8 (K = 128)
+    (2, 16, 6, 64, 2),      # D first layer C=3 target=True
+    (3, 16, 64, 128, 2),
+    (2, 8, 128, 256, 2),
+    (16, 2, 512, 512, 2),   # bottleneck: M = 16, split-K, BM=16
+    (4, 4, 512, 512, 2),    # M = 16
+    (2, 32, 256, 512, 1),   # D conv4: 32 -> 31
+    (2, 31, 512, 1, 1),     # D last: 31 -> 30, Cout = 1
+    (1, 64, 64, 128, 2),    # M = 1024
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d_fwd_dgrad_wgrad(ctx, case):
+    from gan_amd import _lib as L
+    from gan_amd.nets import Buf
+    N, H, ci, co, s = case
+    rng = np.random.default_rng(hash(case) % 2**31)
+    x = q(ctx, rng.standard_normal((N, H, H, ci)))
+    w = q(ctx, 0.05 * rng.standard_normal((4, 4, ci, co)))
+    bias = rng.standard_normal(co).astype(np.float32) if co == 1 else None
+    Ho = (H + 2 - 4) // s + 1
+    ci8 = (ci + 7) // 8 * 8
+    xb, _ = dev(ctx, x, pitch=ci8 + 8)               # pitch > c: exercises channel-slice views
+    xv = xb.view(0, ci8)
+    nat, tr = prep(ctx, w)
+    # forward (bias + fp32 output for the Cout=1 logits layer; fused LeakyReLU otherwise)
+    yb = Buf(ctx, N, Ho, Ho, (co + 7) // 8 * 8 + 8, torch.float32 if co == 1 else None)
+    bt = torch.from_numpy(bias).to(ctx.device) if bias is not None else None
+    act = 0 if co == 1 else L.ACT_LRELU
+    conv_call(ctx, 'conv_fwd', xv, yb.view(8, co), tr, co, s, bt, act, 1 if co == 1 else 0)
+    ref = O.conv2d_fwd(x, w, s)
+    if bias is not None:
+        ref = ref + bias
+    else:
+        ref = O.act_fwd(ref, 'lrelu')
+    assert rel(host(yb, 8, co), ref) < TOL[ctx.dtype]
+    assert np.all(host(yb, 0, 8) == 0)               # neighbouring channels untouched
+    # dgrad / wgrad
+    dy = q(ctx, rng.standard_normal((N, Ho, Ho, co)))
+    dyb, dyv = dev(ctx, dy)
+    dyv = dyb.view(0, (co + 7) // 8 * 8)
+    dxb = Buf(ctx, N, H, H, ci8)
+    conv_call(ctx, 'conv_dgrad', dyv, dxb.view(0, ci), nat, ci, s)
+    dx_ref, dw_ref = O.conv2d_bwd(x, w, dy, s)
+    assert rel(host(dxb, 0, ci), dx_ref) < TOL[ctx.dtype]
+    dw = torch.full((16, ci, co), 7.0, dtype=torch.float32, device=ctx.device)
+    d = L.GanWgradDesc(ctx.dt, s, xv, dyv, dw.data_ptr(), ci, co, 0, ctx.ws_ptr, ctx.ws_bytes)
+    assert ctx.lib.gan_conv_wgrad(C.byref(d), ctx.stream()) == 0
+    torch.cuda.synchronize()
+    assert rel(dw.cpu().numpy().reshape(4, 4, ci, co), dw_ref) < TOL[ctx.dtype]
+    d.accumulate = 1                                  # dw += (cycle_gan: a net called several times)
+    assert ctx.lib.gan_conv_wgrad(C.byref(d), ctx.stream()) == 0
+    torch.cuda.synchronize()
+    assert rel(dw.cpu().numpy().reshape(4, 4, ci, co), 2 * dw_ref) < TOL[ctx.dtype]
+
+
+CONVT_CASES = [  # (N, h, Cin, Cout)
+    (16, 1, 512, 512),      # up0 at 256: 1x1 -> 2x2
+    (2, 4, 1024, 512),
+    (2, 16, 512, 128),
+    (2, 32, 256, 64),
+    (2, 32, 128, 1),        # head: Cout = 1, bias + tanh
+    (1, 16, 128, 3),        # head, 3 channels
+]
+
+
+@pytest.mark.parametrize("case", CONVT_CASES)
+def test_convT2d_fwd_dgrad_wgrad(ctx, case):
+    from gan_amd import _lib as L
+    from gan_amd.nets import Buf
+    N, h, ci, co = case
+    rng = np.random.default_rng(hash(case) % 2**31)
+    x = q(ctx, rng.standard_normal((N, h, h, ci)))
+    w = q(ctx, 0.05 * rng.standard_normal((4, 4, co, ci)))
+    head = co < 8
+    bias = (0.1 * rng.standard_normal(co)).astype(np.float32) if head else None
+    xb, xv = dev(ctx, x)
+    nat, tr = prep(ctx, w)
+    co8 = (co + 7) // 8 * 8
+    yb = Buf(ctx, N, 2 * h, 2 * h, co8)
+    bt = torch.from_numpy(bias).to(ctx.device) if head else None
+    conv_call(ctx, 'convT_fwd', xv, yb.view(0, co), nat, co, 2, bt, L.ACT_TANH if head else 0)
+    ref = O.convT2d_fwd(x, w)
+    if head:
+        ref = np.tanh(ref + bias)
+    assert rel(host(yb, 0, co), ref) < TOL[ctx.dtype]
+    dy = q(ctx, rng.standard_normal((N, 2 * h, 2 * h, co)))
+    dyb, _ = dev(ctx, dy)
+    dyv = dyb.view(0, co8)
+    dxb = Buf(ctx, N, h, h, ci)
+    conv_call(ctx, 'convT_dgrad', dyv, dxb.view(), tr, ci, 2)
+    dx_ref, dw_ref = O.convT2d_bwd(x, w, dy)
+    assert rel(host(dxb), dx_ref) < TOL[ctx.dtype]
+    dw = torch.zeros((16, co, ci), dtype=torch.float32, device=ctx.device)
+    d = L.GanWgradDesc(ctx.dt, 2, dyv, xv, dw.data_ptr(), co, ci, 0, ctx.ws_ptr, ctx.ws_bytes)
+    assert ctx.lib.gan_conv_wgrad(C.byref(d), ctx.stream()) == 0
+    torch.cuda.synchronize()
+    assert rel(dw.cpu().numpy().reshape(4, 4, co, ci), dw_ref) < TOL[ctx.dtype]
+
+
+def test_wgrad_tr_read_matches_plain(ctx, monkeypatch):
+    """bf16 wgrad fragments come from ds_read_b64_tr_b16; fp32 from ds_read_b32.  Exact integer data with an
+    asymmetric pattern catches any row/column mix-up in the transposing read."""
+    from gan_amd import _lib as L
+    N, H, ci, co = 1, 16, 64, 128
+    x = np.zeros((N, H, H, ci))
+    dy = np.zeros((N, H // 2, H // 2, co))
+    rng = np.random.default_rng(5)
+    x[:] = rng.integers(-3, 4, x.shape)
+    dy[:] = rng.integers(-3, 4, dy.shape)
+    xb, xv = dev(ctx, x)
+    dyb, dyv = dev(ctx, dy)
+    dw = torch.zeros((16, ci, co), dtype=torch.float32, device=ctx.device)
+    d = L.GanWgradDesc(ctx.dt, 2, xv, dyv, dw.data_ptr(), ci, co, 0, ctx.ws_ptr, ctx.ws_bytes)
+    assert ctx.lib.gan_conv_wgrad(C.byref(d), ctx.stream()) == 0
+    torch.cuda.synchronize()
+    _, ref = O.conv2d_bwd(x, np.zeros((4, 4, ci, co)), dy, 2, need_dx=False)
+    assert np.array_equal(dw.cpu().numpy().reshape(4, 4, ci, co), ref)    # small integers: exact in bf16 and fp32
+
+
+@pytest.mark.parametrize("kind,groups_of", [('batchnorm', lambda n: 1), ('batchnorm', lambda n: 2), ('instancenorm', lambda n: n)])
+@pytest.mark.parametrize("act,drop", [('lrelu', False), ('relu', True)])
+def test_norm_act_fwd_bwd(ctx, kind, groups_of, act, drop):
+    from gan_amd import _lib as L
+    from gan_amd.nets import Buf
+    N, H, c = 4, 8, 64
+    G = groups_of(N)
+    rng = np.random.default_rng(3)
+    y = q(ctx, rng.standard_normal((N, H, H, c)) * 1.5 + 0.3)
+    gamma = (1 + 0.2 * rng.standard_normal(c)).astype(np.float32)
+    beta = (0.2 * rng.standard_normal(c)).astype(np.float32)
+    mask = (rng.random((N, H, H, c)) > 0.5).astype(np.float64) if drop else None
+    eps = 1e-3 if kind == 'batchnorm' else 1e-5
+    yb, yv = dev(ctx, y)
+    ab = Buf(ctx, N, H, H, c + 64)
+    f32 = torch.float32
+    tg, tb = torch.from_numpy(gamma).to(ctx.device), torch.from_numpy(beta).to(ctx.device)
+    mean, rstd = torch.zeros(G * c, dtype=f32, device=ctx.device), torch.zeros(G * c, dtype=f32, device=ctx.device)
+    mm, mv = torch.zeros(c, dtype=f32, device=ctx.device), torch.ones(c, dtype=f32, device=ctx.device)
+    tm = torch.from_numpy(mask.astype(np.uint8)).to(ctx.device) if drop else None
+    bn = kind == 'batchnorm'
+    d = L.GanNormDesc(ctx.dt, yv, ab.view(64, c), G, eps, tg.data_ptr(), tb.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                      mm.data_ptr() if bn else None, mv.data_ptr() if bn else None, 0.99, tm.data_ptr() if drop else None,
+                      L.ACTS[act], 0.3, ctx.ws_ptr, ctx.ws_bytes)
+    assert ctx.lib.gan_norm_stats(C.byref(d), ctx.stream()) == 0
+    assert ctx.lib.gan_norm_act_fwd(C.byref(d), ctx.stream()) == 0
+    torch.cuda.synchronize()
+    # oracle: groups == separate calls on batch slices
+    gs = N // G
+    refs, caches = [], []
+    st = {}
+    for g in range(G):
+        sl = slice(g * gs, (g + 1) * gs)
+        P = {'l.gamma': gamma.astype(np.float64), 'l.beta': beta.astype(np.float64), 'l.scale': gamma.astype(np.float64),
+             'l.offset': beta.astype(np.float64)}
+        if kind == 'batchnorm':
+            z, cache = O.norm_fwd(y[sl], P['l.gamma'], P['l.beta'], kind)
+            n = gs * H * H
+            mu, var = cache[2].reshape(-1), cache[3].reshape(-1)
+            st.setdefault('mm', np.zeros(c)); st.setdefault('mv', np.ones(c))
+            st['mm'] += (mu - st['mm']) * 0.01
+            st['mv'] += (var * n / (n - 1) - st['mv']) * 0.01
+        else:
+            z, cache = O.norm_fwd(y[sl], P['l.scale'], P['l.offset'], kind)
+        zd = z * mask[sl] * 2 if drop else z
+        refs.append(O.act_fwd(zd, act))
+        caches.append((cache, zd))
+    ref = np.concatenate(refs)
+    tol = TOL[ctx.dtype]
+    assert rel(host(ab, 64, c), ref) < tol
+    if bn:
+        assert rel(mm.cpu().numpy(), st['mm']) < 1e-4 and rel(mv.cpu().numpy(), st['mv']) < 1e-4
+    # backward, two upstream gradients
+    da = q(ctx, rng.standard_normal((N, H, H, c)))
+    da2 = q(ctx, rng.standard_normal((N, H, H, c)))
+    dab, dav = dev(ctx, da, pitch=c + 8)
+    da2b, da2v = dev(ctx, da2)
+    dyb = Buf(ctx, N, H, H, c)
+    dg, db = torch.zeros(c, dtype=f32, device=ctx.device), torch.zeros(c, dtype=f32, device=ctx.device)
+    bd = L.GanNormBwdDesc(ctx.dt, yv, dav, da2v, dyb.view(), G, tg.data_ptr(), tb.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                          tm.data_ptr() if drop else None, L.ACTS[act], 0.3, dg.data_ptr(), db.data_ptr(), 0, ctx.ws_ptr, ctx.ws_bytes)
+    assert ctx.lib.gan_norm_act_bwd(C.byref(bd), ctx.stream()) == 0
+    torch.cuda.synchronize()
+    dys, dgs, dbs = [], 0, 0
+    for g in range(G):
+        sl = slice(g * gs, (g + 1) * gs)
+        cache, zd = caches[g]
+        dzd = O.act_bwd(da[sl] + da2[sl], zd, refs[g], act)
+        dz = dzd * mask[sl] * 2 if drop else dzd
+        dy_, dg_, db_ = O.norm_bwd(dz, cache, gamma.astype(np.float64), kind)
+        dys.append(dy_); dgs = dgs + dg_; dbs = dbs + db_
+    assert rel(host(dyb), np.concatenate(dys)) < tol
+    assert rel(dg.cpu().numpy(), dgs) < max(tol, 1e-4) and rel(db.cpu().numpy(), dbs) < max(tol, 1e-4)
+
+
+def test_act_bwd_bias_grad_losses(ctx):
+    from gan_amd import _lib as L
+    from gan_amd.nets import Buf
+    rng = np.random.default_rng(9)
+    N, H = 2, 16
+    # tanh head backward with two upstream gradients
+    a = q(ctx, np.tanh(rng.standard_normal((N, H, H, 1))))
+    da = q(ctx, rng.standard_normal((N, H, H, 1)))
+    da2 = q(ctx, rng.standard_normal((N, H, H, 1)))
+    ab, _ = dev(ctx, a); dab, _ = dev(ctx, da); da2b, _ = dev(ctx, da2)
+    dyb = Buf(ctx, N, H, H, 8)
+    d = L.GanActBwdDesc(ctx.dt, ab.view(), dab.view(), da2b.view(), dyb.view(), L.ACT_TANH, 0.3, None, 0, ctx.ws_ptr, ctx.ws_bytes)
+    assert ctx.lib.gan_act_bwd(C.byref(d), ctx.stream()) == 0
+    dbias = torch.zeros(8, dtype=torch.float32, device=ctx.device)
+    v = dyb.view()
+    assert ctx.lib.gan_bias_grad(ctx.dt, C.byref(v), dbias.data_ptr(), 0, ctx.ws_ptr, ctx.ws_bytes, ctx.stream()) == 0
+    torch.cuda.synchronize()
+    ref = (da + da2) * (1 - a * a)
+    tol = TOL[ctx.dtype]
+    assert rel(host(dyb, 0, 1), ref) < tol
+    assert abs(dbias[0].item() - q(ctx, ref).sum()) < max(tol, 1e-4) * np.abs(ref).sum()
+    assert np.all(dbias[1:].cpu().numpy() == 0)
+    # BCE from logits (+ gradient into an 8-pitch typed buffer)
+    x = (3 * rng.standard_normal((N, 30, 30, 1))).astype(np.float32)
+    xt = torch.from_numpy(x).to(ctx.device)
+    loss = torch.zeros(2, dtype=torch.float32, device=ctx.device)
+    dxb = Buf(ctx, N, 30, 30, 8)
+    for tgt in (1.0, 0.0):
+        rc = ctx.lib.gan_bce_logits(xt.data_ptr(), x.size, tgt, 0.5, 0, loss.data_ptr(), 0.5, ctx.dt, dxb.t.data_ptr(), 8, ctx.stream())
+        assert rc == 0
+        torch.cuda.synchronize()
+        l, g = O.bce_logits(x.astype(np.float64), tgt)
+        assert abs(loss[0].item() - 0.5 * l) < 1e-6 * max(1, abs(l))
+        assert rel(host(dxb, 0, 1), 0.5 * g) < (1e-5 if ctx.dtype == 'f32' else 1e-2)
+    # KAT: BCE(logit 0) = ln 2
+    z = torch.zeros(900, dtype=torch.float32, device=ctx.device)
+    ctx.lib.gan_bce_logits(z.data_ptr(), 900, 1.0, 1.0, 0, loss.data_ptr(), 1.0, ctx.dt, None, 8, ctx.stream())
+    torch.cuda.synchronize()
+    assert abs(loss[0].item() - np.log(2)) < 1e-6
+    # L1 mean + sign gradient, accumulate flag
+    a1 = q(ctx, rng.uniform(-1, 1, (N, H, H, 3))); b1 = q(ctx, rng.uniform(-1, 1, (N, H, H, 3)))
+    a1b, a1v = dev(ctx, a1); b1b, b1v = dev(ctx, b1, pitch=16, c0=3)
+    gb = Buf(ctx, N, H, H, 8)
+    gv = gb.view(0, 3)
+    ws = torch.zeros(4096, dtype=torch.float32, device=ctx.device)
+    loss.zero_(); loss[0] = 1.0
+    rc = ctx.lib.gan_l1(ctx.dt, C.byref(a1v), C.byref(b1v), 2.0, 1, loss.data_ptr(), 100.0, C.byref(gv), ws.data_ptr(), ctx.stream())
+    assert rc == 0
+    torch.cuda.synchronize()
+    l, g = O.l1_mean(a1, b1)
+    assert abs(loss[0].item() - (1.0 + 2.0 * l)) < 1e-5
+    assert rel(host(gb, 0, 3), 100.0 * g) < (1e-6 if ctx.dtype == 'f32' else 1e-2)
+
+
+def test_adam_tf_and_weight_prep(ctx):
+    rng = np.random.default_rng(2)
+    n = 4096
+    p0 = rng.standard_normal(n).astype(np.float32)
+    P = {'w': p0.astype(np.float64).copy()}
+    opt = O.AdamTF(2e-4, 0.5, 0.999)
+    f32 = torch.float32
+    p = torch.from_numpy(p0.copy()).to(ctx.device)
+    m, v = torch.zeros(n, dtype=f32, device=ctx.device), torch.zeros(n, dtype=f32, device=ctx.device)
+    step = torch.zeros(1, dtype=torch.int32, device=ctx.device)
+    lr_t = torch.zeros(1, dtype=f32, device=ctx.device)
+    for it in range(3):
+        g = (rng.standard_normal(n) * 10.0 ** rng.integers(-6, 1, n)).astype(np.float32)
+        gt = torch.from_numpy(g).to(ctx.device)
+        assert ctx.lib.gan_adam_begin(step.data_ptr(), lr_t.data_ptr(), 2e-4, 0.5, 0.999, ctx.stream()) == 0
+        assert ctx.lib.gan_adam_tf(p.data_ptr(), m.data_ptr(), v.data_ptr(), gt.data_ptr(), n, lr_t.data_ptr(), 0.5, 0.999,
+                                   1e-7, 1.0, ctx.stream()) == 0
+        opt.apply(P, {'w': g.astype(np.float64)})
+    torch.cuda.synchronize()
+    assert step.item() == 3
+    assert np.abs(p.cpu().numpy() - P['w']).max() < 1e-6
+    # weight prep layouts
+    w = rng.standard_normal((4, 4, 3, 64)).astype(np.float32)
+    nat, tr = prep(ctx, w)
+    wq = q(ctx, w).reshape(16, 3, 64)
+    assert np.array_equal(nat.float().cpu().numpy(), wq)
+    t = tr.float().cpu().numpy()
+    assert t.shape == (16, 64, 8) and np.array_equal(t[:, :, :3], wq.transpose(0, 2, 1)) and np.all(t[:, :, 3:] == 0)
+
+
+def test_dropout_mask_and_pack(ctx):
+    from gan_amd.nets import Buf
+    step = torch.tensor([5], dtype=torch.int32, device=ctx.device)
+    n = 16 * 8 * 8 * 512
+    m1 = torch.zeros(n, dtype=torch.uint8, device=ctx.device)
+    m2 = torch.zeros(n, dtype=torch.uint8, device=ctx.device)
+    assert ctx.lib.gan_dropout_mask(m1.data_ptr(), n, 123, step.data_ptr(), 0, ctx.stream()) == 0
+    assert ctx.lib.gan_dropout_mask(m2.data_ptr(), n, 123, step.data_ptr(), 1, ctx.stream()) == 0
+    torch.cuda.synchronize()
+    a, b = m1.cpu().numpy(), m2.cpu().numpy()
+    assert set(np.unique(a)) == {0, 1} and abs(a.mean() - 0.5) < 5e-3 and abs((a == b).mean() - 0.5) < 5e-3
+    x = np.random.default_rng(1).uniform(-1, 1, (2, 8, 8, 3)).astype(np.float32)
+    xt = torch.from_numpy(x).to(ctx.device)
+    b8 = Buf(ctx, 2, 8, 8, 8)
+    v = b8.view(2, 3)
+    assert ctx.lib.gan_pack(ctx.dt, xt.data_ptr(), C.byref(v), ctx.stream()) == 0
+    out = torch.zeros_like(xt)
+    assert ctx.lib.gan_unpack(ctx.dt, C.byref(v), out.data_ptr(), ctx.stream()) == 0
+    b2 = Buf(ctx, 2, 8, 8, 16)
+    v2 = b2.view(5, 3)
+    assert ctx.lib.gan_copy_view(ctx.dt, C.byref(v), C.byref(v2), ctx.stream()) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy().astype(np.float64), q(ctx, x))
+    assert np.array_equal(host(b2, 5, 3), q(ctx, x)) and np.all(host(b2, 0, 5) == 0)
+
+
+def test_bad_arguments_return_codes(ctx):
+    from gan_amd import _lib as L
+    from gan_amd.nets import Buf
+    xb = Buf(ctx, 1, 8, 8, 8)
+    yb = Buf(ctx, 1, 5, 5, 64)        # wrong output size for stride 2
+    w = torch.zeros((16, 64, 8), dtype=ctx.tdtype, device=ctx.device)
+    d = L.GanConvDesc(ctx.dt, 2, xb.view(), yb.view(), w.data_ptr(), 64, None, 0, 0.3, 0, ctx.ws_ptr, ctx.ws_bytes)
+    assert ctx.lib.gan_conv2d_fwd(C.byref(d), ctx.stream()) == -2
+    d2 = L.GanConvDesc(ctx.dt, 2, xb.view(), yb.view(), None, 64, None, 0, 0.3, 0, ctx.ws_ptr, ctx.ws_bytes)
+    assert ctx.lib.gan_conv2d_fwd(C.byref(d2), ctx.stream()) == -1

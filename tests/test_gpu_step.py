@@ -1,0 +1,135 @@
+"""Whole-step GPU parity against the CPU oracle: generator output (the 1e-3 max-abs gate of BASELINE.json,
+fp32 exact-MFMA path), the four Pix2Pix losses, parameter gradients and post-Adam weights; bf16 reports
+its own error against looser bounds; CycleGAN likewise.  Also hipGraph replay == eager."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import gan_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    return float(np.abs(np.asarray(a, np.float64) - b).max() / (np.abs(b).max() + 1e-30))
+
+
+def _setup_p2p(dtype, B=2, S=256, C=1, dropout=True):
+    from gan_amd.nets import Ctx
+    from gan_amd.steps import Pix2PixStep
+    ctx = Ctx('cuda:0', dtype)
+    st = Pix2PixStep(ctx, B, S, C, lam=100.0, seed=123, dropout=dropout)
+    Gp = O.init_generator(C, seed=11)
+    Dp = O.init_discriminator(C, True, seed=12)
+    rng = np.random.default_rng(0)
+    for P in (Gp, Dp):      # non-trivial affine parameters
+        for k in P:
+            if k.endswith(('.gamma', '.beta', '.bias')):
+                P[k] = (P[k] + 0.1 * rng.standard_normal(P[k].shape)).astype(np.float32)
+    st.G.params.load_numpy(Gp)
+    st.D.params.load_numpy(Dp)
+    inp, tar = O.synthetic_pair(B, S, C, seed=123)
+    masks = O.dropout_masks(B, S, seed=5) if dropout else None
+    if dropout:
+        st.g.set_dropmasks(masks)
+    return ctx, st, Gp, Dp, inp, tar, masks
+
+
+@pytest.mark.parametrize("dtype", ['f32', 'bf16'])
+def test_pix2pix_train_step_parity(dtype):
+    ctx, st, Gp, Dp, inp, tar, masks = _setup_p2p(dtype)
+    f64 = lambda P: {k: v.astype(np.float64) for k, v in P.items()}
+    Gr, Dr = f64(Gp), f64(Dp)
+    optG, optD = O.AdamTF(), O.AdamTF()
+    stG, stD = {}, {}
+    out = O.pix2pix_train_step(Gr, Dr, optG, optD, inp.astype(np.float64), tar.astype(np.float64), 100.0,
+                               [m.astype(np.float64) for m in masks], True, stateG=stG, stateD=stD, return_grads=True)
+    ref_losses, gen_ref, gG, gD = np.array(out[:4], np.float64), out[4], out[5], out[6]
+    ti, tt = torch.from_numpy(inp).to(ctx.device), torch.from_numpy(tar).to(ctx.device)
+    losses = st.train_step(ti, tt, True).cpu().numpy()
+    gen = st.g.output_f32().cpu().numpy()
+    err = np.abs(gen - gen_ref).max()
+    print(f"[{dtype}] generator output max-abs err vs oracle: {err:.3e}; losses {losses} ref {ref_losses}")
+    if dtype == 'f32':
+        assert err < 1e-3                      # BASELINE.json north_star gate (fp32 exact-MFMA path)
+        assert np.allclose(losses, ref_losses, rtol=2e-4)
+        gtol, ptol = 2e-3, 2e-5
+    else:
+        assert err < 0.15                      # bf16 storage: reported, not the parity gate
+        assert np.allclose(losses, ref_losses, rtol=5e-2)
+        gtol, ptol = 0.12, 4.1e-4              # Adam's first step is ~lr*sign(g): sign flips of tiny grads
+    got_gG, got_gD = st.G.params.to_numpy('grad'), st.D.params.to_numpy('grad')
+    worst = max(max(rel(got_gG[k], gG[k]) for k in gG), max(rel(got_gD[k], gD[k]) for k in gD))
+    print(f"[{dtype}] worst per-tensor gradient rel err: {worst:.3e}")
+    for k in gG:
+        assert rel(got_gG[k], gG[k]) < gtol, ('G', k, rel(got_gG[k], gG[k]))
+    for k in gD:
+        assert rel(got_gD[k], gD[k]) < gtol, ('D', k, rel(got_gD[k], gD[k]))
+    newG, newD = st.G.params.to_numpy(), st.D.params.to_numpy()
+    for k in Gp:
+        assert np.abs(newG[k] - Gr[k]).max() < ptol, k
+    for k in Dp:
+        assert np.abs(newD[k] - Dr[k]).max() < ptol, k
+    if dtype == 'f32':                         # BN moving statistics (D updated twice per step)
+        for k, v in stD.items():
+            assert rel(newD[k], v) < 1e-4, k
+        for k, v in stG.items():
+            assert rel(newG[k], v) < 1e-4, k
+    # training=False leaves weights alone (pix2pix.py:208)
+    before = st.G.params.master.clone()
+    st.train_step(ti, tt, False)
+    assert torch.equal(before, st.G.params.master)
+
+
+def test_pix2pix_graph_replay_matches_eager():
+    ctx, st, Gp, Dp, inp, tar, masks = _setup_p2p('bf16', B=2)
+    ti, tt = torch.from_numpy(inp).to(ctx.device), torch.from_numpy(tar).to(ctx.device)
+    l_eager = [st.train_step(ti, tt, True).cpu().numpy().copy() for _ in range(2)]
+    w_eager = st.G.params.master.clone()
+    ctx2, st2, *_ = _setup_p2p('bf16', B=2)
+    replay = st2.capture(training=True)        # capture itself performs warm-up steps: reload state after
+    st2.G.params.load_numpy(Gp); st2.D.params.load_numpy(Dp)
+    for ps in (st2.G.params, st2.D.params):
+        ps.m.zero_(); ps.v.zero_(); ps.step.zero_()
+    l_graph = [replay(ti, tt)[:4].cpu().numpy().copy() for _ in range(2)]
+    assert np.allclose(l_eager, l_graph, rtol=1e-5)
+    assert torch.allclose(w_eager, st2.G.params.master, atol=1e-6)
+
+
+@pytest.mark.parametrize("dtype", ['f32', 'bf16'])
+def test_cyclegan_train_step_parity(dtype):
+    from gan_amd.nets import Ctx
+    from gan_amd.steps import CycleGANStep
+    ctx = Ctx('cuda:0', dtype)
+    B, S, C = 1, 256, 1
+    st = CycleGANStep(ctx, B, S, C, lam=10.0, seed=7, dropout=True)
+    n = 'instancenorm'
+    Ps = [O.init_generator(C, n, seed=21), O.init_generator(C, n, seed=22),
+          O.init_discriminator(C, False, n, seed=23), O.init_discriminator(C, False, n, seed=24)]
+    for net, P in zip((st.Gg, st.Gf, st.Dx, st.Dy), Ps):
+        net.params.load_numpy(P)
+    rx, ry = O.synthetic_pair(B, S, C, seed=9)
+    keys = ['fake_y', 'cycled_x', 'fake_x', 'cycled_y', 'same_x', 'same_y']
+    masks = {k: O.dropout_masks(B, S, seed=40 + i) for i, k in enumerate(keys)}
+    for k, call in st.gen_calls().items():
+        call.set_dropmasks(masks[k])
+    Pr = [{k: v.astype(np.float64) for k, v in P.items()} for P in Ps]
+    opts = [O.AdamTF() for _ in range(4)]
+    m64 = {k: [m.astype(np.float64) for m in v] for k, v in masks.items()}
+    out = O.cyclegan_train_step(*Pr, opts, rx.astype(np.float64), ry.astype(np.float64), 10.0, m64, True, return_grads=True)
+    ref_losses, fakes, grads = np.array(out[:7], np.float64), out[7], out[8:]
+    tx, ty = torch.from_numpy(rx).to(ctx.device), torch.from_numpy(ry).to(ctx.device)
+    losses = st.train_step(tx, ty, True).cpu().numpy()
+    fy = st.fy.output_f32().cpu().numpy()
+    err = np.abs(fy - fakes['fake_y']).max()
+    print(f"[{dtype}] cyclegan fake_y max-abs err: {err:.3e}; losses {losses} ref {ref_losses}")
+    if dtype == 'f32':
+        assert err < 1e-3 and np.allclose(losses, ref_losses, rtol=5e-4)
+        gtol = 5e-3
+    else:
+        assert err < 0.2 and np.allclose(losses, ref_losses, rtol=8e-2)
+        gtol = 0.2
+    for net, g in zip((st.Gg, st.Gf, st.Dx, st.Dy), grads):
+        got = net.params.to_numpy('grad')
+        for k in g:
+            assert rel(got[k], g[k]) < gtol, (k, rel(got[k], g[k]))
