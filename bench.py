@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Pix2Pix `train_step` images/sec at 256x256 (BASELINE.json), bf16, batch 16 per GPU.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is one full Pix2Pix.train_step(training=True): generator forward, discriminator forward on
+real++fake, BCE/L1 losses, both backward passes (dgrad + wgrad), TF-form Adam on every weight, and (N>1)
+the RCCL gradient all-reduce - the whole step replayed from a captured hipGraph, inputs resident in HBM.
+Prints ONE JSON line (rank 0) with the step throughput, the roofline of the dominant GEMM kernel measured
+live with HIP events, and the CPU oracle timed on this box's host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+# algorithmic FLOPs per image of one Pix2Pix train_step = 3*F_G + 7*F_D (SURVEY.md 8d / BASELINE.md section 2)
+GF_PER_IMG = {256: 79.51, 512: 321.72}
+MFMA_PEAK_TFLOPS = 2500.0      # dense bf16, MI355X_MICROARCH.md chip table
+HBM_PEAK_GBS = 8000.0
+
+
+def gemm_profile(step, inputs, reps=3):
+    """Eager (non-graph) instrumented passes: HIP events around every GEMM-type launch, on the stream the
+    kernels run on.  Returns {kernel symbol: (total_ms_per_step, total_flops_per_step, launches_per_step)}."""
+    ctx = step.ctx
+    recs = {}
+    orig_run = ctx.run
+
+    def timed_run(ops):
+        st = ctx.stream()
+        for op in ops:
+            meta = op[3] if len(op) > 3 else None
+            if meta is None:
+                rc = op[0](*op[1], st)
+            else:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                rc = op[0](*op[1], st)
+                e1.record()
+                recs.setdefault(meta['kernel'], []).append((e0, e1, meta['flops']))
+            if rc:
+                raise RuntimeError(f"{op[2]} failed rc={rc}")
+    ctx.run = timed_run
+    try:
+        for _ in range(reps):
+            step._run(*inputs, training=True)
+        torch.cuda.synchronize()
+    finally:
+        ctx.run = orig_run
+    out = {}
+    for k, lst in recs.items():
+        ms = sum(a.elapsed_time(b) for a, b, _ in lst) / reps
+        fl = sum(f for _, _, f in lst) / reps
+        out[k] = (ms, fl, len(lst) // reps)
+    return out
+
+
+def cpu_baseline(budget_s=20.0):
+    """The numpy oracle's pix2pix_train_step (the CPU restatement of the reference path; the TF reference
+    itself is not installable here) on this box's host cores: 256x256, batch 1 (BASELINE config 1)."""
+    from oracle import gan_oracle as O
+    Gp, Dp = O.init_generator(1, seed=11), O.init_discriminator(1, True, seed=12)
+    optG, optD = O.AdamTF(), O.AdamTF()
+    inp, tar = O.synthetic_pair(1, 256, 1, seed=123)
+    masks = O.dropout_masks(1, 256, seed=5)
+    O.pix2pix_train_step(Gp, Dp, optG, optD, inp, tar, 100.0, masks, True)       # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        O.pix2pix_train_step(Gp, Dp, optG, optD, inp, tar, 100.0, masks, True)
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt > budget_s or n >= 50:
+            break
+    try:
+        from threadpoolctl import threadpool_info
+        cores = max([p.get('num_threads', 1) for p in threadpool_info()] or [1])
+    except Exception:
+        cores = os.cpu_count() or 1
+    return {"value": round(n / dt, 4), "unit": "images/sec", "cores": int(cores), "kind": "port",
+            "sample": f"{n} train_steps of the numpy oracle (fp32), Pix2Pix 256x256 batch 1, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--batch', type=int, default=16, help='per-GPU batch')
+    ap.add_argument('--img-size', type=int, default=256)
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
+    ap.add_argument('--model', default='pix2pix', choices=['pix2pix', 'cyclegan'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-graph', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        dist.init_process_group('nccl', device_id=torch.device(f'cuda:{local}'))
+    if args.gpus != world and rank == 0 and world > 1:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+
+    from gan_amd.ddp import GradSync
+    from gan_amd.nets import Ctx
+    from gan_amd.steps import CycleGANStep, Pix2PixStep
+    dev = f'cuda:{local}'
+    torch.cuda.set_device(local)
+    ctx = Ctx(dev, args.dtype)
+    B, S = args.batch, args.img_size
+    if args.model == 'pix2pix':
+        step = Pix2PixStep(ctx, B, S, 1, lam=100.0, seed=123)
+    else:
+        step = CycleGANStep(ctx, B, S, 1, lam=10.0, seed=123)
+    if world > 1:
+        step.sync = GradSync([n.params.grad for n in step.nets()])
+    # synthetic inputs on the normalize() lattice u/127.5-1 (base_gan.py:56-61), different per rank
+    g = torch.Generator(device='cpu').manual_seed(123 + rank)
+    mk = lambda: (torch.randint(0, 256, (B, S, S, 1), generator=g).float() / 127.5 - 1.0).to(dev)
+    inputs = (mk(), mk())
+
+    run = (lambda: step._run(*inputs, training=True)) if args.no_graph else None
+    if run is None:
+        replay = step.capture(training=True)
+        run = lambda: replay(*inputs)
+    for _ in range(args.warmup):
+        run()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    losses = step.losses.cpu().numpy()
+    if not np.all(np.isfinite(losses)):
+        raise RuntimeError(f"non-finite losses {losses}")
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        value = world * B * args.steps / dt
+        unit = "images/sec" if args.model == 'pix2pix' else "pairs/sec"
+        out = {"metric": "Pix2Pix train_step images/sec at 256x256" if args.model == 'pix2pix' else "CycleGAN train_step pairs/sec",
+               "value": round(value, 2), "unit": unit, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": args.dtype, "data": "synthetic",
+               "config": {"workload": f"{'Pix2Pix' if args.model == 'pix2pix' else 'CycleGAN'} {S}x{S} {args.dtype} "
+                                      f"batch={B}/GPU train_step (G fwd, D fwd real+fake, losses, dgrad+wgrad, Adam"
+                                      f"{', RCCL grad all-reduce' if world > 1 else ''})",
+                          "global_batch": world * B, "img_size": S, "channels": 1, "parallelism": f"dp{world}",
+                          "hipgraph": not args.no_graph}}
+        if args.model == 'pix2pix' and S in GF_PER_IMG:
+            out["step_tflops"] = round(value * GF_PER_IMG[S] / 1e3, 1)
+            out["step_mfma_frac"] = round(value * GF_PER_IMG[S] / 1e3 / (MFMA_PEAK_TFLOPS * world), 4)
+        # roofline of the dominant kernel, measured live (eager, HIP events on the launch stream)
+        prof = gemm_profile(step, inputs)
+        tot_ms = sum(v[0] for v in prof.values())
+        kname, (kms, kfl, kn) = max(prof.items(), key=lambda kv: kv[1][0])
+        ach = kfl / (kms * 1e-3) / 1e12
+        out["roofline"] = {"bound": "mfma", "kernel": kname, "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS,
+                           "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                           "launches_per_step": kn, "avg_launch_us": round(kms / kn * 1e3, 2),
+                           "gemm_share_of_eager_gemm_time": round(kms / tot_ms, 3)}
+        out["kernels"] = {k: {"ms_per_step": round(v[0], 4), "tflops": round(v[1] / (v[0] * 1e-3) / 1e12, 1), "launches": v[2]}
+                          for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}
+        out["losses"] = [round(float(x), 5) for x in losses[:4]]
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -63,6 +63,8 @@ SYMBOLS = {
     "gan_convT2d_fwd": (C.c_int, [C.POINTER(GanConvDesc), C.c_void_p]),
     "gan_convT2d_dgrad": (C.c_int, [C.POINTER(GanConvDesc), C.c_void_p]),
     "gan_conv_workspace_bytes": (C.c_size_t, [C.POINTER(GanConvDesc), C.c_int]),
+    "gan_conv_plan_info": (C.c_int, [C.POINTER(GanConvDesc), C.c_int, C.POINTER(C.c_int32)]),
+    "gan_wgrad_plan_info": (C.c_int, [C.POINTER(GanWgradDesc), C.POINTER(C.c_int32)]),
     "gan_conv_wgrad": (C.c_int, [C.POINTER(GanWgradDesc), C.c_void_p]),
     "gan_wgrad_workspace_bytes": (C.c_size_t, [C.POINTER(GanWgradDesc)]),
     "gan_weights_prepare": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -346,6 +346,17 @@ int gan_conv2d_fwd(const GanConvDesc* d, gan_stream_t s) { return run_gemm(d, 0,
 int gan_conv2d_dgrad(const GanConvDesc* d, gan_stream_t s) { return run_gemm(d, 1, s); }
 int gan_convT2d_fwd(const GanConvDesc* d, gan_stream_t s) { return run_gemm(d, 2, s); }
 int gan_convT2d_dgrad(const GanConvDesc* d, gan_stream_t s) { return run_gemm(d, 3, s); }
+int gan_conv_plan_info(const GanConvDesc* d, int op, int32_t* info /*[4]: BM, BN, splits, parities*/) {
+  GemmPlan pl;
+  GanConvDesc t = *d;
+  if (!t.x.ptr) t.x.ptr = (void*)16;
+  if (!t.y.ptr) t.y.ptr = (void*)16;
+  if (!t.w) t.w = (void*)16;
+  int rc = plan_gemm(&t, op, &pl);
+  if (rc) return rc;
+  info[0] = pl.BM; info[1] = pl.BN; info[2] = pl.p.splits; info[3] = pl.P;
+  return 0;
+}
 size_t gan_conv_workspace_bytes(const GanConvDesc* d, int op) {
   GemmPlan pl;
   GanConvDesc t = *d;

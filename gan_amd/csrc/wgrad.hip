@@ -287,8 +287,6 @@ static int launch_wgrad(const WgradPlan& pl, hipStream_t st) {
     case 128064: return launch_wcfg<T, 128, 64, 2, 2, TR>(pl, st);
     case 64128: return launch_wcfg<T, 64, 128, 2, 2, TR>(pl, st);
     case 64064: return launch_wcfg<T, 64, 64, 2, 2, TR>(pl, st);
-    case 16128: return launch_wcfg<T, 16, 128, 1, 4, TR>(pl, st);
-    case 16064: return launch_wcfg<T, 16, 64, 1, 4, TR>(pl, st);
     case 128016: return launch_wcfg<T, 128, 16, 4, 1, TR>(pl, st);
     case 64016: return launch_wcfg<T, 64, 16, 4, 1, TR>(pl, st);
     default: return GAN_E_SHAPE;
@@ -317,6 +315,17 @@ int gan_conv_wgrad(const GanWgradDesc* d, gan_stream_t stream) {
                        (const float*)pl.p.slab, pl.p.dw, count, pl.p.splits, pl.p.accumulate);
     GAN_CHECK_LAUNCH();
   }
+  return 0;
+}
+int gan_wgrad_plan_info(const GanWgradDesc* d, int32_t* info /*[4]: TA, TB, splits, fold*/) {
+  WgradPlan pl;
+  GanWgradDesc t = *d;
+  if (!t.big.ptr) t.big.ptr = (void*)16;
+  if (!t.small.ptr) t.small.ptr = (void*)16;
+  if (!t.dw) t.dw = (float*)16;
+  int rc = plan_wgrad(&t, &pl);
+  if (rc) return rc;
+  info[0] = pl.TA; info[1] = pl.TB; info[2] = pl.p.splits; info[3] = pl.p.fold;
   return 0;
 }
 size_t gan_wgrad_workspace_bytes(const GanWgradDesc* d) {

@@ -47,7 +47,8 @@ class Ctx:
 
     def run(self, ops):
         st = self.stream()
-        for fn, args, what in ops:
+        for op in ops:
+            fn, args, what = op[0], op[1], op[2]
             rc = fn(*args, st)
             if rc:
                 L.check(rc, what)
@@ -214,7 +215,7 @@ class _Builder:
         self.keep.append(d)
         return C.byref(d)
 
-    def conv(self, op, x, y, w, w_rows, stride=2, bias=None, act=None, y_f32=0):
+    def conv(self, op, x, y, w, w_rows, stride=2, bias=None, act=None, y_f32=0, k_real=None):
         d = L.GanConvDesc(self.ctx.dt, stride, x, y, w, w_rows, bias, L.ACTS[act], LEAKY_ALPHA, y_f32,
                           self.ctx.ws_ptr, self.ctx.ws_bytes)
         opi = {'conv_fwd': 0, 'conv_dgrad': 1, 'convT_fwd': 2, 'convT_dgrad': 3}[op]
@@ -222,7 +223,15 @@ class _Builder:
         need = self.lib.gan_conv_workspace_bytes(C.byref(d), opi)
         if need > self.ctx.ws_bytes:
             raise L.GanAmdError(f"workspace too small for {op}: need {need}")
-        return (fn, (self._desc(d),), op)
+        info = (C.c_int32 * 4)()
+        self.lib.gan_conv_plan_info(C.byref(d), opi, info)
+        T = 4 if info[3] == 4 else 16
+        # algorithmic FLOPs, SURVEY.md 8(d) convention: real channel counts, border taps not discounted
+        creal = k_real or x.c
+        M = x.n * (x.h * x.w if info[3] == 4 else y.h * y.w)
+        flops = 2.0 * M * info[3] * T * y.c * creal
+        meta = dict(kind='gemm', kernel=f"conv_gemm<{self.ctx.dtype},{info[0]},{info[1]}>", flops=flops, splits=info[2])
+        return (fn, (self._desc(d),), op, meta)
 
     def wgrad(self, big, small, dw_ptr, big_c, small_c, stride, accumulate):
         d = L.GanWgradDesc(self.ctx.dt, stride, big, small, dw_ptr, big_c, small_c, int(accumulate),
@@ -230,7 +239,11 @@ class _Builder:
         need = self.lib.gan_wgrad_workspace_bytes(C.byref(d))
         if need > self.ctx.ws_bytes:
             raise L.GanAmdError(f"workspace too small for wgrad: need {need}")
-        return (self.lib.gan_conv_wgrad, (self._desc(d),), "conv_wgrad")
+        info = (C.c_int32 * 4)()
+        self.lib.gan_wgrad_plan_info(C.byref(d), info)
+        flops = 2.0 * small.n * small.h * small.w * 16 * big_c * small_c
+        meta = dict(kind='gemm', kernel=f"wgrad<{self.ctx.dtype},{info[0]},{info[1]}>", flops=flops, splits=info[2])
+        return (self.lib.gan_conv_wgrad, (self._desc(d),), "conv_wgrad", meta)
 
     def norm_names(self):
         return ('.gamma', '.beta') if self.norm == 'batchnorm' else ('.scale', '.offset')
@@ -332,7 +345,7 @@ class GenCall:
             name = f'down{i}'
             w = P.tr[name + '.kernel']
             if i == 0:      # conv -> LeakyReLU fused in the GEMM epilogue (apply_norm=False, base_gan.py:180)
-                fwd.append(bd.conv('conv_fwd', x, a_down(0), w.data_ptr(), G_DOWN[0], 2, None, 'lrelu'))
+                fwd.append(bd.conv('conv_fwd', x, a_down(0), w.data_ptr(), G_DOWN[0], 2, None, 'lrelu', k_real=C_))
             else:
                 fwd.append(bd.conv('conv_fwd', x, self.y_down[i].view(), w.data_ptr(), G_DOWN[i], 2))
                 mean, rstd = stat(name, G_DOWN[i])
@@ -369,7 +382,7 @@ class GenCall:
                               self.dpre.view(), 'tanh'))
         ops.append(bd.wgrad(self.dpre.view(), self.cat[6].view(), P.ptr('last.kernel', 'grad'), C_, 128, 2, accumulate))
         ops.append(bd.bias_grad(self.dpre.view(), P.ptr('last.bias', 'grad'), accumulate))
-        ops.append(bd.conv('convT_dgrad', self.dpre.view(), self.dcat[6].view(), P.tr['last.kernel'].data_ptr(), 128, 2))
+        ops.append(bd.conv('convT_dgrad', self.dpre.view(), self.dcat[6].view(), P.tr['last.kernel'].data_ptr(), 128, 2, k_real=C_))
         for j in range(6, -1, -1):
             name = f'up{j}'
             mean, rstd = self.stats[name]
@@ -494,7 +507,7 @@ class DiscCall:
         dev, f32 = ctx.device, torch.float32
         self.stats = {k: (torch.zeros(groups * c, dtype=f32, device=dev), torch.zeros(groups * c, dtype=f32, device=dev))
                       for k, c in [('down1', 128), ('down2', 256), ('conv', 512)]}
-        fwd = [bd.conv('conv_fwd', self.xin.view(), self.a0.view(), P.tr['down0.kernel'].data_ptr(), 64, 2, None, 'lrelu')]
+        fwd = [bd.conv('conv_fwd', self.xin.view(), self.a0.view(), P.tr['down0.kernel'].data_ptr(), 64, 2, None, 'lrelu', k_real=net.cin)]
         prev = self.a0
         for name, co, stride in self.LAYERS[1:4]:
             fwd.append(bd.conv('conv_fwd', prev.view(), self.y[name].view(), P.tr[name + '.kernel'].data_ptr(), co, stride))
@@ -538,7 +551,7 @@ class DiscCall:
         if wgrads:
             ops.append(bd.wgrad(sv(self.a['conv']), dl, P.ptr('last.kernel', 'grad'), 512, 1, 1, accumulate))
             ops.append(bd.bias_grad(dl, P.ptr('last.bias', 'grad'), accumulate))
-        ops.append(bd.conv('conv_dgrad', dl, gv(self.dA['conv']), P.nat['last.kernel'].data_ptr(), 512, 1))
+        ops.append(bd.conv('conv_dgrad', dl, gv(self.dA['conv']), P.nat['last.kernel'].data_ptr(), 512, 1, k_real=1))
         order = [('conv', 'down2', 1, 256), ('down2', 'down1', 2, 128), ('down1', 'down0', 2, 64)]
         for name, prev, stride, cprev in order:
             mean, rstd = self.stats[name]

@@ -36,9 +36,23 @@ class _StepBase:
     def _copy(self, src_view, dst_view):
         L.check(self.ctx.lib.gan_copy_view(self.ctx.dt, C.byref(src_view), C.byref(dst_view), self.ctx.stream()), "copy_view")
 
+    def _run(self, a, b, training=True):
+        self._forward_backward(a, b, training)
+        if training:
+            if self.sync is not None:
+                self.sync()                       # data-parallel gradient exchange (RCCL)
+            self._update()
+        return self.losses
+
+    def _update(self):
+        gs = self.sync.grad_scale if self.sync is not None else 1.0
+        for net in self.nets():
+            net.params.adam(self.lr, self.b1, self.b2, grad_scale=gs)
+
     # ---- hipGraph capture of a whole step --------------------------------------------------------
     def capture(self, training=True):
-        """Capture one full step on static input buffers; returns a callable replaying it."""
+        """Capture one full step on static input buffers; returns a callable replaying it.  With a gradient
+        exchange attached the step becomes graph(forward+backward) -> collectives -> graph(Adam)."""
         self._static_in = [torch.zeros_like(t) for t in self._example_inputs()]
         torch.cuda.synchronize()
         s = torch.cuda.Stream(device=self.ctx.device)
@@ -47,16 +61,28 @@ class _StepBase:
             self._run(*self._static_in, training=training)
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            self._run(*self._static_in, training=training)
-        self._graph = graph
+        split = training and self.sync is not None and self.sync.world > 1
+        g1 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g1):
+            if split:
+                self._forward_backward(*self._static_in, training)
+            else:
+                self._run(*self._static_in, training=training)
+        g2 = None
+        if split:
+            g2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g2):
+                self._update()
+        self._graphs = (g1, g2)
 
         def replay(*inputs):
             for dst, src in zip(self._static_in, inputs):
                 if src is not dst:
                     dst.copy_(src, non_blocking=True)
-            graph.replay()
+            g1.replay()
+            if g2 is not None:
+                self.sync()
+                g2.replay()
             return self.losses
         return replay
 
@@ -72,13 +98,16 @@ class Pix2PixStep(_StepBase):
         self.d = self.D.new_call(batch, size, calls=2)
         self.losses = torch.zeros(8, dtype=torch.float32, device=ctx.device)
         self.l1_ws = torch.zeros(4096, dtype=torch.float32, device=ctx.device)
-        self.grad_hook = None        # set by the data-parallel wrapper: called between backward and Adam
+        self.sync = None             # GradSync for data-parallel runs
+
+    def nets(self):
+        return (self.G, self.D)
 
     def _example_inputs(self):
         sh = (self.B, self.S, self.S, self.C)
         return [torch.zeros(sh, dtype=torch.float32, device=self.ctx.device) for _ in range(2)]
 
-    def _run(self, inp, tar, training=True):
+    def _forward_backward(self, inp, tar, training=True):
         B, Cc, g, d = self.B, self.C, self.g, self.d
         # inputs -> typed, channel-padded buffers.  D input = concat([inp, tar|gen]) (base_gan.py:139)
         self._pack(inp, g.xin.view(0, Cc))
@@ -102,11 +131,7 @@ class Pix2PixStep(_StepBase):
             self._copy(d.dxin.view(Cc, Cc), g.dgen2.view(0, Cc))
             g.backward(use_dgen2=True)                                # pix2pix.py:210
             d.backward_params()                                       # pix2pix.py:211
-            if self.grad_hook is not None:
-                self.grad_hook()
-            self.G.params.adam(self.lr, self.b1, self.b2)             # pix2pix.py:213-216
-            self.D.params.adam(self.lr, self.b1, self.b2)
-        return self.losses
+        return self.losses                                            # Adam: _update() (pix2pix.py:213-216)
 
     def train_step(self, input_image, target, training=True):
         """(gen_total_loss, gen_gan_loss, gen_l1_loss, disc_loss) as a 4-element device tensor view."""
@@ -131,7 +156,10 @@ class CycleGANStep(_StepBase):
         self.dy = self.Dy.new_call(batch, size, calls=2)
         self.losses = torch.zeros(12, dtype=torch.float32, device=ctx.device)
         self.l1_ws = torch.zeros(4096, dtype=torch.float32, device=ctx.device)
-        self.grad_hook = None
+        self.sync = None
+
+    def nets(self):
+        return (self.Gg, self.Gf, self.Dx, self.Dy)
 
     def gen_calls(self):
         return dict(fake_y=self.fy, cycled_x=self.cx, fake_x=self.fx, cycled_y=self.cy, same_x=self.sx, same_y=self.sy)
@@ -140,7 +168,7 @@ class CycleGANStep(_StepBase):
         sh = (self.B, self.S, self.S, self.C)
         return [torch.zeros(sh, dtype=torch.float32, device=self.ctx.device) for _ in range(2)]
 
-    def _run(self, real_x, real_y, training=True):
+    def _forward_backward(self, real_x, real_y, training=True):
         B, Cc, lam = self.B, self.C, self.lam
         fy, cx, fx, cy, sx, sy, dx, dy = self.fy, self.cx, self.fx, self.cy, self.sx, self.sy, self.dx, self.dy
         self._pack(real_x, fy.xin.view(0, Cc)); self._pack(real_x, sx.xin.view(0, Cc)); self._pack(real_x, dx.xin.view(0, Cc, 0, B))
@@ -182,11 +210,7 @@ class CycleGANStep(_StepBase):
             sy.backward(accumulate=True)                              # identity_y -> G_g
             sx.backward(accumulate=True)                              # identity_x -> G_f
             dx.backward_params(); dy.backward_params()                # :257-260
-            if self.grad_hook is not None:
-                self.grad_hook()
-            for net in (self.Gg, self.Gf, self.Dx, self.Dy):          # :263-273
-                net.params.adam(self.lr, self.b1, self.b2)
-        return self.losses
+        return self.losses                                            # four Adam applies: _update() (:263-273)
 
     def train_step(self, real_x, real_y, training=True):
         """7 losses in the reference's order (cycle_gan.py:275-276)."""

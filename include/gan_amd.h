@@ -67,6 +67,8 @@ int gan_convT2d_fwd(const GanConvDesc* d, gan_stream_t stream);
  * w = transposed NK copy ([tap][cin][cout]). */
 int gan_convT2d_dgrad(const GanConvDesc* d, gan_stream_t stream);
 size_t gan_conv_workspace_bytes(const GanConvDesc* d, int op /*0 conv_fwd,1 conv_dgrad,2 convT_fwd,3 convT_dgrad*/);
+/* launch plan the library picks for this problem (profiling / bench bookkeeping): info = {BM, BN, splitK, parities} */
+int gan_conv_plan_info(const GanConvDesc* d, int op, int32_t* info);
 
 typedef struct GanWgradDesc {
   int32_t dtype;
@@ -83,6 +85,7 @@ typedef struct GanWgradDesc {
  * pix2pix.py:210-211, cycle_gan.py:252-260). */
 int gan_conv_wgrad(const GanWgradDesc* d, gan_stream_t stream);
 size_t gan_wgrad_workspace_bytes(const GanWgradDesc* d);
+int gan_wgrad_plan_info(const GanWgradDesc* d, int32_t* info /* {TA, TB, splitM, fold} */);
 
 /* Produce typed NK copies from a fp32 Keras-layout master [16][A][B]:
  * nk_native [16][A][pad8(B)] and nk_transposed [16][B][pad8(A)] (either may be NULL). */
