@@ -8,25 +8,34 @@
 // (and the dgrad of a stride-2 conv) is four output-parity sub-GEMMs with 4 taps each (K = 4*Cin),
 // selected by blockIdx.z, so no zero-inserted input is ever materialised.
 //
-// Tiling: 256 threads = 4 waves; block tile BM x BN x 128 bytes of K; LDS double-buffered, rows padded
-// to 144 B so the 16 rows of a ds_read_b128 fragment read land on 16 distinct 16-B slots; global->VGPR
-// prefetch of tile k+1 is issued before the MFMAs of tile k and written to the other LDS buffer after
-// them (one barrier per K step).  bf16: v_mfma_f32_16x16x32_bf16; fp32 (parity path): exact
-// v_mfma_f32_16x16x4_f32.  Small problems split K across blockIdx.z into fp32 slabs + a reduce kernel.
+// Data path: the im2col gather goes global -> LDS directly (global_load_lds_dwordx4: per-lane SOURCE
+// address = the gather, lane-linear LDS destination), no VGPR staging and no ds_write.  An LDS tile row is
+// 128 bytes of K (64 bf16 / 32 fp32) = eight 16-byte slots, XOR-swizzled by (row & 7) through the source
+// address so the ds_read_b128 fragment reads are bank-conflict free.  Padding taps and out-of-range rows
+// read a zero page.  Two LDS stages: tile k+1 streams in while tile k is multiplied; one barrier per
+// 128-byte K step.  256 threads = 4 waves; block tile BM x BN; bf16: v_mfma_f32_16x16x32_bf16, fp32
+// (parity path): exact v_mfma_f32_16x16x4_f32.  The epilogue stages the tile in LDS and writes whole
+// 16-byte channel vectors (bias + activation fused).  Small problems split K across blockIdx.z into fp32
+// slabs + a reduce kernel.  Block ids are remapped so that each XCD (own L2) works on a contiguous range
+// of M tiles and all their N tiles.
 #include "common.h"
 
 struct GemmParams {
   const void* x; const void* w; void* y; float* slab; const float* bias;
   int Nimg, Hs, Ws, xpitch, Cin, log2_cvecs;
   int Hg, Wg, M;
-  int S, TWlog2, T;
+  int S, TWlog2, T, log2T;
   int dy0, dx0, dstep, wy0, wx0, wstep;
   int parity;
   int Wrows;
   int Ho, Wo, ypitch, Cout, OS;
   int splits, kchunks, NslabPitch;
-  int act; float slope; int out_f32;
+  int tilesM, tilesN;
+  int act; float slope; int out_f32; int vec_store;
+  unsigned xbytes, wbytes;   // extents for the buffer descriptors (out-of-range offsets read zeros)
 };
+
+__device__ uint4 g_zero_page[8];   // 128 B of zeros: source of padding taps / out-of-range rows
 
 template <typename T> struct Mma;
 template <> struct Mma<bf16_t> {
@@ -59,84 +68,116 @@ __device__ __forceinline__ size_t out_pixel_offset(const GemmParams& p, int m, i
   return ((size_t)(img * p.Ho + gy * p.OS + py) * p.Wo + (gx * p.OS + px)) * (size_t)p.ypitch;
 }
 
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N>
-__global__ __launch_bounds__(256) void conv_gemm_kernel(const GemmParams p) {
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// BKB: bytes of K per LDS row / pipeline step (128 or 64); NS: LDS stages (NS-1 tiles in flight)
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int BKB, int NS>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_gemm_kernel(const GemmParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)   // body uses device-only buffer-descriptor builtins; the host pass only needs the stub
   constexpr int VEC = VecOf<T>::N;
-  constexpr int ROWB = 144;
+  constexpr int NW = WAVES_M * WAVES_N, NTHREADS = 64 * NW;
   constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N, MT = WTM / 16, NT = WTN / 16;
-  constexpr int AI = (BM + 31) / 32, BI = (BN + 31) / 32;
-  static_assert(WAVES_M * WAVES_N == 4, "4 waves");
+  constexpr int SLOTS = BKB / 16, RPI = 1024 / BKB;      // 16-B slots per row; rows per 1-KiB wave-instruction
+  constexpr int AINS = BM / RPI, BINS = BN / RPI;        // 1-KiB pieces per tile
+  constexpr int AI = (AINS + NW - 1) / NW, BI = (BINS + NW - 1) / NW;  // per wave
+  constexpr int STAGE = (BM + BN) * BKB;
+  constexpr int KSTEPS = BKB / 64;                       // 64-byte MFMA k-steps per row
+  static_assert(NS == 2 || (AINS % NW == 0 && BINS % NW == 0), "counted vmcnt needs equal pieces per wave");
+  // slot swizzle so that the 16 rows of a ds_read_b128 fragment read hit 16 distinct 16-B bank groups
+  auto fsw = [](int row) { return BKB == 128 ? (row & 7) : ((0 - (row >> 2)) & 3); };
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* As = smem;
-  unsigned char* Bs = smem + 2 * BM * ROWB;
 
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
   const int r = lane & 15, q = lane >> 4;
-  const int bm0 = blockIdx.x * BM, bn0 = blockIdx.y * BN;
+
+  // XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch); give each XCD a contiguous
+  // run of logical tiles, N tiles fastest, so an A tile is fetched into ONE L2 and re-used by its N tiles.
+  int bid = blockIdx.x;
+  const int nb = p.tilesM * p.tilesN;
+  if ((nb & 7) == 0) bid = (bid & 7) * (nb >> 3) + (bid >> 3);
+  const int bm0 = (bid / p.tilesN) * BM, bn0 = (bid % p.tilesN) * BN;
+
   int par = 0, split = blockIdx.z;
   if (p.parity) { par = blockIdx.z / p.splits; split = blockIdx.z % p.splits; }
   const int py = par >> 1, px = par & 1;
   int dy0 = p.dy0, dx0 = p.dx0, wy0 = p.wy0, wx0 = p.wx0;
   if (p.parity) { dy0 = py; dx0 = px; wy0 = 1 - py; wx0 = 1 - px; }
 
-  const int vec = tid & 7, row0 = tid >> 3;
-  int ay[AI], ax[AI], ab[AI];
-#pragma unroll
-  for (int i = 0; i < AI; ++i) {
-    int row = row0 + 32 * i;
-    int m = bm0 + row;
-    if (row < BM && m < p.M) {
-      int gx = m % p.Wg;
-      int t = m / p.Wg;
-      int gy = t % p.Hg;
-      ab[i] = (t / p.Hg) * p.Hs;
-      ay[i] = gy * p.S;
-      ax[i] = gx * p.S;
-    } else {
-      ab[i] = 0; ay[i] = -(1 << 20); ax[i] = -(1 << 20);
-    }
-  }
-  const T* xg = (const T*)p.x;
-  const T* wg = (const T*)p.w;
+  // this lane's slot in every 8-row x 128-B LDS piece, and the K chunk it must fetch for it (swizzle)
+  const int lrow = lane / SLOTS, slot = lane % SLOTS;
+  const int chunk = slot ^ fsw(lrow);
   const int cmask = (1 << p.log2_cvecs) - 1;
   const int twmask = (1 << p.TWlog2) - 1;
 
-  uint4 ra[AI], rb[BI];
-  auto gload = [&](int kc) {
-    int kvec = kc * 8 + vec;
-    int tap = kvec >> p.log2_cvecs;
-    int cv = kvec & cmask;
-    int ty = tap >> p.TWlog2, tx = tap & twmask;
-    int dy = dy0 + ty * p.dstep, dx = dx0 + tx * p.dstep;
+  // Gather table, built once per block: byte offset of the source pixel for every (tap, tile row), or
+  // 0x80000000 for zero padding / rows past M.  Loads go through buffer descriptors, whose range check turns
+  // such offsets into zeros, so the K loop spends one LDS read + one add per 1-KiB piece on addressing.
+  int* tbl = (int*)(smem + NS * STAGE);       // [T][BM]
+  for (int e = tid; e < p.T * BM; e += NTHREADS) {
+    const int row = e % BM, tap = e / BM;
+    const int m = bm0 + row;
+    int off = (int)0x80000000;
+    if (m < p.M) {
+      const int gx = m % p.Wg;
+      const int t = m / p.Wg;
+      const int gy = t % p.Hg, img = t / p.Hg;
+      const int ty = tap >> p.TWlog2, tx = tap & twmask;
+      const int sy = gy * p.S + dy0 + ty * p.dstep, sx = gx * p.S + dx0 + tx * p.dstep;
+      if ((unsigned)sy < (unsigned)p.Hs && (unsigned)sx < (unsigned)p.Ws)
+        off = (int)((((size_t)(img * p.Hs + sy) * p.Ws + sx) * (size_t)p.xpitch) * sizeof(T));
+    }
+    tbl[e] = off;
+  }
+  int nbo[BI];
+#pragma unroll
+  for (int i = 0; i < BI; ++i) {
+    const int n = bn0 + (wave + NW * i) * RPI + lrow;
+    nbo[i] = n < p.Wrows ? (int)((size_t)n * p.Cin * sizeof(T)) : (int)0x80000000;
+  }
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.xbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.wbytes, 0x00020000);
+  const int wtapbytes = p.Wrows * p.Cin * (int)sizeof(T);
+  __syncthreads();
+
+  auto issue = [&](int kc, int stage) {
+    unsigned char* As = smem + stage * STAGE;
+    unsigned char* Bs = As + BM * BKB;
+    // K order: channel-chunk major, tap minor (when a 128-B chunk lies inside one tap): the 16 (or 4) taps
+    // of one channel chunk re-read the same input lines shifted by a pixel, so consecutive K steps hit in L2
+    // instead of coming back after the whole channel range has been streamed.
+    int tap, coffB;
+    if ((1 << p.log2_cvecs) >= SLOTS) {
+      tap = kc & (p.T - 1);
+      coffB = ((kc >> p.log2T) * SLOTS + chunk) * 16;
+    } else {
+      const int kvec = kc * SLOTS + chunk;
+      tap = kvec >> p.log2_cvecs;
+      coffB = (kvec & cmask) * 16;
+    }
+    const int* trow = tbl + tap * BM + lrow;
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
-      int sy = ay[i] + dy, sx = ax[i] + dx;
-      bool ok = (unsigned)sy < (unsigned)p.Hs && (unsigned)sx < (unsigned)p.Ws;
-      size_t off = ((size_t)(ab[i] + sy) * p.Ws + sx) * (size_t)p.xpitch + (size_t)cv * VEC;
-      ra[i] = ok ? *(const uint4*)(xg + off) : make_uint4(0, 0, 0, 0);
+      const int ia = wave + NW * i;
+      if (ia < AINS)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(As + ia * 1024), 16,
+                                                 trow[ia * RPI] + coffB, 0, 0, 0);
     }
-    int widx = (wy0 + ty * p.wstep) * 4 + (wx0 + tx * p.wstep);
+    const int ty = tap >> p.TWlog2, tx = tap & twmask;
+    const int wofs = ((wy0 + ty * p.wstep) * 4 + (wx0 + tx * p.wstep)) * wtapbytes + coffB;
 #pragma unroll
     for (int i = 0; i < BI; ++i) {
-      int row = row0 + 32 * i;
-      int n = bn0 + row;
-      bool ok = row < BN && n < p.Wrows;
-      size_t off = ((size_t)widx * p.Wrows + n) * (size_t)p.Cin + (size_t)cv * VEC;
-      rb[i] = ok ? *(const uint4*)(wg + off) : make_uint4(0, 0, 0, 0);
-    }
-  };
-  auto lstore = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < AI; ++i) {
-      int row = row0 + 32 * i;
-      if (BM % 32 == 0 || row < BM) *(uint4*)(As + (buf * BM + row) * ROWB + vec * 16) = ra[i];
-    }
-#pragma unroll
-    for (int i = 0; i < BI; ++i) {
-      int row = row0 + 32 * i;
-      if (BN % 32 == 0 || row < BN) *(uint4*)(Bs + (buf * BN + row) * ROWB + vec * 16) = rb[i];
+      const int ib = wave + NW * i;
+      if (ib < BINS)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(Bs + ib * 1024), 16,
+                                                 nbo[i] + wofs, 0, 0, 0);
     }
   };
 
@@ -146,36 +187,61 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const GemmParams p) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int kc_begin = (int)((long long)p.kchunks * split / p.splits);
-  const int kc_end = (int)((long long)p.kchunks * (split + 1) / p.splits);
-
-  int buf = 0;
-  if (kc_begin < kc_end) {
-    gload(kc_begin);
-    lstore(0);
-  }
-  __syncthreads();
-  for (int kc = kc_begin; kc < kc_end; ++kc) {
-    const bool more = kc + 1 < kc_end;
-    if (more) gload(kc + 1);
-    const unsigned char* Ab = As + (buf * BM + wm * WTM + r) * ROWB + q * 16;
-    const unsigned char* Bb = Bs + (buf * BN + wn * WTN + r) * ROWB + q * 16;
+  // fragment read offsets: row R = base + r, slot ((s*4+q) ^ (R&7)) with R&7 == r&7 (bases are multiples of 16)
+  // Fragment reads are issued as inline-asm ds_read_b128: hipcc orders every compiler-visible LDS read behind
+  // ALL in-flight LDS-DMA (it inserts s_waitcnt vmcnt(0)), which would drain the multi-stage pipeline each
+  // step.  Ordering is ours instead: counted vmcnt + barrier before a stage is read (K loop below), and
+  // counted lgkmcnt + sched_barrier before the MFMAs that consume the fragments.
+  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  const unsigned sw0 = ((q ^ fsw(r)) << 4), sw1 = (((4 + q) ^ fsw(r)) << 4);
+  const unsigned a_off = (wm * WTM + r) * BKB, b_off = BM * BKB + (wn * WTN + r) * BKB;
+  auto compute = [&](int stage) {
+    const unsigned sbase = lds_base + stage * STAGE;
+    uint4 af[KSTEPS][MT], bfr[KSTEPS][NT];
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      uint4 af[MT], bfr[NT];
+    for (int s = 0; s < KSTEPS; ++s) {
+      const unsigned sw = s ? sw1 : sw0;
 #pragma unroll
-      for (int i = 0; i < MT; ++i) af[i] = *(const uint4*)(Ab + i * 16 * ROWB + s * 64);
+      for (int i = 0; i < MT; ++i) asm volatile("ds_read_b128 %0, %1" : "=v"(af[s][i]) : "v"(sbase + a_off + i * 16 * BKB + sw));
 #pragma unroll
-      for (int j = 0; j < NT; ++j) bfr[j] = *(const uint4*)(Bb + j * 16 * ROWB + s * 64);
+      for (int j = 0; j < NT; ++j) asm volatile("ds_read_b128 %0, %1" : "=v"(bfr[s][j]) : "v"(sbase + b_off + j * 16 * BKB + sw));
+    }
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s) {
+      if (s + 1 < KSTEPS) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(MT + NT) : "memory");
+      else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < NT; ++j) Mma<T>::run(acc[i][j], af[i], bfr[j]);
+        for (int j = 0; j < NT; ++j) Mma<T>::run(acc[i][j], af[s][i], bfr[s][j]);
     }
-    if (more) lstore(buf ^ 1);
-    __syncthreads();
-    buf ^= 1;
+  };
+
+  const int kc_begin = (int)((long long)p.kchunks * split / p.splits);
+  const int kc_end = (int)((long long)p.kchunks * (split + 1) / p.splits);
+  const int nk = kc_end - kc_begin;
+  // NS-1 tiles stay in flight.  At step i: wait until all but the newest (NS-2) tiles of THIS wave have landed
+  // (counted vmcnt: LDS-DMA pieces retire in issue order), barrier (everyone's pieces of tile i are in LDS and
+  // everyone has finished reading tile i-1), refill the stage tile i-1 occupied, multiply tile i.
+  constexpr int PT = AI + BI;                           // pieces per wave per tile
+#pragma unroll
+  for (int s = 0; s < NS - 1; ++s)
+    if (s < nk) issue(kc_begin + s, s);
+  int st_c = 0, st_i = NS - 1;                          // stage of tile i / of tile i+NS-1
+  for (int i = 0; i < nk; ++i) {
+    const int pending = nk - 1 - i < NS - 2 ? nk - 1 - i : NS - 2;
+    if (NS >= 5 && pending == 3) wait_vmcnt<3 * PT>();
+    else if (NS >= 4 && pending == 2) wait_vmcnt<2 * PT>();
+    else if (NS >= 3 && pending == 1) wait_vmcnt<PT>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (i + NS - 1 < nk) issue(kc_begin + i + NS - 1, st_i);
+    compute(st_c);
+    st_c = st_c + 1 == NS ? 0 : st_c + 1;
+    st_i = st_i + 1 == NS ? 0 : st_i + 1;
   }
+  __syncthreads();
 
   // epilogue: C/D layout of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg
   if (p.splits > 1) {
@@ -193,6 +259,34 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const GemmParams p) {
           }
         }
       }
+  } else if (p.vec_store) {
+    // stage 16 rows per wave-row at a time (bias + activation applied) as T in LDS, then coalesced 16-byte
+    // row stores: MT passes over a [WAVES_M*16][BN] staging tile
+    constexpr int CS = BN * (int)sizeof(T) + (sizeof(T) == 2 ? 32 : 16);
+    constexpr int VPR = BN / VEC;
+    unsigned char* Cs = smem;
+    float bv[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int n = bn0 + wn * WTN + j * 16 + r;
+      bv[j] = (p.bias && n < p.Cout) ? p.bias[n] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      if (i) __syncthreads();
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          st_f((T*)(Cs + (wm * 16 + q * 4 + e) * CS) + wn * WTN + j * 16 + r, apply_act(acc[i][j][e] + bv[j], p.act, p.slope));
+      __syncthreads();
+      for (int idx = tid; idx < WAVES_M * 16 * VPR; idx += NTHREADS) {
+        const int sr = idx / VPR, v = idx % VPR;
+        const int m = bm0 + (sr >> 4) * WTM + i * 16 + (sr & 15), n = bn0 + v * VEC;
+        if (m < p.M && n < p.Cout)
+          *(uint4*)((T*)p.y + out_pixel_offset(p, m, py, px) + n) = *(const uint4*)(Cs + sr * CS + v * 16);
+      }
+    }
   } else {
 #pragma unroll
     for (int i = 0; i < MT; ++i)
@@ -209,6 +303,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const GemmParams p) {
         }
       }
   }
+#endif
 }
 
 template <typename T>
@@ -227,6 +322,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// pipeline shape per tile: big (one block per CU) tiles use 64-byte K rows and 4-5 stages so ~100 KB of
+// LDS-DMA stays in flight per CU; small tiles (several blocks per CU) use 128-byte rows, 2 stages.
+static constexpr int cfg_bkb(int BM, int BN) { return BM == 256 ? 64 : 128; }
+static constexpr int cfg_ns(int BM, int BN) { return BM == 256 ? (BN == 256 ? 4 : 5) : 2; }
+
 struct GemmPlan {
   GemmParams p;
   int BM, BN, P;
@@ -241,18 +341,26 @@ static int plan_gemm(const GanConvDesc* d, int op, GemmPlan* pl) {
   const GanTensor &x = d->x, &y = d->y;
   if (x.c <= 0 || x.c % 8 || x.pitch % 8 || x.pitch < x.c || y.pitch < y.c || y.c <= 0) return GAN_E_SHAPE;
   if (x.n != y.n || d->w_rows < y.c) return GAN_E_SHAPE;
+  if (((uintptr_t)x.ptr | (uintptr_t)d->w) & 15) return GAN_E_ARG;   // 16-byte LDS-DMA pieces
   int l2 = ilog2_exact(x.c / vec);
   if (l2 < 0) return GAN_E_SHAPE;
   GemmParams& p = pl->p;
   p.x = x.ptr; p.w = d->w; p.y = y.ptr; p.bias = d->bias; p.slab = (float*)d->workspace;
+  {
+    const size_t es = d->dtype == GAN_F32 ? 4 : 2;
+    const size_t xb = (((size_t)x.n * x.h * x.w - 1) * x.pitch + x.c) * es, wb = (size_t)16 * d->w_rows * x.c * es;
+    if (xb >= 0x7fffffffull || wb >= 0x7fffffffull) return GAN_E_SHAPE;
+    p.xbytes = (unsigned)xb; p.wbytes = (unsigned)wb;
+  }
   p.Nimg = x.n; p.Hs = x.h; p.Ws = x.w; p.xpitch = x.pitch; p.Cin = x.c; p.log2_cvecs = l2;
   p.Wrows = d->w_rows; p.Ho = y.h; p.Wo = y.w; p.ypitch = y.pitch; p.Cout = y.c;
   p.act = d->act; p.slope = d->slope; p.out_f32 = d->y_f32 || d->dtype == GAN_F32;
-  p.parity = 0; p.OS = 1; p.wy0 = p.wx0 = 0; p.wstep = 1; p.TWlog2 = 2; p.T = 16;
+  p.vec_store = (!d->y_f32 || d->dtype == GAN_F32) && y.c % vec == 0 && y.pitch % vec == 0 && ((uintptr_t)y.ptr % 16) == 0;
+  p.parity = 0; p.OS = 1; p.wy0 = p.wx0 = 0; p.wstep = 1; p.TWlog2 = 2; p.T = 16; p.log2T = 4;
   const bool parity = (op == 1 && d->stride == 2) || op == 2;
   if (parity) {            // convT forward / stride-2 conv dgrad: 4 output-parity sub-GEMMs
     if (d->stride != 2 || y.h != 2 * x.h || y.w != 2 * x.w) return GAN_E_SHAPE;
-    p.parity = 1; p.OS = 2; p.S = 1; p.TWlog2 = 1; p.T = 4; p.dstep = -1; p.wstep = 2;
+    p.parity = 1; p.OS = 2; p.S = 1; p.TWlog2 = 1; p.T = 4; p.log2T = 2; p.dstep = -1; p.wstep = 2;
     p.dy0 = p.dx0 = 0; p.Hg = x.h; p.Wg = x.w;
   } else if (op == 0 || op == 3) {   // conv forward (stride s) / convT dgrad (= conv s2 over dy)
     int s = (op == 3) ? 2 : d->stride;
@@ -266,29 +374,43 @@ static int plan_gemm(const GanConvDesc* d, int op, GemmPlan* pl) {
   long long M = (long long)x.n * p.Hg * p.Wg;
   if (M <= 0 || M > 0x7fffffffLL) return GAN_E_SHAPE;
   p.M = (int)M;
-  const int bke = 128 / (d->dtype == GAN_F32 ? 4 : 2);
-  long long K = (long long)p.T * x.c;
-  if (K % bke) return GAN_E_SHAPE;
-  p.kchunks = (int)(K / bke);
+  const long long Kbytes = (long long)p.T * x.c * (d->dtype == GAN_F32 ? 4 : 2);
+  if (Kbytes % 128) return GAN_E_SHAPE;
   const int P = parity ? 4 : 1;
   pl->P = P;
+  // Tile choice.  The 128x128 tile needs ~38 TB/s of L2->LDS traffic at the MFMA peak (65 FLOP per byte
+  // staged), more than the L2s deliver, so big layers use 256-row tiles (512 threads, one block per CU);
+  // efficiency of a candidate = relative tile quality x how full its last round of blocks is.
   int BN = y.c > 64 ? 128 : (y.c > 16 ? 64 : 16);
-  int tilesN = (y.c + BN - 1) / BN;
   int BM = 128;
-  if (((M + 127) / 128) * tilesN * P < 192) BM = 64;
+  if (((M + 127) / 128) * ((y.c + BN - 1) / BN) * P < 192) BM = 64;
   if (BM == 64 && M <= 32 && BN != 16) BM = 16;
-  long long blocks = ((M + BM - 1) / BM) * tilesN * P;
+  if (y.c >= 128 && M >= 256 && !getenv("GAN_AMD_NO_BIG_TILES")) {
+    auto fill = [](long long blocks, long long slots) { return (double)blocks / (double)(((blocks + slots - 1) / slots) * slots); };
+    const long long b128 = ((M + 127) / 128) * ((y.c + 127) / 128) * P;
+    const long long b256n = ((M + 255) / 256) * ((y.c + 127) / 128) * P;
+    const long long b256 = ((M + 255) / 256) * ((y.c + 255) / 256) * P;
+    double best = 0.55 * fill(b128, 512);
+    if (b256n >= 128 && 0.8 * fill(b256n, 256) > best) { best = 0.8 * fill(b256n, 256); BM = 256; BN = 128; }
+    if (y.c >= 256 && b256 >= 128 && 1.0 * fill(b256, 256) > best) { BM = 256; BN = 256; }
+  }
+  p.kchunks = (int)(Kbytes / cfg_bkb(BM, BN));
+  int tilesN = (y.c + BN - 1) / BN;
+  long long tilesM = (M + BM - 1) / BM;
+  long long blocks = tilesM * tilesN * P;
   int splits = 1;
-  if (blocks < 256) {
-    splits = (int)((512 + blocks - 1) / blocks);
-    int maxs = p.kchunks / 2; if (maxs < 1) maxs = 1;
+  const long long target = BM == 256 ? 128 : (BN == 16 ? 1024 : 512);   // BN=16: streaming layers want more, shorter blocks
+  if (blocks < target) {
+    splits = (int)((target + blocks - 1) / blocks);
+    int maxs = p.kchunks / 4; if (maxs < 1) maxs = 1;
     if (splits > maxs) splits = maxs;
-    if (splits > 32) splits = 32;
+    if (splits > 64) splits = 64;
   }
   p.splits = splits;
   p.NslabPitch = tilesN * BN;
+  p.tilesM = (int)tilesM; p.tilesN = tilesN;
   pl->BM = BM; pl->BN = BN;
-  pl->grid = dim3((unsigned)((M + BM - 1) / BM), (unsigned)tilesN, (unsigned)(P * splits));
+  pl->grid = dim3((unsigned)(tilesM * tilesN), 1, (unsigned)(P * splits));
   pl->slab_bytes = splits > 1 ? (size_t)P * splits * (size_t)M * p.NslabPitch * sizeof(float) : 0;
   return 0;
 }
@@ -296,14 +418,17 @@ static int plan_gemm(const GanConvDesc* d, int op, GemmPlan* pl) {
 template <typename T, int BM, int BN, int WM, int WN>
 static int launch_cfg(const GemmPlan& pl, hipStream_t st) {
   static bool attr_set = false;
-  constexpr size_t smem = 2 * (BM + BN) * 144;
-  auto kern = conv_gemm_kernel<T, BM, BN, WM, WN>;
+  constexpr int BKB = cfg_bkb(BM, BN), NS = cfg_ns(BM, BN);
+  constexpr size_t stage2 = (size_t)NS * (BM + BN) * BKB + 16 * BM * sizeof(int);   // stages + gather table
+  constexpr size_t cs = (size_t)WM * 16 * (BN * sizeof(T) + (sizeof(T) == 2 ? 32 : 16));
+  constexpr size_t smem = stage2 > cs ? stage2 : cs;
+  auto kern = conv_gemm_kernel<T, BM, BN, WM, WN, BKB, NS>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, pl.grid, dim3(256), smem, st, pl.p);
+  hipLaunchKernelGGL(kern, pl.grid, dim3(64 * WM * WN), smem, st, pl.p);
   GAN_CHECK_LAUNCH();
   return 0;
 }
@@ -313,6 +438,8 @@ static int launch_gemm(const GemmPlan& pl, hipStream_t st) {
   int rc;
   const int key = pl.BM * 1000 + pl.BN;
   switch (key) {
+    case 256256: rc = launch_cfg<T, 256, 256, 2, 4>(pl, st); break;
+    case 256128: rc = launch_cfg<T, 256, 128, 4, 2>(pl, st); break;
     case 128128: rc = launch_cfg<T, 128, 128, 2, 2>(pl, st); break;
     case 128064: rc = launch_cfg<T, 128, 64, 2, 2>(pl, st); break;
     case 128016: rc = launch_cfg<T, 128, 16, 4, 1>(pl, st); break;
@@ -341,6 +468,12 @@ static int run_gemm(const GanConvDesc* d, int op, gan_stream_t stream) {
   return d->dtype == GAN_F32 ? launch_gemm<float>(pl, st) : launch_gemm<bf16_t>(pl, st);
 }
 
+static void plan_only_desc(GanConvDesc* t) {   // planning only looks at shapes and alignment
+  if (!t->x.ptr) t->x.ptr = (void*)16;
+  if (!t->y.ptr) t->y.ptr = (void*)16;
+  if (!t->w) t->w = (void*)16;
+}
+
 extern "C" {
 int gan_conv2d_fwd(const GanConvDesc* d, gan_stream_t s) { return run_gemm(d, 0, s); }
 int gan_conv2d_dgrad(const GanConvDesc* d, gan_stream_t s) { return run_gemm(d, 1, s); }
@@ -349,9 +482,7 @@ int gan_convT2d_dgrad(const GanConvDesc* d, gan_stream_t s) { return run_gemm(d,
 int gan_conv_plan_info(const GanConvDesc* d, int op, int32_t* info /*[4]: BM, BN, splits, parities*/) {
   GemmPlan pl;
   GanConvDesc t = *d;
-  if (!t.x.ptr) t.x.ptr = (void*)16;
-  if (!t.y.ptr) t.y.ptr = (void*)16;
-  if (!t.w) t.w = (void*)16;
+  plan_only_desc(&t);
   int rc = plan_gemm(&t, op, &pl);
   if (rc) return rc;
   info[0] = pl.BM; info[1] = pl.BN; info[2] = pl.p.splits; info[3] = pl.P;
@@ -360,9 +491,7 @@ int gan_conv_plan_info(const GanConvDesc* d, int op, int32_t* info /*[4]: BM, BN
 size_t gan_conv_workspace_bytes(const GanConvDesc* d, int op) {
   GemmPlan pl;
   GanConvDesc t = *d;
-  if (!t.x.ptr) t.x.ptr = (void*)16;   // planning only looks at shapes
-  if (!t.y.ptr) t.y.ptr = (void*)16;
-  if (!t.w) t.w = (void*)16;
+  plan_only_desc(&t);
   if (plan_gemm(&t, op, &pl)) return 0;
   return pl.slab_bytes;
 }

@@ -1,0 +1,444 @@
+// Normalisation (BatchNorm / InstanceNorm as "statistics groups") + dropout + activation, forward and
+// backward, plus activation-only backward and bias gradients.  All HBM-bound: 16-byte vector accesses on
+// NHWC rows, 4 independent rows in flight per thread (memory-level parallelism instead of a dependent
+// load-compute chain), per-channel parameters fetched as float4.  Reductions are two-stage and
+// deterministic: block partials [group][chunk][C][2] -> a chunk-parallel finalize in double precision.
+#include "common.h"
+
+struct RedGeom {
+  int C, cvecs;            // channels, 16-byte vectors per row
+  long long rows_per_group;
+  int chunks;              // row chunks per group (gridDim.x)
+  int hw, gsize;           // pixels per image, images per group
+  int rslots;              // row slots per 256-thread block = 256 / min(cvecs, 256)
+};
+
+struct NormP {
+  const void* y; int ypitch;
+  const void* da; int dapitch;
+  const void* da2; int da2pitch;
+  void* out; int outpitch;          // a (fwd) or dy (bwd)
+  const float* gamma; const float* beta; const float* mean; const float* rstd;
+  const uint8_t* mask;
+  const float* sums;                // bwd apply: [G][C][2] = (sum dz, sum dz*xhat)
+  int act; float slope;
+  int has_norm;                     // 0: plain activation backward on saved a
+};
+
+template <int VEC>
+__device__ __forceinline__ void ldp(const float* base, float* out) {   // VEC consecutive floats, 16-B aligned
+#pragma unroll
+  for (int i = 0; i < VEC / 4; ++i) {
+    float4 v = *(const float4*)(base + 4 * i);
+    out[4 * i] = v.x; out[4 * i + 1] = v.y; out[4 * i + 2] = v.z; out[4 * i + 3] = v.w;
+  }
+}
+
+template <int VEC>
+__device__ __forceinline__ void ld_mask(const uint8_t* m, float* out) {  // VEC consecutive 0/1 bytes -> 2*mask
+  if (VEC == 8) {
+    uint2 w = *(const uint2*)m;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { out[e] = 2.f * (float)((w.x >> (8 * e)) & 0xff); out[4 + e] = 2.f * (float)((w.y >> (8 * e)) & 0xff); }
+  } else {
+    uint32_t w = *(const uint32_t*)m;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) out[e] = 2.f * (float)((w >> (8 * e)) & 0xff);
+  }
+}
+
+__device__ __forceinline__ float bwd_dz(float da, float z, float mk, int act, float slope) {
+  float zd = z * mk;                // mk = 2*mask or 1
+  float g;
+  if (act == GAN_ACT_LRELU) g = zd > 0.f ? 1.f : slope;
+  else if (act == GAN_ACT_RELU) g = zd > 0.f ? 1.f : 0.f;
+  else g = 1.f;
+  return da * g * mk;
+}
+
+// MODE 0: stats (y, y^2).  MODE 1: norm backward sums (dz, dz*xhat).  MODE 2: column sum of `da` (bias grad).
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void reduce_partial_kernel(const NormP p, const RedGeom g, float* partial) {
+  constexpr int VEC = VecOf<T>::N;
+  constexpr int U = 4;
+  extern __shared__ float lds[];     // [rslots][C][2]
+  const int grp = blockIdx.y, chunk = blockIdx.x;
+  const int cvl = g.cvecs < 256 ? g.cvecs : 256;
+  const int rslots = g.rslots;
+  const int cv = threadIdx.x % cvl, rslot = threadIdx.x / cvl;
+  const long long r0 = g.rows_per_group * chunk / g.chunks, r1 = g.rows_per_group * (chunk + 1) / g.chunks;
+  const long long rowbase = (long long)grp * g.rows_per_group;
+  float* out2 = partial + ((size_t)grp * g.chunks + chunk) * g.C * 2;
+  float s1[VEC], s2[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) s1[e] = s2[e] = 0.f;
+  float ga[VEC], be[VEC], mu[VEC], rs[VEC];
+  if (MODE == 1) {
+    ldp<VEC>(p.mean + grp * g.C + cv * VEC, mu); ldp<VEC>(p.rstd + grp * g.C + cv * VEC, rs);
+    ldp<VEC>(p.gamma + cv * VEC, ga); ldp<VEC>(p.beta + cv * VEC, be);
+  }
+  for (long long rr = r0 + rslot; rr < r1; rr += (long long)rslots * U) {
+    uint4 vy[U], vd[U], v2[U];
+    bool ok[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      long long row = rowbase + rr + (long long)u * rslots;
+      ok[u] = rr + (long long)u * rslots < r1;
+      vy[u] = vd[u] = v2[u] = make_uint4(0, 0, 0, 0);
+      if (ok[u]) {
+        if (MODE != 2) vy[u] = *(const uint4*)((const T*)p.y + row * p.ypitch + cv * VEC);
+        if (MODE != 0) vd[u] = *(const uint4*)((const T*)p.da + row * p.dapitch + cv * VEC);
+        if (MODE == 1 && p.da2) v2[u] = *(const uint4*)((const T*)p.da2 + row * p.da2pitch + cv * VEC);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (!ok[u]) continue;
+      if (MODE == 0) {
+        float v[VEC];
+        unpack16<T>(vy[u], v);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) { s1[e] += v[e]; s2[e] += v[e] * v[e]; }
+      } else if (MODE == 1) {
+        float yv[VEC], dv[VEC], d2[VEC], mk[VEC];
+        unpack16<T>(vy[u], yv); unpack16<T>(vd[u], dv); unpack16<T>(v2[u], d2);
+        if (p.mask) ld_mask<VEC>(p.mask + (rowbase + rr + (long long)u * rslots) * g.C + cv * VEC, mk);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          float xh = (yv[e] - mu[e]) * rs[e];
+          float z = ga[e] * xh + be[e];
+          float dz = bwd_dz(dv[e] + d2[e], z, p.mask ? mk[e] : 1.f, p.act, p.slope);
+          s1[e] += dz; s2[e] += dz * xh;
+        }
+      } else {
+        float dv[VEC];
+        unpack16<T>(vd[u], dv);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) s1[e] += dv[e];
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) {
+    lds[((size_t)rslot * g.C + cv * VEC + e) * 2 + 0] = s1[e];
+    lds[((size_t)rslot * g.C + cv * VEC + e) * 2 + 1] = s2[e];
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < g.C; c += 256) {
+    float a = 0.f, b = 0.f;
+    for (int k = 0; k < rslots; ++k) { a += lds[((size_t)k * g.C + c) * 2]; b += lds[((size_t)k * g.C + c) * 2 + 1]; }
+    out2[c * 2] = a; out2[c * 2 + 1] = b;
+  }
+}
+
+// Sum one (group, channel) pair over chunks: 8 chunk lanes x 32 channels per block.
+__device__ __forceinline__ void chunk_sum(const float* partial, int g, int chunks, int C, int c, int kl, double* red,
+                                          double& s1, double& s2) {
+  double a = 0, b = 0;
+  if (c < C)
+    for (int k = kl; k < chunks; k += 8) {
+      float2 v = *(const float2*)(partial + (((size_t)g * chunks + k) * C + c) * 2);
+      a += v.x; b += v.y;
+    }
+  const int cl = threadIdx.x & 31;
+  red[(kl * 32 + cl) * 2] = a; red[(kl * 32 + cl) * 2 + 1] = b;
+  __syncthreads();
+  s1 = s2 = 0;
+  if (kl == 0)
+    for (int k = 0; k < 8; ++k) { s1 += red[(k * 32 + cl) * 2]; s2 += red[(k * 32 + cl) * 2 + 1]; }
+  __syncthreads();
+}
+
+// groups are processed in order inside a block when moving averages are updated (two successive
+// BatchNormalization calls update them one after the other); otherwise gridDim.y = groups.
+__global__ __launch_bounds__(256) void stats_finalize_kernel(const float* partial, int G, int chunks, int C, long long rows,
+                                                             float eps, float* mean, float* rstd, float* mmean, float* mvar,
+                                                             float momentum) {
+  __shared__ double red[8 * 32 * 2];
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31), kl = threadIdx.x >> 5;
+  const int g0 = mmean ? 0 : blockIdx.y, g1 = mmean ? G : blockIdx.y + 1;
+  for (int g = g0; g < g1; ++g) {
+    double s, s2;
+    chunk_sum(partial, g, chunks, C, c, kl, red, s, s2);
+    if (kl == 0 && c < C) {
+      double m = s / (double)rows;
+      double var = s2 / (double)rows - m * m;
+      if (var < 0) var = 0;
+      mean[g * C + c] = (float)m;
+      rstd[g * C + c] = 1.0f / sqrtf((float)var + eps);
+      if (mmean) {
+        double adj = (double)rows / (double)(rows > 1 ? rows - 1 : 1);
+        mmean[c] += ((float)m - mmean[c]) * (1.f - momentum);
+        mvar[c] += ((float)(var * adj) - mvar[c]) * (1.f - momentum);
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void bwd_finalize_kernel(const float* partial, int G, int chunks, int C, float* sums,
+                                                           float* dgamma, float* dbeta, int accumulate) {
+  __shared__ double red[8 * 32 * 2];
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31), kl = threadIdx.x >> 5;
+  double tg = 0, tb = 0;
+  for (int g = 0; g < G; ++g) {
+    double s1, s2;
+    chunk_sum(partial, g, chunks, C, c, kl, red, s1, s2);
+    if (kl == 0 && c < C) {
+      if (sums) { sums[(g * C + c) * 2] = (float)s1; sums[(g * C + c) * 2 + 1] = (float)s2; }
+      tb += s1; tg += s2;
+    }
+  }
+  if (kl == 0 && c < C) {
+    if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)tg;
+    if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)tb;
+  }
+}
+
+// forward: a = act(dropout(gamma*(y-mean)*rstd + beta)); each thread: one channel vector x 4 rows
+template <typename T>
+__global__ __launch_bounds__(256) void norm_act_fwd_kernel(const NormP p, const RedGeom g, long long rows) {
+  constexpr int VEC = VecOf<T>::N;
+  constexpr int U = 4;
+  long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int cv = (int)(idx % g.cvecs);
+  const long long rb = idx / g.cvecs * U;
+  if (rb >= rows) return;
+  uint4 vy[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u)
+    vy[u] = rb + u < rows ? *(const uint4*)((const T*)p.y + (rb + u) * p.ypitch + cv * VEC) : make_uint4(0, 0, 0, 0);
+  float ga[VEC], be[VEC], mu[VEC], rs[VEC];
+  ldp<VEC>(p.gamma + cv * VEC, ga); ldp<VEC>(p.beta + cv * VEC, be);
+  int cur = -1;
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const long long row = rb + u;
+    if (row >= rows) break;
+    const int grp = (int)((row / g.hw) / g.gsize);
+    if (grp != cur) { ldp<VEC>(p.mean + grp * g.C + cv * VEC, mu); ldp<VEC>(p.rstd + grp * g.C + cv * VEC, rs); cur = grp; }
+    float v[VEC], o[VEC], mk[VEC];
+    unpack16<T>(vy[u], v);
+    if (p.mask) ld_mask<VEC>(p.mask + row * g.C + cv * VEC, mk);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      float z = ga[e] * ((v[e] - mu[e]) * rs[e]) + be[e];
+      if (p.mask) z *= mk[e];
+      o[e] = apply_act(z, p.act, p.slope);
+    }
+    *(uint4*)((T*)p.out + row * p.outpitch + cv * VEC) = pack16<T>(o);
+  }
+}
+
+// backward apply: dy = gamma*rstd*(dz - S1/R - xhat*S2/R)      (has_norm)
+//                 dy = (da+da2) * act'(a)                       (!has_norm; y holds the saved activation a)
+template <typename T>
+__global__ __launch_bounds__(256) void norm_act_bwd_kernel(const NormP p, const RedGeom g, long long rows) {
+  constexpr int VEC = VecOf<T>::N;
+  constexpr int U = 4;
+  long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int cv = (int)(idx % g.cvecs);
+  const long long rb = idx / g.cvecs * U;
+  if (rb >= rows) return;
+  uint4 vy[U], vd[U], v2[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const bool ok = rb + u < rows;
+    vy[u] = ok ? *(const uint4*)((const T*)p.y + (rb + u) * p.ypitch + cv * VEC) : make_uint4(0, 0, 0, 0);
+    vd[u] = ok ? *(const uint4*)((const T*)p.da + (rb + u) * p.dapitch + cv * VEC) : make_uint4(0, 0, 0, 0);
+    v2[u] = (ok && p.da2) ? *(const uint4*)((const T*)p.da2 + (rb + u) * p.da2pitch + cv * VEC) : make_uint4(0, 0, 0, 0);
+  }
+  float ga[VEC], be[VEC], mu[VEC], rs[VEC], q1[VEC], q2[VEC];
+  if (p.has_norm) { ldp<VEC>(p.gamma + cv * VEC, ga); ldp<VEC>(p.beta + cv * VEC, be); }
+  const float invR = 1.0f / (float)g.rows_per_group;
+  int cur = -1;
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const long long row = rb + u;
+    if (row >= rows) break;
+    float yv[VEC], dv[VEC], d2[VEC], o[VEC];
+    unpack16<T>(vy[u], yv); unpack16<T>(vd[u], dv); unpack16<T>(v2[u], d2);
+    if (p.has_norm) {
+      const int grp = (int)((row / g.hw) / g.gsize);
+      if (grp != cur) {
+        ldp<VEC>(p.mean + grp * g.C + cv * VEC, mu); ldp<VEC>(p.rstd + grp * g.C + cv * VEC, rs);
+        float t[2 * VEC];
+        ldp<2 * VEC>(p.sums + ((size_t)grp * g.C + cv * VEC) * 2, t);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) { q1[e] = t[2 * e] * invR; q2[e] = t[2 * e + 1] * invR; }
+        cur = grp;
+      }
+      float mk[VEC];
+      if (p.mask) ld_mask<VEC>(p.mask + row * g.C + cv * VEC, mk);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        float xh = (yv[e] - mu[e]) * rs[e];
+        float z = ga[e] * xh + be[e];
+        float dz = bwd_dz(dv[e] + d2[e], z, p.mask ? mk[e] : 1.f, p.act, p.slope);
+        o[e] = ga[e] * rs[e] * (dz - q1[e] - xh * q2[e]);
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        float a = yv[e], gq;
+        if (p.act == GAN_ACT_LRELU) gq = a > 0.f ? 1.f : p.slope;
+        else if (p.act == GAN_ACT_RELU) gq = a > 0.f ? 1.f : 0.f;
+        else if (p.act == GAN_ACT_TANH) gq = 1.f - a * a;
+        else gq = 1.f;
+        o[e] = (dv[e] + d2[e]) * gq;
+      }
+    }
+    *(uint4*)((T*)p.out + row * p.outpitch + cv * VEC) = pack16<T>(o);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+static int pick_chunks(long long rows_per_group, int rslots, int groups) {
+  long long ch = (rows_per_group + (long long)rslots * 16 - 1) / ((long long)rslots * 16);
+  long long cap = 2048 / groups; if (cap < 1) cap = 1;
+  if (ch > cap) ch = cap;
+  if (ch < 1) ch = 1;
+  return (int)ch;
+}
+static int red_geom(const GanTensor& t, int groups, int dtype, RedGeom* g) {
+  const int vec = dtype == GAN_F32 ? 4 : 8;
+  if (t.c <= 0 || t.c % 8 || t.pitch % 8 || groups <= 0 || t.n % groups) return GAN_E_SHAPE;
+  g->C = t.c; g->cvecs = t.c / vec; g->hw = t.h * t.w; g->gsize = t.n / groups;
+  if (g->cvecs > 256 || (g->cvecs & (g->cvecs - 1))) return GAN_E_SHAPE;
+  g->rslots = 256 / g->cvecs;
+  g->rows_per_group = (long long)g->gsize * g->hw;
+  g->chunks = pick_chunks(g->rows_per_group, g->rslots, groups);
+  return 0;
+}
+static size_t red_ws_bytes(int groups, int chunks, int c) {
+  return ((size_t)groups * chunks * c * 2 + (size_t)groups * c * 2) * sizeof(float);
+}
+
+template <typename T, int MODE>
+static int launch_partial(const NormP& p, const RedGeom& g, int groups, float* partial, hipStream_t st) {
+  size_t lds = (size_t)g.rslots * g.C * 2 * sizeof(float);
+  hipLaunchKernelGGL((reduce_partial_kernel<T, MODE>), dim3(g.chunks, groups), dim3(256), lds, st, p, g, partial);
+  GAN_CHECK_LAUNCH();
+  return 0;
+}
+
+template <typename T, typename K>
+static int launch_rows(K kern, const NormP& p, const RedGeom& g, long long rows, hipStream_t st) {
+  long long threads = (rows + 3) / 4 * g.cvecs;
+  hipLaunchKernelGGL(kern, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, p, g, rows);
+  GAN_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" {
+
+size_t gan_norm_workspace_bytes(int32_t groups, int32_t c, int64_t rows_per_group) {
+  int cvecs = c / 4; if (cvecs < 1) cvecs = 1; if (cvecs > 256) cvecs = 256;   // fp32 layout = upper bound
+  return red_ws_bytes(groups, pick_chunks(rows_per_group, 256 / cvecs, groups), c);
+}
+
+int gan_norm_stats(const GanNormDesc* d, gan_stream_t stream) {
+  if (!d || !d->y.ptr || !d->mean || !d->rstd || !d->workspace) return GAN_E_ARG;
+  RedGeom g;
+  int rc = red_geom(d->y, d->groups, d->dtype, &g);
+  if (rc) return rc;
+  if (red_ws_bytes(d->groups, g.chunks, g.C) > d->workspace_bytes) return GAN_E_WORKSPACE;
+  NormP p = {};
+  p.y = d->y.ptr; p.ypitch = d->y.pitch;
+  hipStream_t st = (hipStream_t)stream;
+  float* partial = (float*)d->workspace;
+  rc = d->dtype == GAN_F32 ? launch_partial<float, 0>(p, g, d->groups, partial, st)
+                           : launch_partial<bf16_t, 0>(p, g, d->groups, partial, st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(stats_finalize_kernel, dim3((g.C + 31) / 32, d->moving_mean ? 1 : d->groups), dim3(256), 0, st,
+                     (const float*)partial, d->groups, g.chunks, g.C, g.rows_per_group, d->eps, d->mean, d->rstd,
+                     d->moving_mean, d->moving_var, d->momentum);
+  GAN_CHECK_LAUNCH();
+  return 0;
+}
+
+int gan_norm_act_fwd(const GanNormDesc* d, gan_stream_t stream) {
+  if (!d || !d->y.ptr || !d->a.ptr || !d->mean || !d->rstd || !d->gamma || !d->beta) return GAN_E_ARG;
+  RedGeom g;
+  int rc = red_geom(d->y, d->groups, d->dtype, &g);
+  if (rc) return rc;
+  if (d->a.pitch % 8 || d->a.c != d->y.c) return GAN_E_SHAPE;
+  NormP p = {};
+  p.y = d->y.ptr; p.ypitch = d->y.pitch; p.out = d->a.ptr; p.outpitch = d->a.pitch;
+  p.gamma = d->gamma; p.beta = d->beta; p.mean = d->mean; p.rstd = d->rstd; p.mask = d->dropmask;
+  p.act = d->act; p.slope = d->slope;
+  long long rows = (long long)d->y.n * g.hw;
+  hipStream_t st = (hipStream_t)stream;
+  return d->dtype == GAN_F32 ? launch_rows<float>(norm_act_fwd_kernel<float>, p, g, rows, st)
+                             : launch_rows<bf16_t>(norm_act_fwd_kernel<bf16_t>, p, g, rows, st);
+}
+
+int gan_norm_act_bwd(const GanNormBwdDesc* d, gan_stream_t stream) {
+  if (!d || !d->y.ptr || !d->da.ptr || !d->dy.ptr || !d->mean || !d->rstd || !d->gamma || !d->beta || !d->workspace)
+    return GAN_E_ARG;
+  RedGeom g;
+  int rc = red_geom(d->y, d->groups, d->dtype, &g);
+  if (rc) return rc;
+  if (d->da.pitch % 8 || d->dy.pitch % 8 || (d->da2.ptr && d->da2.pitch % 8)) return GAN_E_SHAPE;
+  if (red_ws_bytes(d->groups, g.chunks, g.C) > d->workspace_bytes) return GAN_E_WORKSPACE;
+  NormP p = {};
+  p.y = d->y.ptr; p.ypitch = d->y.pitch; p.da = d->da.ptr; p.dapitch = d->da.pitch;
+  p.da2 = d->da2.ptr; p.da2pitch = d->da2.pitch; p.out = d->dy.ptr; p.outpitch = d->dy.pitch;
+  p.gamma = d->gamma; p.beta = d->beta; p.mean = d->mean; p.rstd = d->rstd; p.mask = d->dropmask;
+  p.act = d->act; p.slope = d->slope; p.has_norm = 1;
+  float* partial = (float*)d->workspace;
+  float* sums = partial + (size_t)d->groups * g.chunks * g.C * 2;
+  p.sums = sums;
+  hipStream_t st = (hipStream_t)stream;
+  rc = d->dtype == GAN_F32 ? launch_partial<float, 1>(p, g, d->groups, partial, st)
+                           : launch_partial<bf16_t, 1>(p, g, d->groups, partial, st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(bwd_finalize_kernel, dim3((g.C + 31) / 32), dim3(256), 0, st, (const float*)partial, d->groups,
+                     g.chunks, g.C, sums, d->dgamma, d->dbeta, d->accumulate);
+  GAN_CHECK_LAUNCH();
+  long long rows = (long long)d->y.n * g.hw;
+  return d->dtype == GAN_F32 ? launch_rows<float>(norm_act_bwd_kernel<float>, p, g, rows, st)
+                             : launch_rows<bf16_t>(norm_act_bwd_kernel<bf16_t>, p, g, rows, st);
+}
+
+static int bias_grad_impl(int32_t dtype, const GanTensor& dy, float* dbias, int32_t accumulate, void* workspace,
+                          size_t workspace_bytes, hipStream_t st) {
+  RedGeom g;
+  int rc = red_geom(dy, 1, dtype, &g);
+  if (rc) return rc;
+  if (!workspace || red_ws_bytes(1, g.chunks, g.C) > workspace_bytes) return GAN_E_WORKSPACE;
+  NormP q = {};
+  q.da = dy.ptr; q.dapitch = dy.pitch;
+  float* partial = (float*)workspace;
+  rc = dtype == GAN_F32 ? launch_partial<float, 2>(q, g, 1, partial, st) : launch_partial<bf16_t, 2>(q, g, 1, partial, st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(bwd_finalize_kernel, dim3((g.C + 31) / 32), dim3(256), 0, st, (const float*)partial, 1, g.chunks, g.C,
+                     (float*)nullptr, (float*)nullptr, dbias, accumulate);
+  GAN_CHECK_LAUNCH();
+  return 0;
+}
+
+int gan_act_bwd(const GanActBwdDesc* d, gan_stream_t stream) {
+  if (!d || !d->a.ptr || !d->da.ptr || !d->dy.ptr) return GAN_E_ARG;
+  RedGeom g;
+  int rc = red_geom(d->a, 1, d->dtype, &g);
+  if (rc) return rc;
+  if (d->da.pitch % 8 || d->dy.pitch % 8 || (d->da2.ptr && d->da2.pitch % 8)) return GAN_E_SHAPE;
+  NormP p = {};
+  p.y = d->a.ptr; p.ypitch = d->a.pitch; p.da = d->da.ptr; p.dapitch = d->da.pitch;
+  p.da2 = d->da2.ptr; p.da2pitch = d->da2.pitch; p.out = d->dy.ptr; p.outpitch = d->dy.pitch;
+  p.act = d->act; p.slope = d->slope; p.has_norm = 0;
+  hipStream_t st = (hipStream_t)stream;
+  long long rows = (long long)d->a.n * g.hw;
+  rc = d->dtype == GAN_F32 ? launch_rows<float>(norm_act_bwd_kernel<float>, p, g, rows, st)
+                           : launch_rows<bf16_t>(norm_act_bwd_kernel<bf16_t>, p, g, rows, st);
+  if (rc) return rc;
+  if (d->dbias) return bias_grad_impl(d->dtype, d->dy, d->dbias, d->accumulate, d->workspace, d->workspace_bytes, st);
+  return 0;
+}
+
+int gan_bias_grad(int32_t dtype, const GanTensor* dy, float* dbias, int32_t accumulate, void* workspace,
+                  size_t workspace_bytes, gan_stream_t stream) {
+  if (!dy || !dy->ptr || !dbias) return GAN_E_ARG;
+  return bias_grad_impl(dtype, *dy, dbias, accumulate, workspace, workspace_bytes, (hipStream_t)stream);
+}
+}  // extern "C"

@@ -208,11 +208,21 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
 }
 
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* slab, float* dw, long long count, int splits, int accumulate) {
-  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= count) return;
+  // 32 elements x 8 split-lanes per block: the sum over (up to 1024) slabs is not one dependent chain
+  __shared__ float red[8][33];
+  const int el = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const long long i = (long long)blockIdx.x * 32 + el;
   float s = 0.f;
-  for (int k = 0; k < splits; ++k) s += slab[(size_t)k * count + i];
-  dw[i] = accumulate ? dw[i] + s : s;
+  if (i < count)
+    for (int k = sl; k < splits; k += 8) s += slab[(size_t)k * count + i];
+  red[sl][el] = s;
+  __syncthreads();
+  if (sl == 0 && i < count) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += red[k][el];
+    dw[i] = accumulate ? dw[i] + t : t;
+  }
 }
 
 struct WgradPlan { WgradParams p; int TA, TB; dim3 grid; size_t slab_bytes; };
@@ -250,11 +260,12 @@ static int plan_wgrad(const GanWgradDesc* d, WgradPlan* pl) {
   p.kchunks = (int)((M + bkm - 1) / bkm);
   long long blocks = (long long)tilesA * tilesB * taps;
   int splits = 1;
-  if (blocks < 256) {
-    splits = (int)((256 + blocks - 1) / blocks);
+  const long long target = p.fold ? 1024 : 256;     // fold mode streams the SMALL tensor once: HBM-bound, wants many blocks
+  if (blocks < target) {
+    splits = (int)((target + blocks - 1) / blocks);
     int maxs = p.kchunks / 4; if (maxs < 1) maxs = 1;
     if (splits > maxs) splits = maxs;
-    if (splits > 64) splits = 64;
+    if (splits > 1024) splits = 1024;
   }
   p.splits = splits;
   pl->TA = TA; pl->TB = TB;
@@ -311,7 +322,7 @@ int gan_conv_wgrad(const GanWgradDesc* d, gan_stream_t stream) {
   if (rc) return rc;
   if (pl.p.splits > 1) {
     long long count = (long long)16 * pl.p.CaReal * pl.p.CbReal;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((count + 31) / 32)), dim3(256), 0, st,
                        (const float*)pl.p.slab, pl.p.dw, count, pl.p.splits, pl.p.accumulate);
     GAN_CHECK_LAUNCH();
   }

@@ -230,7 +230,8 @@ class _Builder:
         creal = k_real or x.c
         M = x.n * (x.h * x.w if info[3] == 4 else y.h * y.w)
         flops = 2.0 * M * info[3] * T * y.c * creal
-        meta = dict(kind='gemm', kernel=f"conv_gemm<{self.ctx.dtype},{info[0]},{info[1]}>", flops=flops, splits=info[2])
+        meta = dict(kind='gemm', kernel=f"conv_gemm<{self.ctx.dtype},{info[0]},{info[1]}>", flops=flops, splits=info[2],
+                    shape=f"{op} M{M}{'x4' if info[3] == 4 else ''} N{y.c} K{T * x.c} s{info[2]}")
         return (fn, (self._desc(d),), op, meta)
 
     def wgrad(self, big, small, dw_ptr, big_c, small_c, stride, accumulate):
@@ -242,7 +243,8 @@ class _Builder:
         info = (C.c_int32 * 4)()
         self.lib.gan_wgrad_plan_info(C.byref(d), info)
         flops = 2.0 * small.n * small.h * small.w * 16 * big_c * small_c
-        meta = dict(kind='gemm', kernel=f"wgrad<{self.ctx.dtype},{info[0]},{info[1]}>", flops=flops, splits=info[2])
+        meta = dict(kind='gemm', kernel=f"wgrad<{self.ctx.dtype},{info[0]},{info[1]}>", flops=flops, splits=info[2],
+                    shape=f"wgrad A{big_c} B{small_c} M{small.n * small.h * small.w} s{info[2]}")
         return (self.lib.gan_conv_wgrad, (self._desc(d),), "conv_wgrad", meta)
 
     def norm_names(self):

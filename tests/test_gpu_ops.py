@@ -78,6 +78,9 @@ CONV_CASES = [  # (N, H, Cin, Cout, stride)
     (2, 32, 256, 512, 1),   # D conv4: 32 -> 31
     (2, 31, 512, 1, 1),     # D last: 31 -> 30, Cout = 1
     (1, 64, 64, 128, 2),    # M = 1024
+    (8, 128, 64, 256, 2),   # M = 32768, N = 256: 256x256 tile (8 waves)
+    (8, 128, 64, 128, 2),   # M = 32768, N = 128: 256x128 tile
+    (5, 100, 64, 128, 2),   # M = 12500: ragged last tile
 ]
 
 
@@ -133,6 +136,7 @@ CONVT_CASES = [  # (N, h, Cin, Cout)
     (2, 32, 256, 64),
     (2, 32, 128, 1),        # head: Cout = 1, bias + tanh
     (1, 16, 128, 3),        # head, 3 channels
+    (4, 64, 128, 128),      # M = 16384 x 4 parities: 256x128 tile
 ]
 
 
