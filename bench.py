@@ -28,7 +28,7 @@ MFMA_PEAK_TFLOPS = 2500.0      # dense bf16, MI355X_MICROARCH.md chip table
 HBM_PEAK_GBS = 8000.0
 
 
-def gemm_profile(step, inputs, reps=3):
+def gemm_profile(step, inputs, reps=5):
     """Eager (non-graph) instrumented passes: HIP events around every GEMM-type launch, on the stream the
     kernels run on.  Returns {kernel symbol: (total_ms_per_step, total_flops_per_step, launches_per_step)}."""
     ctx = step.ctx
@@ -49,6 +49,8 @@ def gemm_profile(step, inputs, reps=3):
                 recs.setdefault(meta['kernel'], []).append((e0, e1, meta['flops']))
             if rc:
                 raise RuntimeError(f"{op[2]} failed rc={rc}")
+    step._run(*inputs, training=True)          # untimed eager pass (first eager launches pay one-time costs)
+    torch.cuda.synchronize()
     ctx.run = timed_run
     try:
         for _ in range(reps):
@@ -58,9 +60,11 @@ def gemm_profile(step, inputs, reps=3):
         ctx.run = orig_run
     out = {}
     for k, lst in recs.items():
-        ms = sum(a.elapsed_time(b) for a, b, _ in lst) / reps
-        fl = sum(f for _, _, f in lst) / reps
-        out[k] = (ms, fl, len(lst) // reps)
+        n = len(lst) // reps                   # launches of this kernel per step
+        per_rep = [sum(a.elapsed_time(b) for a, b, _ in lst[r * n:(r + 1) * n]) for r in range(reps)]
+        ms = sorted(per_rep)[reps // 2]        # median over the passes
+        fl = sum(f for _, _, f in lst[:n])
+        out[k] = (ms, fl, n)
     return out
 
 

@@ -1,0 +1,262 @@
+"""Pix2Pix with the reference's surface (pix2pix.py:27-461): class `Pix2Pix(GAN)`, `train_step`, `fit`,
+`predict`, `parse_opt`, `main` — same flags, defaults, assertions, run-directory layout and metric keys; the
+arithmetic of `train_step` runs as one captured hipGraph of hand-written MI355X kernels (gan_amd/steps.py)."""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from datetime import datetime
+
+import numpy as np
+import torch
+
+from . import data as D
+from .base_gan import GAN
+from .checkpoint import Checkpoint, CheckpointManager, latest_checkpoint
+from .steps import Pix2PixStep
+from .utils import make_fig, pix2pix_losses
+
+
+class Pix2Pix(GAN):
+    def __init__(self, config):
+        super().__init__(config)
+        c = int(self.config['channels'])
+        seed = int(self.config.get('seed', 123))
+        self.generator = super().Generator(shape=(self.config['img_size'], self.config['img_size'], c), seed=seed)
+        self.discriminator = super().Discriminator(target=True, seed=seed + 1)
+        mk = lambda: super(Pix2Pix, self).optimizer(learning_rate=self.config['learning_rate'], beta_1=self.config['beta_1'],
+                                                   beta_2=self.config['beta_2'])
+        self.generator_optimizer = mk().bind(self.generator.net.params)
+        self.discriminator_optimizer = mk().bind(self.discriminator.net.params)
+        self._steps = {}          # (batch, training) -> (Pix2PixStep, graph replay)
+        self._rng = np.random.default_rng(seed)
+        self.sync = None          # gan_amd.ddp.GradSync for data-parallel training
+
+    # ---- input pipeline (pix2pix.py:34-165) ------------------------------------------------------
+    def split_img(self, image_file: str):
+        return D.split_img(super().load(image_file, resize=False), self.config['input_img_orient'])
+
+    def random_crop(self, input_image, real_image, height: int, width: int):
+        y, x = self._rng.integers(0, input_image.shape[0] - height + 1), self._rng.integers(0, input_image.shape[1] - width + 1)
+        return input_image[y:y + height, x:x + width], real_image[y:y + height, x:x + width]
+
+    def random_jitter(self, input_image, real_image):
+        return D.random_jitter_pair(input_image, real_image, self.config['img_size'], self._rng)
+
+    def process_images_train(self, image_file: str):
+        a, b = self.split_img(image_file)
+        a, b = self.random_jitter(a, b)
+        return super().normalize(a), super().normalize(b)
+
+    def process_images_pred(self, image_file: str):
+        a, b = self.split_img(image_file)
+        s = self.config['img_size']
+        return super().normalize(super().resize(a, s, s)), super().normalize(super().resize(b, s, s))
+
+    def image_pipeline(self, predict: bool = False):
+        print("\nReading in and processing images.\n", flush=True)
+        contents = [i for i in os.listdir(self.config['data']) if 'png' in i or 'jpg' in i]
+        assert contents, "No images found in data directory!"
+        full = lambda names: [self.config['data'] + '/' + i for i in names]
+        dev = self.ctx.device
+        if predict:
+            return D.Batches(full(contents), self.process_images_pred, 1, None), None, None
+        train, val, test = D.pix2pix_split(contents, self.config['seed'], self.config['test_img'], self.config['validation_size'])
+        bs = self.config["batch_size"]
+        return (D.Batches(full(train), self.process_images_train, bs, dev),
+                D.Batches(full(val), self.process_images_pred, bs, dev),
+                D.Batches(full(test), self.process_images_pred, bs, dev))
+
+    # ---- losses / step (pix2pix.py:167-218) ------------------------------------------------------
+    def generator_loss(self, disc_generated_output, gen_output, target, input_image):
+        gan_loss = self.loss_obj(1.0, disc_generated_output)
+        assert self.config['generator_loss'] == 'l1', "only the default l1 secondary loss is on the accelerated path"
+        gan_loss2 = (torch.as_tensor(target, device=self.ctx.device).float() - gen_output).abs().mean()
+        return gan_loss + (self.config['lambda'] * gan_loss2), gan_loss, gan_loss2
+
+    def _step_for(self, batch, training):
+        key = (batch, bool(training))
+        if key not in self._steps:
+            st = Pix2PixStep(self.ctx, batch, self.config['img_size'], int(self.config['channels']), lam=self.config['lambda'],
+                             lr=self.config['learning_rate'], beta_1=self.config['beta_1'], beta_2=self.config['beta_2'],
+                             seed=int(self.config.get('seed', 123)), nets=(self.generator.net, self.discriminator.net))
+            st.sync = self.sync
+            saved = self._snapshot() if training else None     # capture() runs warm-up steps: undo them
+            replay = st.capture(training=training)
+            if saved is not None:
+                self._restore(saved)
+            self._steps[key] = (st, replay)
+        return self._steps[key]
+
+    def _snapshot(self):
+        return [(ps, ps.master.clone(), ps.m.clone(), ps.v.clone(), ps.step.clone(), {k: v.clone() for k, v in ps.state.items()})
+                for ps in (self.generator.net.params, self.discriminator.net.params)]
+
+    def _restore(self, saved):
+        for ps, w, m, v, step, state in saved:
+            ps.master.copy_(w); ps.m.copy_(m); ps.v.copy_(v); ps.step.copy_(step)
+            for k, t in state.items():
+                ps.state[k].copy_(t)
+            ps.prepare()
+
+    def train_step(self, input_image, target, training: bool = True):
+        """-> (gen_total_loss, gen_gan_loss, gen_gan_loss2, disc_loss) as 0-d device tensors (no host sync)."""
+        x = torch.as_tensor(input_image).to(self.ctx.device, torch.float32)
+        y = torch.as_tensor(target).to(self.ctx.device, torch.float32)
+        st, replay = self._step_for(x.shape[0], training)
+        losses = replay(x.contiguous(), y.contiguous())[:4].clone()
+        return losses[0], losses[1], losses[2], losses[3]
+
+    # ---- images / loops (pix2pix.py:220-339) -----------------------------------------------------
+    def generate_images(self, model, test_input, tar, path_filename: str):
+        import matplotlib
+        matplotlib.use('Agg')
+        import matplotlib.pyplot as plt
+        prediction = model(test_input, training=True).cpu().numpy()
+        test_input, tar = np.asarray(torch.as_tensor(test_input).cpu()), np.asarray(torch.as_tensor(tar).cpu())
+        plt.figure(figsize=(15, 6))
+        display_list = [test_input[0], tar[0], prediction[0]]
+        title = ['Input Image', 'Ground Truth', 'Predicted Image']
+        for i in range(3):
+            plt.subplot(1, 3, i + 1)
+            plt.title(title[i])
+            if self.config['channels'] == '1':
+                plt.imshow(display_list[i][..., 0] * 0.5 + 0.5, cmap=plt.get_cmap('gray'))
+            else:
+                plt.imshow(np.clip(display_list[i] * 0.5 + 0.5, 0, 1))
+            plt.axis('off')
+            plt.tight_layout()
+        plt.savefig(path_filename, dpi=200)
+        plt.close()
+
+    def fit(self, train_ds, val_ds, test_ds, output_path: str, checkpoint_manager=None):
+        print("\nTraining...\n", flush=True)
+        example_input, example_target = next(iter(test_ds))
+        start = time.time()
+        train_cost_functions, val_cost_functions = pix2pix_losses(), pix2pix_losses()
+        keys = list(train_cost_functions.keys())
+        for epoch in range(self.config['epochs']):
+            mini_batch_count = 1
+            tr, va = [], []
+            for input_image, target in train_ds:
+                tr.append(torch.stack(self.train_step(input_image, target, True)))   # stays on device: no per-step sync
+                if mini_batch_count % 100 == 0:
+                    print('.', end='', flush=True)
+                mini_batch_count += 1
+            for input_image, target in val_ds:
+                va.append(torch.stack(self.train_step(input_image, target, False)))
+            trm = torch.stack(tr).mean(0).cpu().tolist()          # one drain per epoch
+            vam = torch.stack(va).mean(0).cpu().tolist() if va else [float('nan')] * 4
+            for k, a, b in zip(keys, trm, vam):
+                train_cost_functions[k].append(a)
+                val_cost_functions[k].append(b)
+            test_img_path = output_path + '/test_images'
+            os.makedirs(test_img_path, exist_ok=True)
+            if ((epoch + 1) % 5 == 0) and ((epoch + 1) != self.config['epochs']):
+                if checkpoint_manager is not None:
+                    checkpoint_manager.save()
+                self.generate_images(self.generator, example_input[:1], example_target[:1],
+                                     path_filename=os.path.join(test_img_path, f"epoch_{epoch + 1}.png"))
+            if (epoch + 1) == self.config['epochs']:
+                if checkpoint_manager is not None:
+                    checkpoint_manager.save()
+            print(f'\nCumulative training duration at end of epoch {epoch + 1}: {(time.time() - start) / 60:.2f} min')
+            print(f"Train generator loss: {round(train_cost_functions['Generator Total Loss'][-1], 2)}, train discriminator loss: {round(train_cost_functions['Discriminator Loss'][-1], 2)}")
+            print(f"Val generator loss: {round(val_cost_functions['Generator Total Loss'][-1], 2)}, val discriminator loss: {round(val_cost_functions['Discriminator Loss'][-1], 2)}\n")
+        return train_cost_functions, val_cost_functions
+
+    def predict(self, predict_ds, output_path: str):
+        plot_path = os.path.join(output_path, 'prediction_images')
+        os.makedirs(plot_path, exist_ok=False)
+        for img_counter, i in enumerate(predict_ds.unbatch()):
+            self.generate_images(self.generator, np.expand_dims(i[0], axis=0), np.expand_dims(i[1], axis=0),
+                                 plot_path + "/" + f"img{img_counter}.png")
+
+
+def parse_opt(argv=None):
+    """Same flags / defaults / assertions as pix2pix.py:341-377 (+ optional --dtype / --device)."""
+    argv = sys.argv[1:] if argv is None else argv
+    parser = argparse.ArgumentParser()
+    parser.add_argument('--data', type=str, help='path to data', required=True)
+    parser.add_argument('--output', type=str, help='path to output results', required=True)
+    parser.add_argument('--img-size', type=int, default=256, help='image size h,w')
+    parser.add_argument('--batch-size', type=int, default=1, help='batch size per replica')
+    parser.add_argument('--buffer-size', type=int, default=99999, help='buffer size')
+    parser.add_argument('--channels', type=str, default='1', choices=['1', '3'], help='number of color channels to read in and output')
+    parser.add_argument('--logging', type=str, default='true', choices=['true', 'false'], help='turn on/off script logging, e.g. for CLI debugging')
+    parser.add_argument('--generator-loss', type=str, default='l1', choices=['l1', 'ssim'], help='combined generator loss function')
+    parser.add_argument('--input-img-orient', type=str, default='left', choices=['left', 'right'], help='whether input image is on left (i.e. target right) or vice-versa')
+    parser.add_argument('--seed', type=int, default=123, help='seed value for random number generator')
+    group = parser.add_mutually_exclusive_group(required=True)
+    group.add_argument('--train', action='store_true', help='train model using data')
+    group.add_argument('--predict', action='store_true', help='use pretrained weights to make predictions on data')
+    parser.add_argument('--save-weights', type=str, default='true', choices=['true', 'false'], help='save model checkpoints and weights')
+    parser.add_argument('--epochs', type=int, default=5, help='number of epochs to train', required='--train' in argv)
+    parser.add_argument('--lambda', type=int, default=100, help='lambda value for secondary generator loss (L1)')
+    parser.add_argument('--validation-size', type=float, default=0.1, help='validation set size as share of number of training images')
+    parser.add_argument('--test-img', type=int, default=5, help='number of test images to sample')
+    parser.add_argument('--learning-rate', type=float, default=2e-4, help='learning rate for Adam optimizer for generator and discriminator')
+    parser.add_argument('--beta-1', type=float, default=0.5, help='exponential decay rate for 1st moment of Adam optimizer for generator and discriminator')
+    parser.add_argument('--beta-2', type=float, default=0.999, help='exponential decay rate for 2st moment of Adam optimizer for generator and discriminator')
+    parser.add_argument('--weights', type=str, help='path to pretrained model weights for prediction', required='--predict' in argv)
+    parser.add_argument('--dtype', type=str, default='bf16', choices=['bf16', 'f32'], help='MI355X compute/storage dtype (f32 = exact parity path)')
+    parser.add_argument('--device', type=str, default='cuda:0')
+    args = parser.parse_args(argv)
+    assert (args.img_size == 256) or (args.img_size == 512), "img-size currently only supported for 256 x 256 or 512 x 512 pixels!"
+    assert (args.validation_size > 0.0 and args.validation_size <= 0.3), "validation size is a proportion and bounded between 0-0.3!"
+    assert (args.test_img >= 1), "test-img is an integer and must be >=1!"
+    return args
+
+
+def main(opt):
+    os.makedirs(opt.output, exist_ok=True)
+    full_path = opt.output + '/' + datetime.now().strftime("%Y-%m-%d-%Hh%M")
+    os.makedirs(full_path, exist_ok=True)
+    log_dir = os.path.join(full_path, 'logs')
+    os.makedirs(log_dir, exist_ok=False)
+    if opt.logging == 'true':
+        sys.stdout = open(os.path.join(log_dir, "Log.txt"), "w")
+        sys.stderr = sys.stdout
+    p2p = Pix2Pix(vars(opt))
+    checkpoint = Checkpoint(generator_optimizer=p2p.generator_optimizer, discriminator_optimizer=p2p.discriminator_optimizer,
+                            generator=p2p.generator, discriminator=p2p.discriminator)
+    with open(os.path.join(log_dir, 'config.json'), 'w') as f:
+        json.dump(p2p.config, f)
+    if opt.predict:
+        prediction_dataset, _, _ = p2p.image_pipeline(predict=True)
+        checkpoint.restore(latest_checkpoint(opt.weights))
+        p2p.predict(prediction_dataset, full_path)
+    if opt.train:
+        train, validation, test = p2p.image_pipeline(predict=False)
+        if opt.save_weights == 'true':
+            manager = CheckpointManager(checkpoint, os.path.join(full_path, 'training_checkpoints'), max_to_keep=1)
+        else:
+            manager = None
+        train_metrics, val_metrics = p2p.fit(train_ds=train, val_ds=validation, test_ds=test, output_path=full_path,
+                                             checkpoint_manager=manager)
+        final_test_imgs = full_path + '/final_test_imgs'
+        os.makedirs(final_test_imgs, exist_ok=False)
+        for img_counter, i in enumerate(test.unbatch()):
+            p2p.generate_images(p2p.generator, np.expand_dims(i[0], axis=0), np.expand_dims(i[1], axis=0),
+                                final_test_imgs + "/" + f"img{img_counter}.png")
+        with open(os.path.join(log_dir, 'train_metrics.json'), 'w') as f:
+            json.dump(train_metrics, f)
+        with open(os.path.join(log_dir, 'val_metrics.json'), 'w') as f:
+            json.dump(val_metrics, f)
+        import pandas as pd
+        for key in train_metrics.keys():
+            tr = pd.DataFrame(train_metrics[key]).reset_index()
+            va = pd.DataFrame(val_metrics[key]).reset_index()
+            tr['index'] = tr['index'] + 1
+            tr = tr.set_index('index')
+            va['index'] = va['index'] + 1
+            va = va.set_index('index')
+            make_fig(tr, va, title='Pix2Pix ' + key, output_path=os.path.join(full_path, 'figs'))
+    print("Done.")
+
+
+if __name__ == '__main__':
+    main(parse_opt())

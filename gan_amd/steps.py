@@ -89,11 +89,14 @@ class _StepBase:
 
 class Pix2PixStep(_StepBase):
     def __init__(self, ctx: Ctx, batch, size, channels=1, lam=100.0, lr=2e-4, beta_1=0.5, beta_2=0.999,
-                 seed=123, dropout=True):
+                 seed=123, dropout=True, nets=None):
         self.ctx, self.B, self.S, self.C = ctx, batch, size, channels
         self.lam, self.lr, self.b1, self.b2 = float(lam), lr, beta_1, beta_2
-        self.G = GeneratorNet(ctx, channels, 'batchnorm', seed=seed)          # pix2pix.py:29
-        self.D = DiscriminatorNet(ctx, channels, True, 'batchnorm', seed=seed + 1)   # pix2pix.py:30
+        if nets is not None:          # share weights with an existing step / model objects
+            self.G, self.D = nets
+        else:
+            self.G = GeneratorNet(ctx, channels, 'batchnorm', seed=seed)          # pix2pix.py:29
+            self.D = DiscriminatorNet(ctx, channels, True, 'batchnorm', seed=seed + 1)   # pix2pix.py:30
         self.g = self.G.new_call(batch, size, dropout=dropout, seed=seed)
         self.d = self.D.new_call(batch, size, calls=2)
         self.losses = torch.zeros(8, dtype=torch.float32, device=ctx.device)
@@ -140,14 +143,17 @@ class Pix2PixStep(_StepBase):
 
 class CycleGANStep(_StepBase):
     def __init__(self, ctx: Ctx, batch, size, channels=1, lam=10.0, lr=2e-4, beta_1=0.5, beta_2=0.999,
-                 seed=123, dropout=True):
+                 seed=123, dropout=True, nets=None):
         self.ctx, self.B, self.S, self.C = ctx, batch, size, channels
         self.lam, self.lr, self.b1, self.b2 = float(lam), lr, beta_1, beta_2
         n = 'instancenorm'                                                    # cycle_gan.py:30-33
-        self.Gg = GeneratorNet(ctx, channels, n, seed=seed)
-        self.Gf = GeneratorNet(ctx, channels, n, seed=seed + 1)
-        self.Dx = DiscriminatorNet(ctx, channels, False, n, seed=seed + 2)
-        self.Dy = DiscriminatorNet(ctx, channels, False, n, seed=seed + 3)
+        if nets is not None:
+            self.Gg, self.Gf, self.Dx, self.Dy = nets
+        else:
+            self.Gg = GeneratorNet(ctx, channels, n, seed=seed)
+            self.Gf = GeneratorNet(ctx, channels, n, seed=seed + 1)
+            self.Dx = DiscriminatorNet(ctx, channels, False, n, seed=seed + 2)
+            self.Dy = DiscriminatorNet(ctx, channels, False, n, seed=seed + 3)
         mk = lambda net, sid: net.new_call(batch, size, dropout=dropout, seed=seed, stream_id=sid)
         self.fy, self.cx = mk(self.Gg, 0), mk(self.Gf, 1)      # fake_y = G_g(x); cycled_x = G_f(fake_y)
         self.fx, self.cy = mk(self.Gf, 2), mk(self.Gg, 3)      # fake_x = G_f(y); cycled_y = G_g(fake_x)

@@ -1,0 +1,159 @@
+"""CPU tests of the host layer: C-ABI library loads and exports every declared symbol (no compute calls),
+header <-> binding consistency, CLI surface, input pipeline, checkpoint layout, data-parallel gradient
+exchange with gloo (world_size 2)."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_loads_and_exports_every_header_symbol():
+    from gan_amd import _lib
+    lib = _lib.load()
+    hdr = open(os.path.join(ROOT, 'include', 'gan_amd.h')).read()
+    declared = set(re.findall(r'\b(gan_[a-zA-Z0-9_]+)\s*\(', hdr))
+    assert declared, "no declarations parsed"
+    assert declared == set(_lib.SYMBOLS), (declared ^ set(_lib.SYMBOLS))
+    for name in declared:
+        assert hasattr(lib, name)
+    assert b'gfx950' in lib.gan_version()
+
+
+def test_product_path_has_no_cpu_fallback_and_never_imports_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, 'gan_amd')):
+        for f in files:
+            if f.endswith('.py'):
+                src = open(os.path.join(dirpath, f)).read()
+                assert 'oracle' not in src.replace('no-oracle', ''), f
+    from gan_amd import _lib
+    from gan_amd.nets import Ctx
+    if not torch.cuda.is_available():
+        with pytest.raises(_lib.GanAmdError):
+            Ctx('cuda:0', 'bf16')
+
+
+def test_cli_surface_matches_reference():
+    from gan_amd import cycle_gan, pix2pix
+    o = pix2pix.parse_opt(['--data', 'd', '--output', 'o', '--train', '--epochs', '3'])
+    assert (o.img_size, o.batch_size, o.channels, o.generator_loss, o.input_img_orient, o.seed) == (256, 1, '1', 'l1', 'left', 123)
+    assert (getattr(o, 'lambda'), o.validation_size, o.test_img, o.learning_rate, o.beta_1, o.beta_2) == (100, 0.1, 5, 2e-4, 0.5, 0.999)
+    with pytest.raises(SystemExit):       # --train and --predict are mutually exclusive, one is required
+        pix2pix.parse_opt(['--data', 'd', '--output', 'o'])
+    with pytest.raises(SystemExit):       # --epochs required with --train
+        pix2pix.parse_opt(['--data', 'd', '--output', 'o', '--train'])
+    with pytest.raises(SystemExit):       # --weights required with --predict
+        pix2pix.parse_opt(['--data', 'd', '--output', 'o', '--predict'])
+    with pytest.raises(AssertionError):
+        pix2pix.parse_opt(['--data', 'd', '--output', 'o', '--train', '--epochs', '1', '--img-size', '128'])
+    with pytest.raises(AssertionError):
+        pix2pix.parse_opt(['--data', 'd', '--output', 'o', '--train', '--epochs', '1', '--validation-size', '0.5'])
+    c = cycle_gan.parse_opt(['--input-images', 'x', '--target-images', 'y', '--output', 'o', '--train', '--epochs', '2'])
+    assert getattr(c, 'lambda') == 10 and c.batch_size == 1
+    with pytest.raises(SystemExit):       # --target-images required with --train
+        cycle_gan.parse_opt(['--input-images', 'x', '--output', 'o', '--train', '--epochs', '2'])
+    from gan_amd.utils import cyclegan_losses, pix2pix_losses
+    assert list(pix2pix_losses()) == ['Generator Total Loss', 'Generator Loss (Primary)', 'Generator Loss (Secondary)', 'Discriminator Loss']
+    assert len(cyclegan_losses()) == 7
+
+
+def test_input_pipeline(tmp_path):
+    from PIL import Image
+    from gan_amd import data as D
+    rng = np.random.default_rng(0)
+    for i in range(12):
+        Image.fromarray(rng.integers(0, 256, (40, 100), dtype=np.uint8), 'L').save(tmp_path / f"im{i}.png")
+    img = D.load(str(tmp_path / "im0.png"), 1)
+    assert img.shape == (40, 100, 1) and img.dtype == np.float32
+    a, b = D.split_img(img, 'left')
+    assert a.shape == (40, 50, 1) and np.array_equal(a, img[:, :50]) and np.array_equal(b, img[:, 50:])
+    a2, b2 = D.split_img(img, 'right')
+    assert np.array_equal(a2, b) and np.array_equal(b2, a)
+    # nearest neighbour with half-pixel centres: src = floor((dst+.5)*in/out)
+    r = D.resize_nearest(np.arange(4, dtype=np.float32).reshape(1, 4, 1), 1, 8)
+    assert r[0, :, 0].tolist() == [0, 0, 1, 1, 2, 2, 3, 3]
+    r = D.resize_nearest(np.arange(5, dtype=np.float32).reshape(1, 5, 1), 1, 2)
+    assert r[0, :, 0].tolist() == [1, 3]
+    assert np.allclose(D.normalize(np.array([0, 127.5, 255], np.float32)), [-1, 0, 1])
+    ja, jb = D.random_jitter_pair(a, b, 32, np.random.default_rng(1))
+    assert ja.shape == jb.shape == (32, 32, 1)
+    files = D.list_images(str(tmp_path))
+    tr, va, te = D.pix2pix_split(files, 123, 5, 0.1)
+    assert len(te) == 5 and len(va) == 1 and len(tr) == 6 and not (set(tr) & set(va)) and not (set(te) & set(tr + va))
+    assert (tr, va, te) == D.pix2pix_split(files, 123, 5, 0.1)       # seeded: deterministic
+    mk = lambda f: tuple(D.normalize(D.resize_nearest(x, 16, 16)) for x in D.split_img(D.load(f, 1)))
+    ds = D.Batches([str(tmp_path / f) for f in files], mk, 5)
+    batches = list(ds)
+    assert [bt[0].shape[0] for bt in batches] == [5, 5, 2] and batches[0][0].shape == (5, 16, 16, 1)   # last partial batch kept
+
+
+def test_checkpoint_layout_roundtrip(tmp_path):
+    from gan_amd.checkpoint import Checkpoint, CheckpointManager, latest_checkpoint, tf_variable_key, GEN_LAYERS
+
+    class Obj:
+        def __init__(self, seed):
+            r = np.random.default_rng(seed)
+            self.sd = {'layer_with_weights-0/layer_with_weights-0/kernel/.ATTRIBUTES/VARIABLE_VALUE': r.standard_normal((4, 4, 1, 64)).astype(np.float32),
+                       'iter/.ATTRIBUTES/VARIABLE_VALUE': np.array([7], np.int64)}
+
+        def state_dict(self):
+            return self.sd
+
+        def load_state_dict(self, sd):
+            self.loaded = sd
+
+    assert tf_variable_key('generator', GEN_LAYERS, 'up2.gamma') == 'generator/layer_with_weights-10/layer_with_weights-1/gamma/.ATTRIBUTES/VARIABLE_VALUE'
+    g, d = Obj(1), Obj(2)
+    mgr = CheckpointManager(Checkpoint(generator=g, discriminator=d), str(tmp_path / 'training_checkpoints'), max_to_keep=1)
+    p1 = mgr.save()
+    p2 = mgr.save()
+    assert os.path.basename(p2) == 'ckpt-2' and not os.path.exists(p1 + '.index')          # keep-last-1
+    assert sorted(os.listdir(tmp_path / 'training_checkpoints')) == ['checkpoint', 'ckpt-2.data-00000-of-00001', 'ckpt-2.index']
+    assert latest_checkpoint(str(tmp_path / 'training_checkpoints')) == p2
+    g2, d2 = Obj(3), Obj(4)
+    ck = Checkpoint(generator=g2, discriminator=d2, extra=Obj(5)).restore(p2)               # expect_partial semantics
+    k = 'layer_with_weights-0/layer_with_weights-0/kernel/.ATTRIBUTES/VARIABLE_VALUE'
+    assert np.array_equal(g2.loaded[k], g.sd[k]) and np.array_equal(d2.loaded[k], d.sd[k]) and ck.save_counter == 2
+
+
+def _ddp_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from gan_amd.ddp import GradSync, shard_batch
+    g = torch.Generator().manual_seed(5)
+    full = [torch.randn(1000, generator=g), torch.randn(77, generator=g)]          # "gradients" of the whole batch's shards
+    per_rank = [[t * (r + 1) for t in full] for r in range(world)]                 # rank r's local gradients
+    mine = [t.clone() for t in per_rank[rank]]
+    for compress in (False, True):
+        bufs = [t.clone() for t in mine]
+        sync = GradSync(bufs, compress_bf16=compress, max_chunk_elems=300)
+        sync()
+        expect = [sum(per_rank[r][i] for r in range(world)) * sync.grad_scale for i in range(2)]
+        got = [b * sync.grad_scale for b in bufs]
+        tol = 2e-2 if compress else 1e-6
+        ok = all(torch.allclose(a, b, rtol=tol, atol=tol) for a, b in zip(got, expect))
+        q.put((rank, compress, ok, shard_batch(64, rank, world)))
+    dist.destroy_process_group()
+
+
+def test_gradsync_world2_gloo():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 1000
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(4)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, _, ok, _ in res), res
+    shards = {r: s for r, _, _, s in res}
+    assert shards[0] == (0, 32) and shards[1] == (32, 32)
