@@ -156,3 +156,36 @@ def test_cyclegan_train_step_parity(dtype):
     # the numpy oracle itself run in fp32 differs from its fp64 run by up to 5.5e-2 on these tensors
     # (instance-norm + ReLU kinks at batch 1), so that is the noise floor for a per-tensor max-abs bound
     check_grads(dtype, pairs, 1e-1)
+
+
+@pytest.mark.parametrize("dtype", ['f32', 'bf16'])
+def test_generator_output_on_reference_example_pairs(dtype):
+    """BASELINE.json gate: generator output on the reference's own 256x256 thermal/visible example pairs within
+    1e-3 max-abs of the CPU restatement (fp32 exact-MFMA path); bf16 reports its error."""
+    import os
+    from gan_amd.nets import Ctx
+    from gan_amd.steps import Pix2PixStep
+    g = os.path.join(os.path.dirname(__file__), 'golden')
+    pairs = np.load(os.path.join(g, 'example_pairs_256.npz'))
+    gold = np.load(os.path.join(g, 'golden_pix2pix_step.npz'))
+    inp, tar = O.normalize(pairs['input_u8']), O.normalize(pairs['target_u8'])
+    ctx = Ctx('cuda:0', dtype)
+    st = Pix2PixStep(ctx, 2, 256, 1, lam=100.0, seed=123)
+    st.G.params.load_numpy(O.init_generator(1, seed=11))
+    st.D.params.load_numpy(O.init_discriminator(1, True, seed=12))
+    st.g.set_dropmasks(O.dropout_masks(2, 256, seed=5))
+    losses = st.train_step(torch.from_numpy(inp).to(ctx.device), torch.from_numpy(tar).to(ctx.device), True).cpu().numpy()
+    gen = st.g.output_f32().cpu().numpy()
+    err = float(np.abs(gen - gold['gen']).max())
+    print(f"[{dtype}] example pairs: generator max-abs err vs golden {err:.3e}; losses {losses} golden {gold['losses']}")
+    if dtype == 'f32':
+        assert err < 1e-3 and np.allclose(losses, gold['losses'], rtol=2e-4)
+        got = st.G.params.to_numpy()['down3.kernel'][0, 0, :8, :8]
+        assert np.abs(got - gold['new_G_down3_kernel_slice']).max() < 4.1e-4
+        names = list(gold['grad_names'])
+        gG, gD = st.G.params.to_numpy('grad'), st.D.params.to_numpy('grad')
+        for nm, (s, sa) in zip(names, gold['grad_sums']):
+            v = (gG if nm.startswith('G.') else gD)[nm[2:]]
+            assert abs(np.abs(v).sum() - sa) <= 2e-2 * sa + 1e-12, nm       # checksum of |grad| per tensor
+    else:
+        assert err < 0.15 and np.allclose(losses, gold['losses'], rtol=5e-2)

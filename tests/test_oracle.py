@@ -206,3 +206,20 @@ def test_cyclegan_step_vs_torch_autograd():
     for mine, ref in zip(out[8:], (g1, g2, g3, g4)):
         for k in ref:
             assert rel(mine[k], ref[k]) < 1e-7, k
+
+
+def test_oracle_reproduces_committed_golden():
+    """tests/golden/*.npz (made by tests/golden/make_golden.py from the reference's example_images): the fp32
+    oracle must reproduce the committed fp64 expected values — pins the oracle against drift."""
+    import os
+    g = os.path.join(os.path.dirname(__file__), 'golden')
+    pairs = np.load(os.path.join(g, 'example_pairs_256.npz'))
+    gold = np.load(os.path.join(g, 'golden_pix2pix_step.npz'))
+    assert pairs['input_u8'].shape == (2, 256, 256, 1) and pairs['input_u8'].dtype == np.uint8
+    inp, tar = O.normalize(pairs['input_u8']), O.normalize(pairs['target_u8'])
+    G, D = O.init_generator(1, seed=11), O.init_discriminator(1, True, seed=12)
+    masks = O.dropout_masks(2, 256, seed=5)
+    out = O.pix2pix_train_step(G, D, O.AdamTF(), O.AdamTF(), inp, tar, 100.0, masks, True, return_grads=True)
+    assert np.allclose(np.array(out[:4], np.float64), gold['losses'], rtol=1e-5)
+    assert np.abs(out[4] - gold['gen']).max() < 1e-4
+    assert np.abs(G['down3.kernel'][0, 0, :8, :8] - gold['new_G_down3_kernel_slice']).max() < 4.1e-4
