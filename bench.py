@@ -35,7 +35,7 @@ def gemm_profile(step, inputs, reps=5):
     recs = {}
     orig_run = ctx.run
 
-    def timed_run(ops):
+    def timed_run(ops, lane=0):
         st = ctx.stream()
         for op in ops:
             meta = op[3] if len(op) > 3 else None
@@ -52,12 +52,14 @@ def gemm_profile(step, inputs, reps=5):
     step._run(*inputs, training=True)          # untimed eager pass (first eager launches pay one-time costs)
     torch.cuda.synchronize()
     ctx.run = timed_run
+    ctx.multistream = False                    # the instrumented passes run every launch on one stream
     try:
         for _ in range(reps):
             step._run(*inputs, training=True)
         torch.cuda.synchronize()
     finally:
         ctx.run = orig_run
+        ctx.multistream = True
     out = {}
     for k, lst in recs.items():
         n = len(lst) // reps                   # launches of this kernel per step

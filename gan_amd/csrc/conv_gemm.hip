@@ -33,6 +33,7 @@ struct GemmParams {
   int tilesM, tilesN;
   int act; float slope; int out_f32; int vec_store;
   unsigned xbytes, wbytes;   // extents for the buffer descriptors (out-of-range offsets read zeros)
+  int debug;                 // timing experiments only (GAN_AMD_GEMM_DEBUG): 1 = skip MFMA phase, 2 = skip loads
 };
 
 __device__ uint4 g_zero_page[8];   // 128 B of zeros: source of padding taps / out-of-range rows
@@ -147,12 +148,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_gemm_kernel(const
   const int wtapbytes = p.Wrows * p.Cin * (int)sizeof(T);
   __syncthreads();
 
-  auto issue = [&](int kc, int stage) {
-    unsigned char* As = smem + stage * STAGE;
-    unsigned char* Bs = As + BM * BKB;
-    // K order: channel-chunk major, tap minor (when a 128-B chunk lies inside one tap): the 16 (or 4) taps
-    // of one channel chunk re-read the same input lines shifted by a pixel, so consecutive K steps hit in L2
-    // instead of coming back after the whole channel range has been streamed.
+  // prep(kc): per-piece byte offsets of K step kc (gather-table lookup + add); fire(idx, stage): issue piece idx
+  // (A pieces first, then B) of the prepared step into `stage`.  Split so the 1-KiB LDS-DMA issues can be
+  // spread between the MFMAs of the step being multiplied instead of stalling the wave in one burst.
+  constexpr int PT = AI + BI;                           // pieces per wave per tile
+  int va[AI], vb[BI];
+  auto prep = [&](int kc) {
+    // K order: channel-chunk major, tap minor (when a chunk lies inside one tap): the 16 (or 4) taps of one
+    // channel chunk re-read the same input lines shifted by a pixel, so consecutive K steps hit in L2.
     int tap, coffB;
     if ((1 << p.log2_cvecs) >= SLOTS) {
       tap = kc & (p.T - 1);
@@ -164,21 +167,29 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_gemm_kernel(const
     }
     const int* trow = tbl + tap * BM + lrow;
 #pragma unroll
-    for (int i = 0; i < AI; ++i) {
-      const int ia = wave + NW * i;
-      if (ia < AINS)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(As + ia * 1024), 16,
-                                                 trow[ia * RPI] + coffB, 0, 0, 0);
-    }
+    for (int i = 0; i < AI; ++i) va[i] = (wave + NW * i < AINS) ? trow[(wave + NW * i) * RPI] + coffB : (int)0x80000000;
     const int ty = tap >> p.TWlog2, tx = tap & twmask;
     const int wofs = ((wy0 + ty * p.wstep) * 4 + (wx0 + tx * p.wstep)) * wtapbytes + coffB;
 #pragma unroll
-    for (int i = 0; i < BI; ++i) {
-      const int ib = wave + NW * i;
+    for (int i = 0; i < BI; ++i) vb[i] = nbo[i] + wofs;
+  };
+  auto fire = [&](int idx, int stage) {
+    unsigned char* As = smem + stage * STAGE;
+    if (idx < AI) {
+      const int ia = wave + NW * idx;
+      if (ia < AINS)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(As + ia * 1024), 16, va[idx], 0, 0, 0);
+    } else {
+      const int ib = wave + NW * (idx - AI);
       if (ib < BINS)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(Bs + ib * 1024), 16,
-                                                 nbo[i] + wofs, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(As + BM * BKB + ib * 1024), 16,
+                                                 vb[idx - AI], 0, 0, 0);
     }
+  };
+  auto issue = [&](int kc, int stage) {
+    prep(kc);
+#pragma unroll
+    for (int idx = 0; idx < PT; ++idx) fire(idx, stage);
   };
 
   f32x4 acc[MT][NT];
@@ -195,7 +206,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_gemm_kernel(const
   const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
   const unsigned sw0 = ((q ^ fsw(r)) << 4), sw1 = (((4 + q) ^ fsw(r)) << 4);
   const unsigned a_off = (wm * WTM + r) * BKB, b_off = BM * BKB + (wn * WTN + r) * BKB;
-  auto compute = [&](int stage) {
+  auto compute = [&](int stage, bool refill, int stage_i) {
     const unsigned sbase = lds_base + stage * STAGE;
     uint4 af[KSTEPS][MT], bfr[KSTEPS][NT];
 #pragma unroll
@@ -212,9 +223,18 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_gemm_kernel(const
       else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int i = 0; i < MT; ++i)
+      for (int i = 0; i < MT; ++i) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) Mma<T>::run(acc[i][j], af[s][i], bfr[s][j]);
+        // spread this wave's PT piece issues over the KSTEPS*MT row groups of MFMAs
+        constexpr int G = KSTEPS * MT;
+        const int g = s * MT + i;
+        if (refill) {
+#pragma unroll
+          for (int idx = 0; idx < PT; ++idx)
+            if (idx >= g * PT / G && idx < (g + 1) * PT / G) fire(idx, stage_i);
+        }
+      }
     }
   };
 
@@ -224,7 +244,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_gemm_kernel(const
   // NS-1 tiles stay in flight.  At step i: wait until all but the newest (NS-2) tiles of THIS wave have landed
   // (counted vmcnt: LDS-DMA pieces retire in issue order), barrier (everyone's pieces of tile i are in LDS and
   // everyone has finished reading tile i-1), refill the stage tile i-1 occupied, multiply tile i.
-  constexpr int PT = AI + BI;                           // pieces per wave per tile
 #pragma unroll
   for (int s = 0; s < NS - 1; ++s)
     if (s < nk) issue(kc_begin + s, s);
@@ -236,8 +255,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_gemm_kernel(const
     else if (NS >= 3 && pending == 1) wait_vmcnt<PT>();
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
-    if (i + NS - 1 < nk) issue(kc_begin + i + NS - 1, st_i);
-    compute(st_c);
+    // (spreading the piece issues between the MFMAs instead of this burst measured 5 % slower)
+    if (i + NS - 1 < nk && !(p.debug & 2)) issue(kc_begin + i + NS - 1, st_i);
+    if (!(p.debug & 1)) compute(st_c, false, st_i);
     st_c = st_c + 1 == NS ? 0 : st_c + 1;
     st_i = st_i + 1 == NS ? 0 : st_i + 1;
   }
@@ -324,8 +344,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p, 
 // ------------------------------------------------------------------------------------------------
 // pipeline shape per tile: big (one block per CU) tiles use 64-byte K rows and 4-5 stages so ~100 KB of
 // LDS-DMA stays in flight per CU; small tiles (several blocks per CU) use 128-byte rows, 2 stages.
-static constexpr int cfg_bkb(int BM, int BN) { return BM == 256 ? 64 : 128; }
-static constexpr int cfg_ns(int BM, int BN) { return BM == 256 ? (BN == 256 ? 4 : 5) : 2; }
+static constexpr int cfg_bkb(int BM, int BN) { return (BM == 256 && BN == 128) ? 64 : 128; }
+static constexpr int cfg_ns(int BM, int BN) {
+  return BM == 256 ? (BN == 256 ? 2 : 5) : ((BM == 128 && BN >= 64) || (BM == 64 && BN == 128)) ? 3 : 2;
+}
 
 struct GemmPlan {
   GemmParams p;
@@ -354,6 +376,7 @@ static int plan_gemm(const GanConvDesc* d, int op, GemmPlan* pl) {
   }
   p.Nimg = x.n; p.Hs = x.h; p.Ws = x.w; p.xpitch = x.pitch; p.Cin = x.c; p.log2_cvecs = l2;
   p.Wrows = d->w_rows; p.Ho = y.h; p.Wo = y.w; p.ypitch = y.pitch; p.Cout = y.c;
+  { static int dbg = -1; if (dbg < 0) { const char* e = getenv("GAN_AMD_GEMM_DEBUG"); dbg = e ? atoi(e) : 0; } p.debug = dbg; }
   p.act = d->act; p.slope = d->slope; p.out_f32 = d->y_f32 || d->dtype == GAN_F32;
   p.vec_store = (!d->y_f32 || d->dtype == GAN_F32) && y.c % vec == 0 && y.pitch % vec == 0 && ((uintptr_t)y.ptr % 16) == 0;
   p.parity = 0; p.OS = 1; p.wy0 = p.wx0 = 0; p.wstep = 1; p.TWlog2 = 2; p.T = 16; p.log2T = 4;

@@ -131,21 +131,22 @@ __global__ __launch_bounds__(256) void reduce_partial_kernel(const NormP p, cons
   }
 }
 
-// Sum one (group, channel) pair over chunks: 8 chunk lanes x 32 channels per block.
+// Sum one (group, channel) pair over chunks: 32 chunk lanes x 8 channels per block (FC channels per block).
+constexpr int FC = 8, FL = 32;
 __device__ __forceinline__ void chunk_sum(const float* partial, int g, int chunks, int C, int c, int kl, double* red,
                                           double& s1, double& s2) {
   double a = 0, b = 0;
   if (c < C)
-    for (int k = kl; k < chunks; k += 8) {
+    for (int k = kl; k < chunks; k += FL) {
       float2 v = *(const float2*)(partial + (((size_t)g * chunks + k) * C + c) * 2);
       a += v.x; b += v.y;
     }
-  const int cl = threadIdx.x & 31;
-  red[(kl * 32 + cl) * 2] = a; red[(kl * 32 + cl) * 2 + 1] = b;
+  const int cl = threadIdx.x % FC;
+  red[(kl * FC + cl) * 2] = a; red[(kl * FC + cl) * 2 + 1] = b;
   __syncthreads();
   s1 = s2 = 0;
   if (kl == 0)
-    for (int k = 0; k < 8; ++k) { s1 += red[(k * 32 + cl) * 2]; s2 += red[(k * 32 + cl) * 2 + 1]; }
+    for (int k = 0; k < FL; ++k) { s1 += red[(k * FC + cl) * 2]; s2 += red[(k * FC + cl) * 2 + 1]; }
   __syncthreads();
 }
 
@@ -154,8 +155,8 @@ __device__ __forceinline__ void chunk_sum(const float* partial, int g, int chunk
 __global__ __launch_bounds__(256) void stats_finalize_kernel(const float* partial, int G, int chunks, int C, long long rows,
                                                              float eps, float* mean, float* rstd, float* mmean, float* mvar,
                                                              float momentum) {
-  __shared__ double red[8 * 32 * 2];
-  const int c = blockIdx.x * 32 + (threadIdx.x & 31), kl = threadIdx.x >> 5;
+  __shared__ double red[FL * FC * 2];
+  const int c = blockIdx.x * FC + threadIdx.x % FC, kl = threadIdx.x / FC;
   const int g0 = mmean ? 0 : blockIdx.y, g1 = mmean ? G : blockIdx.y + 1;
   for (int g = g0; g < g1; ++g) {
     double s, s2;
@@ -177,8 +178,8 @@ __global__ __launch_bounds__(256) void stats_finalize_kernel(const float* partia
 
 __global__ __launch_bounds__(256) void bwd_finalize_kernel(const float* partial, int G, int chunks, int C, float* sums,
                                                            float* dgamma, float* dbeta, int accumulate) {
-  __shared__ double red[8 * 32 * 2];
-  const int c = blockIdx.x * 32 + (threadIdx.x & 31), kl = threadIdx.x >> 5;
+  __shared__ double red[FL * FC * 2];
+  const int c = blockIdx.x * FC + threadIdx.x % FC, kl = threadIdx.x / FC;
   double tg = 0, tb = 0;
   for (int g = 0; g < G; ++g) {
     double s1, s2;
@@ -294,7 +295,7 @@ __global__ __launch_bounds__(256) void norm_act_bwd_kernel(const NormP p, const 
 // ------------------------------------------------------------------------------------------------
 static int pick_chunks(long long rows_per_group, int rslots, int groups) {
   long long ch = (rows_per_group + (long long)rslots * 16 - 1) / ((long long)rslots * 16);
-  long long cap = 2048 / groups; if (cap < 1) cap = 1;
+  long long cap = 512 / groups; if (cap < 1) cap = 1;   // finalize walks the chunks: keep it short
   if (ch > cap) ch = cap;
   if (ch < 1) ch = 1;
   return (int)ch;
@@ -349,7 +350,7 @@ int gan_norm_stats(const GanNormDesc* d, gan_stream_t stream) {
   rc = d->dtype == GAN_F32 ? launch_partial<float, 0>(p, g, d->groups, partial, st)
                            : launch_partial<bf16_t, 0>(p, g, d->groups, partial, st);
   if (rc) return rc;
-  hipLaunchKernelGGL(stats_finalize_kernel, dim3((g.C + 31) / 32, d->moving_mean ? 1 : d->groups), dim3(256), 0, st,
+  hipLaunchKernelGGL(stats_finalize_kernel, dim3((g.C + FC - 1) / FC, d->moving_mean ? 1 : d->groups), dim3(256), 0, st,
                      (const float*)partial, d->groups, g.chunks, g.C, g.rows_per_group, d->eps, d->mean, d->rstd,
                      d->moving_mean, d->moving_var, d->momentum);
   GAN_CHECK_LAUNCH();
@@ -392,7 +393,7 @@ int gan_norm_act_bwd(const GanNormBwdDesc* d, gan_stream_t stream) {
   rc = d->dtype == GAN_F32 ? launch_partial<float, 1>(p, g, d->groups, partial, st)
                            : launch_partial<bf16_t, 1>(p, g, d->groups, partial, st);
   if (rc) return rc;
-  hipLaunchKernelGGL(bwd_finalize_kernel, dim3((g.C + 31) / 32), dim3(256), 0, st, (const float*)partial, d->groups,
+  hipLaunchKernelGGL(bwd_finalize_kernel, dim3((g.C + FC - 1) / FC), dim3(256), 0, st, (const float*)partial, d->groups,
                      g.chunks, g.C, sums, d->dgamma, d->dbeta, d->accumulate);
   GAN_CHECK_LAUNCH();
   long long rows = (long long)d->y.n * g.hw;
@@ -411,7 +412,7 @@ static int bias_grad_impl(int32_t dtype, const GanTensor& dy, float* dbias, int3
   float* partial = (float*)workspace;
   rc = dtype == GAN_F32 ? launch_partial<float, 2>(q, g, 1, partial, st) : launch_partial<bf16_t, 2>(q, g, 1, partial, st);
   if (rc) return rc;
-  hipLaunchKernelGGL(bwd_finalize_kernel, dim3((g.C + 31) / 32), dim3(256), 0, st, (const float*)partial, 1, g.chunks, g.C,
+  hipLaunchKernelGGL(bwd_finalize_kernel, dim3((g.C + FC - 1) / FC), dim3(256), 0, st, (const float*)partial, 1, g.chunks, g.C,
                      (float*)nullptr, (float*)nullptr, dbias, accumulate);
   GAN_CHECK_LAUNCH();
   return 0;

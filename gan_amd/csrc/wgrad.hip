@@ -207,8 +207,16 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
     }
 }
 
+// few slabs: one thread per element, coalesced; many slabs (fold mode): 32 elements x 8 slab-lanes per block so
+// the sum is not one long dependent chain
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* slab, float* dw, long long count, int splits, int accumulate) {
-  // 32 elements x 8 split-lanes per block: the sum over (up to 1024) slabs is not one dependent chain
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= count) return;
+  float s = 0.f;
+  for (int k = 0; k < splits; ++k) s += slab[(size_t)k * count + i];
+  dw[i] = accumulate ? dw[i] + s : s;
+}
+__global__ __launch_bounds__(256) void wgrad_reduce_wide_kernel(const float* slab, float* dw, long long count, int splits, int accumulate) {
   __shared__ float red[8][33];
   const int el = threadIdx.x & 31, sl = threadIdx.x >> 5;
   const long long i = (long long)blockIdx.x * 32 + el;
@@ -322,8 +330,12 @@ int gan_conv_wgrad(const GanWgradDesc* d, gan_stream_t stream) {
   if (rc) return rc;
   if (pl.p.splits > 1) {
     long long count = (long long)16 * pl.p.CaReal * pl.p.CbReal;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((count + 31) / 32)), dim3(256), 0, st,
-                       (const float*)pl.p.slab, pl.p.dw, count, pl.p.splits, pl.p.accumulate);
+    if (pl.p.splits <= 16)
+      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st,
+                         (const float*)pl.p.slab, pl.p.dw, count, pl.p.splits, pl.p.accumulate);
+    else
+      hipLaunchKernelGGL(wgrad_reduce_wide_kernel, dim3((unsigned)((count + 31) / 32)), dim3(256), 0, st,
+                         (const float*)pl.p.slab, pl.p.dw, count, pl.p.splits, pl.p.accumulate);
     GAN_CHECK_LAUNCH();
   }
   return 0;

@@ -39,19 +39,51 @@ class Ctx:
         self.dtype = dtype
         self.dt = L.BF16 if dtype == 'bf16' else L.F32
         self.tdtype = torch.bfloat16 if dtype == 'bf16' else torch.float32
-        self.ws = torch.empty(workspace_mb << 20, dtype=torch.uint8, device=self.device)
+        # "Lanes": independent launch chains that may overlap on the GPU (separate HIP streams, also inside a
+        # captured graph).  Lane 0 = the current stream; lane 1 = its wgrad side stream (wgrad kernels only
+        # feed Adam, so they run beside the dgrad/norm chain); lane 2 / 3 = a second chain (discriminator
+        # parameter-gradient pass beside the generator backward) and its wgrad side stream.  Each lane has its
+        # own workspace (split-K slabs / reduction partials).
+        self.ws_lanes = [torch.empty(workspace_mb << 20, dtype=torch.uint8, device=self.device) for _ in range(4)]
+        self.ws = self.ws_lanes[0]
         self.ws_ptr, self.ws_bytes = self.ws.data_ptr(), self.ws.numel()
+        self.side = [torch.cuda.Stream(device=self.device) for _ in range(3)]
+        # 0: everything on one stream; 1: one fork/join per step (deferred generator wgrads beside the
+        # discriminator's parameter pass); 2: per-op wgrad side stream + second chain
+        import os
+        self.ms_mode = int(os.environ.get('GAN_AMD_MS', '3'))
+        self.multistream = self.ms_mode == 2
 
     def stream(self):
         return torch.cuda.current_stream(self.device).cuda_stream
 
-    def run(self, ops):
-        st = self.stream()
+    def lane_stream(self, lane):
+        return torch.cuda.current_stream(self.device) if lane == 0 else self.side[lane - 1]
+
+    def run_on(self, ops, stream):
+        """All ops in program order on one explicit stream."""
+        st = stream.cuda_stream
         for op in ops:
-            fn, args, what = op[0], op[1], op[2]
-            rc = fn(*args, st)
+            rc = op[0](*op[1], st)
             if rc:
-                L.check(rc, what)
+                L.check(rc, op[2])
+
+    def run(self, ops, lane=0):
+        main = self.lane_stream(lane)
+        side = self.side[lane] if self.multistream else main
+        st_main, st_side = main.cuda_stream, side.cuda_stream
+        used_side = False
+        for op in ops:
+            if len(op) > 4 and op[4] and self.multistream:
+                side.wait_stream(main)            # the op's inputs were produced on the main chain just before it
+                rc = op[0](*op[1], st_side)
+                used_side = True
+            else:
+                rc = op[0](*op[1], st_main)
+            if rc:
+                L.check(rc, op[2])
+        if used_side:
+            main.wait_stream(side)
 
 
 class Buf:
@@ -206,8 +238,10 @@ def init_params_numpy(spec, seed):
 class _Builder:
     """Helpers that turn layer descriptions into (fn, args, label) C calls."""
 
-    def __init__(self, ctx, params, norm):
+    def __init__(self, ctx, params, norm, lane=0):
         self.ctx, self.P, self.norm = ctx, params, norm
+        self.ws_ptr, self.ws_bytes = ctx.ws_lanes[lane].data_ptr(), ctx.ws_lanes[lane].numel()
+        self.ws_side_ptr = ctx.ws_lanes[lane + 1].data_ptr()
         self.lib = ctx.lib
         self.keep = []       # ctypes structs must outlive the op list
 
@@ -217,11 +251,11 @@ class _Builder:
 
     def conv(self, op, x, y, w, w_rows, stride=2, bias=None, act=None, y_f32=0, k_real=None):
         d = L.GanConvDesc(self.ctx.dt, stride, x, y, w, w_rows, bias, L.ACTS[act], LEAKY_ALPHA, y_f32,
-                          self.ctx.ws_ptr, self.ctx.ws_bytes)
+                          self.ws_ptr, self.ws_bytes)
         opi = {'conv_fwd': 0, 'conv_dgrad': 1, 'convT_fwd': 2, 'convT_dgrad': 3}[op]
         fn = [self.lib.gan_conv2d_fwd, self.lib.gan_conv2d_dgrad, self.lib.gan_convT2d_fwd, self.lib.gan_convT2d_dgrad][opi]
         need = self.lib.gan_conv_workspace_bytes(C.byref(d), opi)
-        if need > self.ctx.ws_bytes:
+        if need > self.ws_bytes:
             raise L.GanAmdError(f"workspace too small for {op}: need {need}")
         info = (C.c_int32 * 4)()
         self.lib.gan_conv_plan_info(C.byref(d), opi, info)
@@ -236,16 +270,16 @@ class _Builder:
 
     def wgrad(self, big, small, dw_ptr, big_c, small_c, stride, accumulate):
         d = L.GanWgradDesc(self.ctx.dt, stride, big, small, dw_ptr, big_c, small_c, int(accumulate),
-                           self.ctx.ws_ptr, self.ctx.ws_bytes)
+                           self.ws_side_ptr, self.ws_bytes)
         need = self.lib.gan_wgrad_workspace_bytes(C.byref(d))
-        if need > self.ctx.ws_bytes:
+        if need > self.ws_bytes:
             raise L.GanAmdError(f"workspace too small for wgrad: need {need}")
         info = (C.c_int32 * 4)()
         self.lib.gan_wgrad_plan_info(C.byref(d), info)
         flops = 2.0 * small.n * small.h * small.w * 16 * big_c * small_c
         meta = dict(kind='gemm', kernel=f"wgrad<{self.ctx.dtype},{info[0]},{info[1]}>", flops=flops, splits=info[2],
                     shape=f"wgrad A{big_c} B{small_c} M{small.n * small.h * small.w} s{info[2]}")
-        return (self.lib.gan_conv_wgrad, (self._desc(d),), "conv_wgrad", meta)
+        return (self.lib.gan_conv_wgrad, (self._desc(d),), "conv_wgrad", meta, True)      # True: side-stream op
 
     def norm_names(self):
         return ('.gamma', '.beta') if self.norm == 'batchnorm' else ('.scale', '.offset')
@@ -259,7 +293,7 @@ class _Builder:
             mv = self.P.state[name + '.moving_variance'].data_ptr()
         d = L.GanNormDesc(self.ctx.dt, y, a, groups, eps, self.P.ptr(name + gk), self.P.ptr(name + bk),
                           mean.data_ptr(), rstd.data_ptr(), mm, mv, BN_MOMENTUM, mask_ptr, L.ACTS[act], LEAKY_ALPHA,
-                          self.ctx.ws_ptr, self.ctx.ws_bytes)
+                          self.ws_ptr, self.ws_bytes)
         r = self._desc(d)
         return [(self.lib.gan_norm_stats, (r,), f"norm_stats({name})"),
                 (self.lib.gan_norm_act_fwd, (r,), f"norm_act_fwd({name})")]
@@ -272,19 +306,19 @@ class _Builder:
                              L.ACTS[act], LEAKY_ALPHA,
                              self.P.ptr(name + gk, 'grad') if want_param_grads else None,
                              self.P.ptr(name + bk, 'grad') if want_param_grads else None,
-                             int(accumulate), self.ctx.ws_ptr, self.ctx.ws_bytes)
+                             int(accumulate), self.ws_ptr, self.ws_bytes)
         return (self.lib.gan_norm_act_bwd, (self._desc(d),), f"norm_act_bwd({name})")
 
     def act_bwd(self, a, da, da2, dy, act):
         z = L.GanTensor(None, 0, 0, 0, 0, 0)
         d = L.GanActBwdDesc(self.ctx.dt, a, da, da2 if da2 is not None else z, dy, L.ACTS[act], LEAKY_ALPHA, None, 0,
-                            self.ctx.ws_ptr, self.ctx.ws_bytes)
+                            self.ws_ptr, self.ws_bytes)
         return (self.lib.gan_act_bwd, (self._desc(d),), "act_bwd")
 
     def bias_grad(self, dy, dbias_ptr, accumulate):
         self.keep.append(dy)
-        return (self.lib.gan_bias_grad, (self.ctx.dt, C.byref(dy), dbias_ptr, int(accumulate), self.ctx.ws_ptr,
-                                         self.ctx.ws_bytes), "bias_grad")
+        return (self.lib.gan_bias_grad, (self.ctx.dt, C.byref(dy), dbias_ptr, int(accumulate), self.ws_ptr,
+                                         self.ws_bytes), "bias_grad")
 
 
 class GeneratorNet:
@@ -450,12 +484,22 @@ class GenCall:
     def out_view(self):
         return self.out.view(0, self.C)
 
-    def backward(self, use_dgen2=False, need_dx=False, accumulate=False):
+    def backward(self, use_dgen2=False, need_dx=False, accumulate=False, defer_wgrads=False):
         """Upstream gradient(s) w.r.t. the tanh output must be in self.dgen (and self.dgen2)."""
         key = (use_dgen2, need_dx, accumulate)
         if key not in self._bwd_cache:
             self._bwd_cache[key] = self._build_bwd(*key)
-        self.ctx.run(self._bwd_cache[key])
+        ops = self._bwd_cache[key]
+        if defer_wgrads:
+            self.ctx.run([o for o in ops if not (len(o) > 4 and o[4])])
+            self._deferred = [o for o in ops if len(o) > 4 and o[4]]
+        else:
+            self.ctx.run(ops)
+
+    def run_deferred_wgrads(self, stream):
+        """Kernel-gradient GEMMs postponed by backward(defer_wgrads=True): they only feed Adam."""
+        self.ctx.run_on(self._deferred, stream)
+        self._deferred = []
 
     def output_f32(self):
         o = torch.empty((self.B, self.S, self.S, self.C), dtype=torch.float32, device=self.ctx.device)
@@ -494,6 +538,7 @@ class DiscCall:
         self.N = N
         bd = _Builder(ctx, P, net.norm)
         self._bd = bd
+        self._bd2 = _Builder(ctx, P, net.norm, lane=2)      # parameter-gradient pass: second chain
         bn = net.norm == 'batchnorm'
         groups = calls if bn else N
         self.groups = groups
@@ -544,7 +589,7 @@ class DiscCall:
     def _chain(self, n0, n, groups, stat_off, wgrads, need_dx, accumulate):
         """Backward over samples [n0, n0+n).  Scratch gradients always live at samples [0, n) of the dA/dy
         buffers; saved forward tensors are read at [n0, n0+n)."""
-        bd, P = self._bd, self.net.params
+        bd, P = (self._bd2 if wgrads else self._bd), self.net.params
         ops = []
         sv = lambda buf: buf.view(0, None, n0, n)          # saved forward tensors
         gv = lambda buf: buf.view(0, None, 0, n)           # gradient scratch
@@ -572,12 +617,18 @@ class DiscCall:
                                P.nat['down0.kernel'].data_ptr(), self.net.cin, 2))
         return ops
 
+    def params_ops(self, accumulate=False):
+        key = ('A', accumulate)
+        if key not in self._cache:
+            self._cache[key] = self._chain(0, self.N, self.groups, 0, True, False, accumulate)
+        return self._cache[key]
+
     def backward_params(self, accumulate=False):
         """Pass A: dlogits (all invocations, written by the loss kernels) -> parameter gradients."""
         key = ('A', accumulate)
         if key not in self._cache:
             self._cache[key] = self._chain(0, self.N, self.groups, 0, True, False, accumulate)
-        self.ctx.run(self._cache[key])
+        self.ctx.run(self._cache[key], lane=2 if self.ctx.multistream else 0)      # (ops carry lane-2/3 workspaces either way)
 
     def backward_input(self, call):
         """Pass B: gradient w.r.t. the input of invocation `call`; its dlogits must be in self.dlogits_b.

@@ -132,8 +132,36 @@ class Pix2PixStep(_StepBase):
         if training:
             d.backward_input(1)                                       # dL_G/d gen through D(fake), pre-update D
             self._copy(d.dxin.view(Cc, Cc), g.dgen2.view(0, Cc))
-            g.backward(use_dgen2=True)                                # pix2pix.py:210
-            d.backward_params()                                       # pix2pix.py:211
+            # two independent chains: D's parameter gradients (pix2pix.py:211) beside G's backward (:210)
+            main, lane2 = self.ctx.lane_stream(0), self.ctx.lane_stream(2)
+            if self.ctx.ms_mode == 2:
+                lane2.wait_stream(main)
+                d.backward_params()
+                g.backward(use_dgen2=True)
+                main.wait_stream(lane2)
+            elif self.ctx.ms_mode == 1:       # one fork/join: G's wgrads (they only feed Adam) beside D's pass
+                g.backward(use_dgen2=True, defer_wgrads=True)
+                lane2.wait_stream(main)
+                g.run_deferred_wgrads(lane2)
+                d.backward_params()
+                main.wait_stream(lane2)
+            elif self.ctx.ms_mode == 3:       # D's parameter pass beside the whole G backward
+                lane2.wait_stream(main)
+                self.ctx.run_on(d.params_ops(), lane2)
+                g.backward(use_dgen2=True)
+                main.wait_stream(lane2)
+            elif self.ctx.ms_mode == 4:       # three chains: D params | G dgrad/norm chain | G wgrads
+                lane3 = self.ctx.lane_stream(3)
+                lane2.wait_stream(main)
+                self.ctx.run_on(d.params_ops(), lane2)
+                g.backward(use_dgen2=True, defer_wgrads=True)
+                lane3.wait_stream(main)
+                g.run_deferred_wgrads(lane3)
+                main.wait_stream(lane2)
+                main.wait_stream(lane3)
+            else:
+                g.backward(use_dgen2=True)
+                d.backward_params()
         return self.losses                                            # Adam: _update() (pix2pix.py:213-216)
 
     def train_step(self, input_image, target, training=True):
@@ -213,9 +241,17 @@ class CycleGANStep(_StepBase):
             dx.backward_input(1)
             self._copy(dx.dxin.view(0, Cc), fx.dgen.view(0, Cc)); self._copy(cy.dxin.view(0, Cc), fx.dgen2.view(0, Cc))
             fx.backward(use_dgen2=True, accumulate=True)              # G_f
-            sy.backward(accumulate=True)                              # identity_y -> G_g
-            sx.backward(accumulate=True)                              # identity_x -> G_f
-            dx.backward_params(); dy.backward_params()                # :257-260
+            main, lane2 = self.ctx.lane_stream(0), self.ctx.lane_stream(2)
+            if self.ctx.ms_mode == 2:
+                lane2.wait_stream(main)
+                dx.backward_params(); dy.backward_params()            # :257-260, second chain beside the identity terms
+                sy.backward(accumulate=True)                          # identity_y -> G_g
+                sx.backward(accumulate=True)                          # identity_x -> G_f
+                main.wait_stream(lane2)
+            else:
+                sy.backward(accumulate=True)
+                sx.backward(accumulate=True)
+                dx.backward_params(); dy.backward_params()
         return self.losses                                            # four Adam applies: _update() (:263-273)
 
     def train_step(self, real_x, real_y, training=True):

@@ -15,7 +15,8 @@ step = (Pix2PixStep if a.model == 'pix2pix' else CycleGANStep)(ctx, a.batch, a.i
 x = [torch.rand(a.batch, a.img_size, a.img_size, 1, device='cuda') * 2 - 1 for _ in range(2)]
 recs = []
 orig = ctx.run
-def timed(ops):
+ctx.multistream = False
+def timed(ops, lane=0):
     st = ctx.stream()
     for op in ops:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
