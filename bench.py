@@ -52,14 +52,14 @@ def gemm_profile(step, inputs, reps=5):
     step._run(*inputs, training=True)          # untimed eager pass (first eager launches pay one-time costs)
     torch.cuda.synchronize()
     ctx.run = timed_run
-    ctx.multistream = False                    # the instrumented passes run every launch on one stream
+    ms_saved, ctx.ms_mode, ctx.multistream = ctx.ms_mode, 0, False   # instrumented passes: every launch on one stream
     try:
         for _ in range(reps):
             step._run(*inputs, training=True)
         torch.cuda.synchronize()
     finally:
         ctx.run = orig_run
-        ctx.multistream = True
+        ctx.ms_mode, ctx.multistream = ms_saved, ms_saved == 2
     out = {}
     for k, lst in recs.items():
         n = len(lst) // reps                   # launches of this kernel per step
@@ -106,6 +106,7 @@ def main():
     ap.add_argument('--model', default='pix2pix', choices=['pix2pix', 'cyclegan'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--fp32-allreduce', action='store_true', help='exchange gradients as fp32 instead of bf16')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -130,7 +131,7 @@ def main():
     else:
         step = CycleGANStep(ctx, B, S, 1, lam=10.0, seed=123)
     if world > 1:
-        step.sync = GradSync([n.params.grad for n in step.nets()])
+        step.sync = GradSync([n.params.grad for n in step.nets()], compress_bf16=(args.dtype == 'bf16' and not args.fp32_allreduce))
     # synthetic inputs on the normalize() lattice u/127.5-1 (base_gan.py:56-61), different per rank
     g = torch.Generator(device='cpu').manual_seed(123 + rank)
     mk = lambda: (torch.randint(0, 256, (B, S, S, 1), generator=g).float() / 127.5 - 1.0).to(dev)
@@ -166,7 +167,7 @@ def main():
         ms = dt / args.steps * 1e3
         value = world * B * args.steps / dt
         unit = "images/sec" if args.model == 'pix2pix' else "pairs/sec"
-        out = {"metric": "Pix2Pix train_step images/sec at 256x256" if args.model == 'pix2pix' else "CycleGAN train_step pairs/sec",
+        out = {"metric": f"Pix2Pix train_step images/sec at {S}x{S}" if args.model == 'pix2pix' else f"CycleGAN train_step pairs/sec at {S}x{S}",
                "value": round(value, 2), "unit": unit, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": args.dtype, "data": "synthetic",

@@ -4,6 +4,12 @@ point-to-point links rather than many small per-tensor all-reduces.  The referen
 (base_gan.py:18-19 only prints the GPU count); semantics are defined here: per-replica
 BatchNorm statistics, gradient = mean over ranks of the per-rank mean-loss gradients.
 
+The exchange is asynchronous: `start(i)` enqueues the all-reduce of buffer i on the communicator's stream
+(after the work already queued on the current stream) and returns; `finish()` makes the current stream wait
+for all of them.  The step driver starts the generator's (large) exchange as soon as its backward is done and
+runs the discriminator's parameter-gradient pass meanwhile.  Optional bf16 wire format halves the bytes
+(57 M fp32 gradients = 229 MB per Pix2Pix step).
+
 Backend "nccl" is RCCL on ROCm; "gloo" is used by the CPU tests (world_size 2).
 """
 from __future__ import annotations
@@ -21,28 +27,41 @@ class GradSync:
         self.compress = compress_bf16
         self.max_chunk = max_chunk_elems
         self._stage = [torch.empty_like(b, dtype=torch.bfloat16) for b in self.bufs] if compress_bf16 else None
+        self._pending = []
 
     @property
     def grad_scale(self):
         """Adam consumes SUM-reduced gradients scaled by 1/world (mean over ranks)."""
         return 1.0 / self.world
 
-    def __call__(self):
+    def start(self, i):
+        """Begin the all-reduce of buffer i (non-blocking for the host and for the current stream)."""
         if self.world == 1:
             return
-        for i, b in enumerate(self.bufs):
-            if self.compress:
-                s = self._stage[i]
-                s.copy_(b)
-                self._all_reduce_chunks(s)
-                b.copy_(s)
-            else:
-                self._all_reduce_chunks(b)
-
-    def _all_reduce_chunks(self, t):
+        b = self.bufs[i]
+        t = b
+        if self.compress:
+            t = self._stage[i]
+            t.copy_(b)
+        works = []
         n = t.numel()
         for o in range(0, n, self.max_chunk):
-            dist.all_reduce(t[o:min(n, o + self.max_chunk)], op=dist.ReduceOp.SUM, group=self.group)
+            works.append(dist.all_reduce(t[o:min(n, o + self.max_chunk)], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        self._pending.append((i, works))
+
+    def finish(self):
+        """Current stream waits for every started exchange; decompress if needed."""
+        for i, works in self._pending:
+            for w in works:
+                w.wait()
+            if self.compress:
+                self.bufs[i].copy_(self._stage[i])
+        self._pending = []
+
+    def __call__(self):
+        for i in range(len(self.bufs)):
+            self.start(i)
+        self.finish()
 
 
 def shard_batch(global_batch, rank, world):

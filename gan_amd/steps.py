@@ -63,17 +63,24 @@ class _StepBase:
         torch.cuda.synchronize()
         split = training and self.sync is not None and self.sync.world > 1
         g1 = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g1):
-            if split:
-                self._forward_backward(*self._static_in, training)
-            else:
+        g2 = g3 = None
+        if not split:
+            with torch.cuda.graph(g1):
                 self._run(*self._static_in, training=training)
-        g2 = None
-        if split:
+        else:
+            # graph 1: forward, losses, generator-side backward  -> start the generators' (large) exchange
+            # graph 2: discriminator parameter pass (overlaps it) -> start the discriminators' exchange
+            # graph 3: Adam, after both exchanges have landed
+            with torch.cuda.graph(g1):
+                self._forward_backward(*self._static_in, training, phase=1)
             g2 = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g2):
+                self._forward_backward(*self._static_in, training, phase=2)
+            g3 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g3):
                 self._update()
-        self._graphs = (g1, g2)
+        self._graphs = (g1, g2, g3)
+        early, late = self.sync_order() if split else ((), ())
 
         def replay(*inputs):
             for dst, src in zip(self._static_in, inputs):
@@ -81,8 +88,13 @@ class _StepBase:
                     dst.copy_(src, non_blocking=True)
             g1.replay()
             if g2 is not None:
-                self.sync()
+                for i in early:
+                    self.sync.start(i)
                 g2.replay()
+                for i in late:
+                    self.sync.start(i)
+                self.sync.finish()
+                g3.replay()
             return self.losses
         return replay
 
@@ -110,8 +122,14 @@ class Pix2PixStep(_StepBase):
         sh = (self.B, self.S, self.S, self.C)
         return [torch.zeros(sh, dtype=torch.float32, device=self.ctx.device) for _ in range(2)]
 
-    def _forward_backward(self, inp, tar, training=True):
+    def sync_order(self):
+        return (0,), (1,)          # indices into nets(): G's gradients are complete after phase 1, D's after phase 2
+
+    def _forward_backward(self, inp, tar, training=True, phase=0):
         B, Cc, g, d = self.B, self.C, self.g, self.d
+        if phase == 2:
+            d.backward_params()
+            return self.losses
         # inputs -> typed, channel-padded buffers.  D input = concat([inp, tar|gen]) (base_gan.py:139)
         self._pack(inp, g.xin.view(0, Cc))
         self._pack(inp, d.xin.view(0, Cc, 0, B))
@@ -134,7 +152,9 @@ class Pix2PixStep(_StepBase):
             self._copy(d.dxin.view(Cc, Cc), g.dgen2.view(0, Cc))
             # two independent chains: D's parameter gradients (pix2pix.py:211) beside G's backward (:210)
             main, lane2 = self.ctx.lane_stream(0), self.ctx.lane_stream(2)
-            if self.ctx.ms_mode == 2:
+            if phase == 1:                    # data-parallel: D's parameter pass is phase 2 (beside G's all-reduce)
+                g.backward(use_dgen2=True)
+            elif self.ctx.ms_mode == 2:
                 lane2.wait_stream(main)
                 d.backward_params()
                 g.backward(use_dgen2=True)
@@ -202,8 +222,14 @@ class CycleGANStep(_StepBase):
         sh = (self.B, self.S, self.S, self.C)
         return [torch.zeros(sh, dtype=torch.float32, device=self.ctx.device) for _ in range(2)]
 
-    def _forward_backward(self, real_x, real_y, training=True):
+    def sync_order(self):
+        return (0, 1), (2, 3)
+
+    def _forward_backward(self, real_x, real_y, training=True, phase=0):
         B, Cc, lam = self.B, self.C, self.lam
+        if phase == 2:
+            self.dx.backward_params(); self.dy.backward_params()
+            return self.losses
         fy, cx, fx, cy, sx, sy, dx, dy = self.fy, self.cx, self.fx, self.cy, self.sx, self.sy, self.dx, self.dy
         self._pack(real_x, fy.xin.view(0, Cc)); self._pack(real_x, sx.xin.view(0, Cc)); self._pack(real_x, dx.xin.view(0, Cc, 0, B))
         self._pack(real_y, fx.xin.view(0, Cc)); self._pack(real_y, sy.xin.view(0, Cc)); self._pack(real_y, dy.xin.view(0, Cc, 0, B))
@@ -242,7 +268,7 @@ class CycleGANStep(_StepBase):
             self._copy(dx.dxin.view(0, Cc), fx.dgen.view(0, Cc)); self._copy(cy.dxin.view(0, Cc), fx.dgen2.view(0, Cc))
             fx.backward(use_dgen2=True, accumulate=True)              # G_f
             main, lane2 = self.ctx.lane_stream(0), self.ctx.lane_stream(2)
-            if self.ctx.ms_mode == 2:
+            if phase == 0 and self.ctx.ms_mode == 2:
                 lane2.wait_stream(main)
                 dx.backward_params(); dy.backward_params()            # :257-260, second chain beside the identity terms
                 sy.backward(accumulate=True)                          # identity_y -> G_g
@@ -251,7 +277,8 @@ class CycleGANStep(_StepBase):
             else:
                 sy.backward(accumulate=True)
                 sx.backward(accumulate=True)
-                dx.backward_params(); dy.backward_params()
+                if phase != 1:
+                    dx.backward_params(); dy.backward_params()
         return self.losses                                            # four Adam applies: _update() (:263-273)
 
     def train_step(self, real_x, real_y, training=True):

@@ -189,3 +189,97 @@ def test_generator_output_on_reference_example_pairs(dtype):
             assert abs(np.abs(v).sum() - sa) <= 2e-2 * sa + 1e-12, nm       # checksum of |grad| per tensor
     else:
         assert err < 0.15 and np.allclose(losses, gold['losses'], rtol=5e-2)
+
+
+class _FakeSync:
+    """world=2 exchange stub: forces the 3-graph data-parallel schedule on one GPU (gradients unchanged)."""
+    world = 2
+    grad_scale = 1.0
+
+    def __init__(self):
+        self.calls = []
+
+    def start(self, i):
+        self.calls.append(('start', i))
+
+    def finish(self):
+        self.calls.append(('finish',))
+
+    def __call__(self):
+        pass
+
+
+def test_ddp_three_graph_schedule_matches_single_graph():
+    ctx, st, Gp, Dp, inp, tar, masks = _setup_p2p('f32', B=2)
+    ti, tt = torch.from_numpy(inp).to(ctx.device), torch.from_numpy(tar).to(ctx.device)
+    st.train_step(ti, tt, True)
+    w_ref, d_ref = st.G.params.master.clone(), st.D.params.master.clone()
+    ctx2, st2, *_ = _setup_p2p('f32', B=2)
+    st2.sync = _FakeSync()
+    replay = st2.capture(training=True)
+    st2.G.params.load_numpy(Gp); st2.D.params.load_numpy(Dp)
+    for ps in (st2.G.params, st2.D.params):
+        ps.m.zero_(); ps.v.zero_(); ps.step.zero_()
+    st2.sync.calls.clear()
+    replay(ti, tt)
+    assert st2.sync.calls == [('start', 0), ('start', 1), ('finish',)]     # G exchange starts before D's pass
+    assert torch.allclose(w_ref, st2.G.params.master, atol=1e-6) and torch.allclose(d_ref, st2.D.params.master, atol=1e-6)
+
+
+def _ddp_gpu_worker(rank, world, port, q):
+    import os
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from gan_amd.ddp import GradSync
+    ctx, st, Gp, Dp, inp, tar, masks = _setup_p2p('f32', B=4)          # global batch 4 -> 2 per rank
+    from gan_amd.nets import Ctx
+    from gan_amd.steps import Pix2PixStep
+    st = Pix2PixStep(ctx, 2, 256, 1, lam=100.0, seed=123)
+    st.G.params.load_numpy(Gp); st.D.params.load_numpy(Dp)
+    st.g.set_dropmasks([m[2 * rank:2 * rank + 2] for m in masks])
+    st.sync = GradSync([n.params.grad for n in st.nets()])
+    sl = slice(2 * rank, 2 * rank + 2)
+    replay = st.capture(training=True)
+    st.G.params.load_numpy(Gp); st.D.params.load_numpy(Dp)
+    for ps in (st.G.params, st.D.params):
+        ps.m.zero_(); ps.v.zero_(); ps.step.zero_()
+    replay(torch.from_numpy(inp[sl]).to(ctx.device), torch.from_numpy(tar[sl]).to(ctx.device))
+    torch.cuda.synchronize()
+    q.put((rank, st.G.params.grad.cpu().numpy() * st.sync.grad_scale, st.G.params.master.cpu().numpy(), st.D.params.master.cpu().numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ddp_two_ranks_equal_sharded_single_process():
+    """SURVEY.md 8e parity definition: a data-parallel step == one process that runs each shard separately (own BN
+    statistics) and averages the gradients.  Two processes share the one GPU; gloo carries the exchange."""
+    import os
+    import torch.multiprocessing as mp
+    mpc = mp.get_context('spawn')
+    q = mpc.Queue()
+    port = 29700 + os.getpid() % 1000
+    procs = [mpc.Process(target=_ddp_gpu_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    # ranks agree with each other after the update
+    assert np.array_equal(res[0][2], res[1][2]) and np.array_equal(res[0][3], res[1][3])
+    assert np.allclose(res[0][1], res[1][1])
+    # single process: shard by shard, average gradients
+    ctx, st, Gp, Dp, inp, tar, masks = _setup_p2p('f32', B=4)
+    from gan_amd.steps import Pix2PixStep
+    acc = None
+    for r in range(2):
+        s1 = Pix2PixStep(ctx, 2, 256, 1, lam=100.0, seed=123)
+        s1.G.params.load_numpy(Gp); s1.D.params.load_numpy(Dp)
+        s1.g.set_dropmasks([m[2 * r:2 * r + 2] for m in masks])
+        sl = slice(2 * r, 2 * r + 2)
+        s1._forward_backward(torch.from_numpy(inp[sl]).to(ctx.device), torch.from_numpy(tar[sl]).to(ctx.device), True)
+        g = s1.G.params.grad.cpu().numpy()
+        acc = g if acc is None else acc + g
+    ref = acc / 2
+    assert np.abs(res[0][1] - ref).max() <= 1e-5 * np.abs(ref).max()

@@ -15,7 +15,7 @@ step = (Pix2PixStep if a.model == 'pix2pix' else CycleGANStep)(ctx, a.batch, a.i
 x = [torch.rand(a.batch, a.img_size, a.img_size, 1, device='cuda') * 2 - 1 for _ in range(2)]
 recs = []
 orig = ctx.run
-ctx.multistream = False
+ctx.multistream = False; ctx.ms_mode = 0
 def timed(ops, lane=0):
     st = ctx.stream()
     for op in ops:
