@@ -184,8 +184,16 @@ def main():
         tot_ms = sum(v[0] for v in prof.values())
         kname, (kms, kfl, kn) = max(prof.items(), key=lambda kv: kv[1][0])
         ach = kfl / (kms * 1e-3) / 1e12
+        traffic = None          # HBM bytes per launch from the committed PMC passes (profiles/), if present
+        try:
+            pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')))
+            if B == 16 and S == 256 and args.model == 'pix2pix' and kname in pmc:
+                traffic = pmc[kname]["hbm_bytes_per_launch"]
+        except Exception:
+            pass
         out["roofline"] = {"bound": "mfma", "kernel": kname, "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS,
-                           "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                           "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                           "flops_per_launch": round(kfl / kn),
                            "launches_per_step": kn, "avg_launch_us": round(kms / kn * 1e3, 2),
                            "gemm_share_of_eager_gemm_time": round(kms / tot_ms, 3)}
         out["kernels"] = {k: {"ms_per_step": round(v[0], 4), "tflops": round(v[1] / (v[0] * 1e-3) / 1e12, 1), "launches": v[2]}
