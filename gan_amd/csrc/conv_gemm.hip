@@ -349,6 +349,13 @@ static constexpr int cfg_ns(int BM, int BN) {
   return BM == 256 ? (BN == 256 ? 2 : 5) : ((BM == 128 && BN >= 64) || (BM == 64 && BN == 128)) ? 3 : 2;
 }
 
+static int tune(const char* name, int dflt) {   // GAN_AMD_<name> overrides a planner constant (tuning experiments)
+  char key[64];
+  snprintf(key, sizeof key, "GAN_AMD_%s", name);
+  const char* e = getenv(key);
+  return e ? atoi(e) : dflt;
+}
+
 struct GemmPlan {
   GemmParams p;
   int BM, BN, P;
@@ -413,16 +420,18 @@ static int plan_gemm(const GanConvDesc* d, int op, GemmPlan* pl) {
     const long long b128 = ((M + 127) / 128) * ((y.c + 127) / 128) * P;
     const long long b256n = ((M + 255) / 256) * ((y.c + 127) / 128) * P;
     const long long b256 = ((M + 255) / 256) * ((y.c + 255) / 256) * P;
-    double best = 0.55 * fill(b128, 512);
-    if (b256n >= 128 && 0.8 * fill(b256n, 256) > best) { best = 0.8 * fill(b256n, 256); BM = 256; BN = 128; }
-    if (y.c >= 256 && b256 >= 128 && 1.0 * fill(b256, 256) > best) { BM = 256; BN = 256; }
+    static const int q128 = tune("Q128", 55), q256n = tune("Q256N", 80), minb = tune("BIGMIN", 128);
+    double best = 0.01 * q128 * fill(b128, 512);
+    if (b256n >= minb && 0.01 * q256n * fill(b256n, 256) > best) { best = 0.01 * q256n * fill(b256n, 256); BM = 256; BN = 128; }
+    if (y.c >= 256 && b256 >= minb && 1.0 * fill(b256, 256) > best) { BM = 256; BN = 256; }
   }
   p.kchunks = (int)(Kbytes / cfg_bkb(BM, BN));
   int tilesN = (y.c + BN - 1) / BN;
   long long tilesM = (M + BM - 1) / BM;
   long long blocks = tilesM * tilesN * P;
   int splits = 1;
-  const long long target = BM == 256 ? 128 : (BN == 16 ? 1024 : 512);   // BN=16: streaming layers want more, shorter blocks
+  static const int t_small = tune("CONV_TARGET", 512), t_skinny = tune("SKINNY_TARGET", 1024);
+  const long long target = BM == 256 ? 128 : (BN == 16 ? t_skinny : t_small);   // BN=16: streaming layers want more, shorter blocks
   if (blocks < target) {
     splits = (int)((target + blocks - 1) / blocks);
     int maxs = p.kchunks / 4; if (maxs < 1) maxs = 1;

@@ -268,7 +268,7 @@ static int plan_wgrad(const GanWgradDesc* d, WgradPlan* pl) {
   p.kchunks = (int)((M + bkm - 1) / bkm);
   long long blocks = (long long)tilesA * tilesB * taps;
   int splits = 1;
-  const long long target = p.fold ? 1024 : 256;     // fold mode streams the SMALL tensor once: HBM-bound, wants many blocks
+  const long long target = p.fold ? 1024 : 512;     // fold mode streams the SMALL tensor once: HBM-bound, wants many blocks
   if (blocks < target) {
     splits = (int)((target + blocks - 1) / blocks);
     int maxs = p.kchunks / 4; if (maxs < 1) maxs = 1;
