@@ -217,18 +217,19 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* slab, fl
   dw[i] = accumulate ? dw[i] + s : s;
 }
 __global__ __launch_bounds__(256) void wgrad_reduce_wide_kernel(const float* slab, float* dw, long long count, int splits, int accumulate) {
-  __shared__ float red[8][33];
-  const int el = threadIdx.x & 31, sl = threadIdx.x >> 5;
-  const long long i = (long long)blockIdx.x * 32 + el;
+  // 4 elements x 64 slab-lanes per block: hundreds of slabs of a small tensor -> many short chains, many blocks
+  __shared__ float red[64][5];
+  const int el = threadIdx.x & 3, sl = threadIdx.x >> 2;
+  const long long i = (long long)blockIdx.x * 4 + el;
   float s = 0.f;
   if (i < count)
-    for (int k = sl; k < splits; k += 8) s += slab[(size_t)k * count + i];
+    for (int k = sl; k < splits; k += 64) s += slab[(size_t)k * count + i];
   red[sl][el] = s;
   __syncthreads();
   if (sl == 0 && i < count) {
     float t = 0.f;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) t += red[k][el];
+#pragma unroll 8
+    for (int k = 0; k < 64; ++k) t += red[k][el];
     dw[i] = accumulate ? dw[i] + t : t;
   }
 }
@@ -334,7 +335,7 @@ int gan_conv_wgrad(const GanWgradDesc* d, gan_stream_t stream) {
       hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st,
                          (const float*)pl.p.slab, pl.p.dw, count, pl.p.splits, pl.p.accumulate);
     else
-      hipLaunchKernelGGL(wgrad_reduce_wide_kernel, dim3((unsigned)((count + 31) / 32)), dim3(256), 0, st,
+      hipLaunchKernelGGL(wgrad_reduce_wide_kernel, dim3((unsigned)((count + 3) / 4)), dim3(256), 0, st,
                          (const float*)pl.p.slab, pl.p.dw, count, pl.p.splits, pl.p.accumulate);
     GAN_CHECK_LAUNCH();
   }
