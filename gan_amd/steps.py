@@ -165,6 +165,13 @@ class Pix2PixStep(_StepBase):
                 g.run_deferred_wgrads(lane2)
                 d.backward_params()
                 main.wait_stream(lane2)
+            elif self.ctx.ms_mode == 5:       # mode 3 + G's wgrads on their own side stream (per-op dependencies)
+                lane2.wait_stream(main)
+                self.ctx.run_on(d.params_ops(), lane2)
+                self.ctx.multistream = True
+                g.backward(use_dgen2=True)
+                self.ctx.multistream = False
+                main.wait_stream(lane2)
             elif self.ctx.ms_mode == 3:       # D's parameter pass beside the whole G backward
                 lane2.wait_stream(main)
                 self.ctx.run_on(d.params_ops(), lane2)
