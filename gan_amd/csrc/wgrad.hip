@@ -25,6 +25,7 @@ struct WgradParams {
   int tilesB;
   int splits, kchunks;
   int accumulate, fold;
+  int debug;     // timing experiments (GAN_AMD_WGRAD_DEBUG): 1 skip the MFMA phase, 2 skip global loads + LDS stores
 };
 
 template <typename T, int TA, int TB, int WAVES_A, int WAVES_B, bool TR>
@@ -115,8 +116,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
   if (kc_begin < kc_end) { gload(kc_begin); lstore(0); }
   __syncthreads();
   for (int kc = kc_begin; kc < kc_end; ++kc) {
-    const bool more = kc + 1 < kc_end;
+    const bool more = kc + 1 < kc_end && !(p.debug & 2);
     if (more) gload(kc + 1);
+    if (!(p.debug & 1)) {
     const unsigned char* Ab = As + buf * BKM * RSA + (wa * WTA) * ES;
     const unsigned char* Bb = Bs + buf * BKM * RSB + (wb * WTB) * ES;
     if constexpr (sizeof(T) == 4) {
@@ -177,6 +179,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
           for (int j = 0; j < NT; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
       }
+    }
     }
     if (more) lstore(buf ^ 1);
     __syncthreads();
@@ -251,6 +254,7 @@ static int plan_wgrad(const GanWgradDesc* d, WgradPlan* pl) {
   p.Hb = b.h; p.Wb = b.w; p.bpitch = b.pitch; p.Ca = b.c; p.spitch = s.pitch; p.Cb = s.c;
   p.S = d->stride; p.M = (int)M; p.divW = make_fastdiv(s.w); p.divH = make_fastdiv(s.h);
   p.CaReal = d->big_c; p.CbReal = d->small_c; p.accumulate = d->accumulate;
+  { static int dbg = -1; if (dbg < 0) { const char* e = getenv("GAN_AMD_WGRAD_DEBUG"); dbg = e ? atoi(e) : 0; } p.debug = dbg; }
   p.fold = (b.c == 8) ? 1 : 0;
   int TA, TB, tilesA, taps;
   if (p.fold) { TA = 128; tilesA = 1; taps = 1; TB = s.c >= 128 ? 128 : (s.c >= 64 ? 64 : 16); if (TB == 16) return GAN_E_SHAPE; }
@@ -313,6 +317,227 @@ static int launch_wgrad(const WgradPlan& pl, hipStream_t st) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// v2: LDS-DMA pipeline.  Both operand tiles go global -> LDS directly (buffer_load_dwordx4 ... lds; zero
+// padding / ragged rows through the descriptor's range check), row-major [m][channel] rows, 16-byte slots
+// XOR-swizzled by SWZ(row) through the SOURCE address so the transposing fragment reads of a 32-lane half
+// cover all 64 banks; NS stages with counted vmcnt + raw s_barrier; fragment reads in inline asm (hipcc would
+// otherwise drain every in-flight LDS-DMA before a compiler-visible LDS read).
+template <int N> __device__ __forceinline__ void wg_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <typename T, int TA, int TB, int WAVES_A, int WAVES_B, int NS>
+__global__ __launch_bounds__(256) void wgrad_dma_kernel(const WgradParams p, unsigned bigbytes, unsigned smallbytes) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int VEC = VecOf<T>::N;
+  constexpr int ES = sizeof(T);
+  constexpr int BKM = 128 / ES;                       // rows (m) per stage: 64 bf16 / 32 fp32
+  constexpr int RSA = TA * ES, RSB = TB * ES;         // unpadded LDS row strides
+  constexpr int LPA = RSA / 16, LPB = RSB / 16;       // lanes (16-B slots) per row
+  constexpr int RPA = 64 / LPA, RPB = 64 / LPB;       // rows per 1-KiB piece
+  constexpr int PA = BKM / RPA, PB = BKM / RPB;       // pieces per stage
+  constexpr int AI = (PA + 3) / 4, BI = (PB + 3) / 4; // per wave
+  constexpr int STAGE = BKM * (RSA + RSB);
+  constexpr int WTA = TA / WAVES_A, WTB = TB / WAVES_B, MT = WTA / 16, NT = WTB / 16;
+  static_assert(WAVES_A * WAVES_B == 4, "4 waves");
+  static_assert(NS == 2 || (PA % 4 == 0 && PB % 4 == 0), "counted vmcnt needs equal pieces per wave");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  // slot swizzle: rows {0..3} and {8..11} (and {4..7}, {12..15}) of a k-step must land on 8 different slot pairs
+  auto swz = [](int row, int lanes_per_row) { return (((row & 3) | (((row >> 3) & 1) << 2)) << 1) & (lanes_per_row - 1) & ~1; };
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wa = wave / WAVES_B, wb = wave % WAVES_B;
+  const int r = lane & 15, q = lane >> 4;
+  const int ta = blockIdx.x / p.tilesB, tb = blockIdx.x % p.tilesB;
+  const int ca0 = ta * TA, cb0 = tb * TB;
+  const int tap = blockIdx.y, split = blockIdx.z;
+  const int kh = tap >> 2, kw = tap & 3;
+  const __amdgpu_buffer_rsrc_t rbig = __builtin_amdgcn_make_buffer_rsrc((void*)p.big, 0, bigbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsmall = __builtin_amdgcn_make_buffer_rsrc((void*)p.small, 0, smallbytes, 0x00020000);
+
+  // per-lane constants of the pieces this wave issues
+  const int arow_l = lane / LPA, aslot = lane % LPA, brow_l = lane / LPB, bslot = lane % LPB;
+  auto issue = [&](int kc, int stage) {
+    unsigned char* As = smem + stage * STAGE;
+    unsigned char* Bs = As + BKM * RSA;
+    const unsigned mbase = (unsigned)kc * BKM;
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      const int pc = wave + 4 * i;
+      if (pc < PA) {
+        const int row = pc * RPA + arow_l;
+        const unsigned m = mbase + row;
+        int off = (int)0x80000000;
+        if (m < (unsigned)p.M) {
+          const unsigned t = fdiv(m, p.divW);
+          const int gx = m - t * p.divW.d;
+          const unsigned img = fdiv(t, p.divH);
+          const int gy = t - img * p.divH.d;
+          const int ce = (aslot ^ swz(row, LPA)) * VEC;          // element index inside the tile row
+          int akh = kh, akw = kw, c = ca0 + ce;
+          if (p.fold) { const int ft = ce >> 3; akh = ft >> 2; akw = ft & 3; c = ce & 7; }
+          const int sy = gy * p.S + akh - 1, sx = gx * p.S + akw - 1;
+          if ((unsigned)sy < (unsigned)p.Hb && (unsigned)sx < (unsigned)p.Wb && c < p.Ca)
+            off = (int)((((size_t)(img * p.Hb + sy) * p.Wb + sx) * (size_t)p.bpitch + c) * ES);
+        }
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rbig, (__attribute__((address_space(3))) void*)(As + pc * 1024), 16, off, 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+      const int pc = wave + 4 * i;
+      if (pc < PB) {
+        const int row = pc * RPB + brow_l;
+        const unsigned m = mbase + row;
+        const int c = cb0 + (bslot ^ swz(row, LPB)) * VEC;
+        const int off = (m < (unsigned)p.M && c < p.Cb) ? (int)(((size_t)m * p.spitch + c) * ES) : (int)0x80000000;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsmall, (__attribute__((address_space(3))) void*)(Bs + pc * 1024), 16, off, 0, 0, 0);
+      }
+    }
+  };
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  auto compute = [&](int stage) {
+    const unsigned abase = lds_base + stage * STAGE, bbase = abase + BKM * RSA;
+    if constexpr (sizeof(T) == 4) {
+      // fp32: A[row = ca][k = m] one element per lane per v_mfma_f32_16x16x4_f32: element (m = kk*4+q, c = tile col + r)
+#pragma unroll 2
+      for (int kk = 0; kk < BKM / 4; ++kk) {
+        const int row = kk * 4 + q;
+        float af[MT], bfv[NT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          const int col = wa * WTA + i * 16 + r;
+          asm volatile("ds_read_b32 %0, %1" : "=v"(af[i]) : "v"(abase + row * RSA + (((col >> 2) ^ swz(row, LPA)) << 4) + (col & 3) * 4));
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const int col = wb * WTB + j * 16 + r;
+          asm volatile("ds_read_b32 %0, %1" : "=v"(bfv[j]) : "v"(bbase + row * RSB + (((col >> 2) ^ swz(row, LPB)) << 4) + (col & 3) * 4));
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bfv[j], acc[i][j], 0, 0, 0);
+      }
+    } else {
+      // bf16: 16-lane group q reads rows ks*32+8q+{0..3} then {4..7} with ds_read_b64_tr_b16; lane i of the group
+      // supplies row (i>>2), elements 4*(i&3).. of the 16-column block and receives column i of the 4 rows
+      typedef __attribute__((ext_vector_type(8))) short s16x8;
+#pragma unroll
+      for (int ks = 0; ks < BKM / 32; ++ks) {
+        s16x4 alo[MT], ahi[MT], blo[NT], bhi[NT];
+        const int row0 = ks * 32 + 8 * q + (r >> 2), row1 = row0 + 4;
+        const int sub = ((r & 3) >> 1), half = (r & 1) * 8;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          const int slot = (wa * WTA + i * 16) / 8 + sub;
+          asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(alo[i]) : "v"(abase + row0 * RSA + ((slot ^ swz(row0, LPA)) << 4) + half));
+          asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(ahi[i]) : "v"(abase + row1 * RSA + ((slot ^ swz(row1, LPA)) << 4) + half));
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const int slot = (wb * WTB + j * 16) / 8 + sub;
+          asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(blo[j]) : "v"(bbase + row0 * RSB + ((slot ^ swz(row0, LPB)) << 4) + half));
+          asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(bhi[j]) : "v"(bbase + row1 * RSB + ((slot ^ swz(row1, LPB)) << 4) + half));
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          s16x8 av = __builtin_shufflevector(alo[i], ahi[i], 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+          for (int j = 0; j < NT; ++j) {
+            s16x8 bv = __builtin_shufflevector(blo[j], bhi[j], 0, 1, 2, 3, 4, 5, 6, 7);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(bf16x8*)&av, *(bf16x8*)&bv, acc[i][j], 0, 0, 0);
+          }
+        }
+      }
+    }
+  };
+
+  const int kc_begin = (int)((long long)p.kchunks * split / p.splits);
+  const int kc_end = (int)((long long)p.kchunks * (split + 1) / p.splits);
+  const int nk = kc_end - kc_begin;
+  constexpr int PT = AI + BI;
+#pragma unroll
+  for (int s = 0; s < NS - 1; ++s)
+    if (s < nk) issue(kc_begin + s, s);
+  int st_c = 0, st_i = NS - 1;
+  for (int i = 0; i < nk; ++i) {
+    const int pending = nk - 1 - i < NS - 2 ? nk - 1 - i : NS - 2;
+    if (NS >= 4 && pending == 2) wg_wait_vmcnt<2 * PT>();
+    else if (NS >= 3 && pending == 1) wg_wait_vmcnt<PT>();
+    else wg_wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (i + NS - 1 < nk) issue(kc_begin + i + NS - 1, st_i);
+    compute(st_c);
+    st_c = st_c + 1 == NS ? 0 : st_c + 1;
+    st_i = st_i + 1 == NS ? 0 : st_i + 1;
+  }
+
+  const size_t per_split = (size_t)16 * p.CaReal * p.CbReal;
+  float* out = p.splits > 1 ? p.slab + (size_t)split * per_split : p.dw;
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      int a = ca0 + wa * WTA + i * 16 + q * 4 + e;
+      int otap = tap, oc = a;
+      if (p.fold) { otap = a >> 3; oc = a & 7; }
+      if (oc < p.CaReal) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          int cb = cb0 + wb * WTB + j * 16 + r;
+          if (cb < p.CbReal) {
+            size_t o = ((size_t)otap * p.CaReal + oc) * p.CbReal + cb;
+            if (p.splits == 1 && p.accumulate) out[o] += acc[i][j][e];
+            else out[o] = acc[i][j][e];
+          }
+        }
+      }
+    }
+#endif
+}
+
+template <typename T, int TA, int TB, int WA, int WB, int NS>
+static int launch_wdma(const WgradPlan& pl, unsigned bigbytes, unsigned smallbytes, hipStream_t st) {
+  static bool attr_set = false;
+  constexpr int ES = sizeof(T);
+  constexpr size_t smem = (size_t)NS * (128 / ES) * (TA + TB) * ES;
+  auto kern = wgrad_dma_kernel<T, TA, TB, WA, WB, NS>;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, pl.grid, dim3(256), smem, st, pl.p, bigbytes, smallbytes);
+  GAN_CHECK_LAUNCH();
+  return 0;
+}
+
+template <typename T>
+static int launch_wgrad_dma(const WgradPlan& pl, unsigned bigbytes, unsigned smallbytes, hipStream_t st) {
+  const int key = pl.TA * 1000 + pl.TB;
+  switch (key) {
+    case 128128: return launch_wdma<T, 128, 128, 2, 2, 2>(pl, bigbytes, smallbytes, st);
+    case 128064: return launch_wdma<T, 128, 64, 2, 2, 3>(pl, bigbytes, smallbytes, st);
+    case 64128: return launch_wdma<T, 64, 128, 2, 2, 3>(pl, bigbytes, smallbytes, st);
+    case 64064: return launch_wdma<T, 64, 64, 2, 2, 3>(pl, bigbytes, smallbytes, st);
+    case 128016: return launch_wdma<T, 128, 16, 4, 1, 2>(pl, bigbytes, smallbytes, st);
+    case 64016: return launch_wdma<T, 64, 16, 4, 1, 2>(pl, bigbytes, smallbytes, st);
+    default: return GAN_E_SHAPE;
+  }
+}
+
 static bool wgrad_use_tr() {
   static int v = -1;
   if (v < 0) { const char* e = getenv("GAN_AMD_WGRAD_NO_TR"); v = (e && e[0] == '1') ? 0 : 1; }
@@ -326,7 +551,15 @@ int gan_conv_wgrad(const GanWgradDesc* d, gan_stream_t stream) {
   if (rc) return rc;
   if (pl.slab_bytes > d->workspace_bytes || (pl.slab_bytes && !d->workspace)) return GAN_E_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
-  if (d->dtype == GAN_F32) rc = launch_wgrad<float, false>(pl, st);
+  static int v1 = -1;
+  if (v1 < 0) { const char* e = getenv("GAN_AMD_WGRAD_V1"); v1 = (e && e[0] == '1') ? 1 : 0; }
+  const size_t es = d->dtype == GAN_F32 ? 4 : 2;
+  const size_t bb = (((size_t)d->big.n * d->big.h * d->big.w - 1) * d->big.pitch + d->big.c) * es;
+  const size_t sb = (((size_t)d->small.n * d->small.h * d->small.w - 1) * d->small.pitch + d->small.c) * es;
+  const bool dma_ok = !v1 && bb < 0x7fffffffull && sb < 0x7fffffffull && !(((uintptr_t)d->big.ptr | (uintptr_t)d->small.ptr) & 15);
+  if (dma_ok) rc = d->dtype == GAN_F32 ? launch_wgrad_dma<float>(pl, (unsigned)bb, (unsigned)sb, st)
+                                       : launch_wgrad_dma<bf16_t>(pl, (unsigned)bb, (unsigned)sb, st);
+  else if (d->dtype == GAN_F32) rc = launch_wgrad<float, false>(pl, st);
   else rc = wgrad_use_tr() ? launch_wgrad<bf16_t, true>(pl, st) : launch_wgrad<bf16_t, false>(pl, st);
   if (rc) return rc;
   if (pl.p.splits > 1) {
