@@ -262,6 +262,8 @@ static int plan_wgrad(const GanWgradDesc* d, WgradPlan* pl) {
     taps = 16;
     TB = s.c >= 128 ? 128 : (s.c >= 64 ? 64 : 16);
     TA = b.c >= 128 ? 128 : (b.c >= 64 ? 64 : 16);
+    { static int big = -1; if (big < 0) { const char* e = getenv("GAN_AMD_WGRAD_BIG"); big = e ? atoi(e) : 0; }
+      if (big && b.c >= 256 && s.c >= 128 && d->dtype == GAN_BF16) TA = 256; }
     if (TB == 16) TA = TA == 16 ? 64 : TA;   // supported: (128|64, 16)
     if (TA == 64 && TB == 16) {}
     if (TA == 16 && TB == 16) return GAN_E_SHAPE;
@@ -326,7 +328,7 @@ static int launch_wgrad(const WgradPlan& pl, hipStream_t st) {
 template <int N> __device__ __forceinline__ void wg_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 template <typename T, int TA, int TB, int WAVES_A, int WAVES_B, int NS>
-__global__ __launch_bounds__(256) void wgrad_dma_kernel(const WgradParams p, unsigned bigbytes, unsigned smallbytes) {
+__global__ __launch_bounds__(64 * WAVES_A * WAVES_B) void wgrad_dma_kernel(const WgradParams p, unsigned bigbytes, unsigned smallbytes) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int VEC = VecOf<T>::N;
   constexpr int ES = sizeof(T);
@@ -335,11 +337,11 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(const WgradParams p, uns
   constexpr int LPA = RSA / 16, LPB = RSB / 16;       // lanes (16-B slots) per row
   constexpr int RPA = 64 / LPA, RPB = 64 / LPB;       // rows per 1-KiB piece
   constexpr int PA = BKM / RPA, PB = BKM / RPB;       // pieces per stage
-  constexpr int AI = (PA + 3) / 4, BI = (PB + 3) / 4; // per wave
+  constexpr int NW = WAVES_A * WAVES_B;
+  constexpr int AI = (PA + NW - 1) / NW, BI = (PB + NW - 1) / NW; // per wave
   constexpr int STAGE = BKM * (RSA + RSB);
   constexpr int WTA = TA / WAVES_A, WTB = TB / WAVES_B, MT = WTA / 16, NT = WTB / 16;
-  static_assert(WAVES_A * WAVES_B == 4, "4 waves");
-  static_assert(NS == 2 || (PA % 4 == 0 && PB % 4 == 0), "counted vmcnt needs equal pieces per wave");
+  static_assert(NS == 2 || (PA % NW == 0 && PB % NW == 0), "counted vmcnt needs equal pieces per wave");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // slot swizzle: rows {0..3} and {8..11} (and {4..7}, {12..15}) of a k-step must land on 8 different slot pairs
   auto swz = [](int row, int lanes_per_row) { return (((row & 3) | (((row >> 3) & 1) << 2)) << 1) & (lanes_per_row - 1) & ~1; };
@@ -363,7 +365,7 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(const WgradParams p, uns
     const unsigned mbase = (unsigned)kc * BKM;
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
-      const int pc = wave + 4 * i;
+      const int pc = wave + NW * i;
       if (pc < PA) {
         const int row = pc * RPA + arow_l;
         const unsigned m = mbase + row;
@@ -385,7 +387,7 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(const WgradParams p, uns
     }
 #pragma unroll
     for (int i = 0; i < BI; ++i) {
-      const int pc = wave + 4 * i;
+      const int pc = wave + NW * i;
       if (pc < PB) {
         const int row = pc * RPB + brow_l;
         const unsigned m = mbase + row;
@@ -519,7 +521,7 @@ static int launch_wdma(const WgradPlan& pl, unsigned bigbytes, unsigned smallbyt
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, pl.grid, dim3(256), smem, st, pl.p, bigbytes, smallbytes);
+  hipLaunchKernelGGL(kern, pl.grid, dim3(64 * WA * WB), smem, st, pl.p, bigbytes, smallbytes);
   GAN_CHECK_LAUNCH();
   return 0;
 }
@@ -528,6 +530,7 @@ template <typename T>
 static int launch_wgrad_dma(const WgradPlan& pl, unsigned bigbytes, unsigned smallbytes, hipStream_t st) {
   const int key = pl.TA * 1000 + pl.TB;
   switch (key) {
+    case 256128: return launch_wdma<T, 256, 128, 4, 2, 2>(pl, bigbytes, smallbytes, st);
     case 128128: return launch_wdma<T, 128, 128, 2, 2, 2>(pl, bigbytes, smallbytes, st);
     case 128064: return launch_wdma<T, 128, 64, 2, 2, 3>(pl, bigbytes, smallbytes, st);
     case 64128: return launch_wdma<T, 64, 128, 2, 2, 3>(pl, bigbytes, smallbytes, st);
