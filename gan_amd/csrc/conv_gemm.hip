@@ -344,9 +344,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p, 
 // ------------------------------------------------------------------------------------------------
 // pipeline shape per tile: big (one block per CU) tiles use 64-byte K rows and 4-5 stages so ~100 KB of
 // LDS-DMA stays in flight per CU; small tiles (several blocks per CU) use 128-byte rows, 2 stages.
-static constexpr int cfg_bkb(int BM, int BN) { return (BM == 256 && BN == 128) ? 64 : 128; }
+static constexpr int cfg_bkb(int BM, int BN) { return 128; }
 static constexpr int cfg_ns(int BM, int BN) {
-  return BM == 256 ? (BN == 256 ? 2 : 5) : ((BM == 128 && BN >= 64) || (BM == 64 && BN == 128)) ? 3 : 2;
+  return BM == 256 ? 2 : ((BM == 128 && BN >= 64) || (BM == 64 && BN == 128)) ? 3 : 2;
 }
 
 static int tune(const char* name, int dflt) {   // GAN_AMD_<name> overrides a planner constant (tuning experiments)
