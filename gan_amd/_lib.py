@@ -22,6 +22,11 @@ class GanTensor(C.Structure):
                 ("pitch", C.c_int32)]
 
 
+class GanPrepEntry(C.Structure):
+    _fields_ = [("master", C.c_void_p), ("nk_native", C.c_void_p), ("nk_transposed", C.c_void_p), ("A", C.c_int32),
+                ("B", C.c_int32), ("tile_start", C.c_int32), ("tiles_b", C.c_int32)]
+
+
 class GanConvDesc(C.Structure):
     _fields_ = [("dtype", C.c_int32), ("stride", C.c_int32), ("x", GanTensor), ("y", GanTensor), ("w", C.c_void_p),
                 ("w_rows", C.c_int32), ("bias", C.c_void_p), ("act", C.c_int32), ("slope", C.c_float),
@@ -68,6 +73,7 @@ SYMBOLS = {
     "gan_conv_wgrad": (C.c_int, [C.POINTER(GanWgradDesc), C.c_void_p]),
     "gan_wgrad_workspace_bytes": (C.c_size_t, [C.POINTER(GanWgradDesc)]),
     "gan_weights_prepare": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gan_weights_prepare_multi": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "gan_norm_stats": (C.c_int, [C.POINTER(GanNormDesc), C.c_void_p]),
     "gan_norm_act_fwd": (C.c_int, [C.POINTER(GanNormDesc), C.c_void_p]),
     "gan_norm_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int64]),

@@ -120,6 +120,41 @@ __global__ __launch_bounds__(256) void wprep_kernel(const float* master, int A, 
   }
 }
 
+// all kernels of a network in ONE launch: blockIdx.x -> (tensor, tap, 64x64 tile) through a small device table
+struct PrepEntry { const float* master; void* nat; void* tr; int32_t A, B, tile_start, tiles_b; };
+template <typename T>
+__global__ __launch_bounds__(256) void wprep_multi_kernel(const PrepEntry* ents, int n) {
+  __shared__ float tile[64][65];
+  int e = 0;
+  while (e + 1 < n && (int)blockIdx.x >= ents[e + 1].tile_start) ++e;
+  const PrepEntry en = ents[e];
+  const int A = en.A, B = en.B;
+  const int B8 = (B + 7) & ~7, A8 = (A + 7) & ~7;
+  const int tiles_a = (A8 + 63) / 64;
+  int t = blockIdx.x - en.tile_start;
+  const int tb = t % en.tiles_b; t /= en.tiles_b;
+  const int ta = t % tiles_a, tap = t / tiles_a;
+  const int b0 = tb * 64, a0 = ta * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  T* nat = (T*)en.nat;
+  T* tr = (T*)en.tr;
+#pragma unroll 4
+  for (int i = 0; i < 16; ++i) {
+    int a = a0 + ty + 4 * i, b = b0 + tx;
+    float v = (a < A && b < B) ? en.master[((size_t)tap * A + a) * B + b] : 0.f;
+    tile[ty + 4 * i][tx] = v;
+    if (nat && a < A && b < B8) st_f(nat + ((size_t)tap * A + a) * B8 + b, v);
+  }
+  __syncthreads();
+  if (tr) {
+#pragma unroll 4
+    for (int i = 0; i < 16; ++i) {
+      int b = b0 + ty + 4 * i, a = a0 + tx;
+      if (b < B && a < A8) st_f(tr + ((size_t)tap * B + b) * A8 + a, tile[tx][ty + 4 * i]);
+    }
+  }
+}
+
 __device__ __forceinline__ uint64_t mix64(uint64_t z) {
   z += 0x9E3779B97F4A7C15ull;
   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
@@ -225,6 +260,17 @@ int gan_weights_prepare(const float* master, int32_t A, int32_t B, int32_t dtype
     hipLaunchKernelGGL(wprep_kernel<float>, grid, dim3(256), 0, st, master, A, B, (float*)nk_native, (float*)nk_transposed);
   else
     hipLaunchKernelGGL(wprep_kernel<bf16_t>, grid, dim3(256), 0, st, master, A, B, (bf16_t*)nk_native, (bf16_t*)nk_transposed);
+  GAN_CHECK_LAUNCH();
+  return 0;
+}
+
+int gan_weights_prepare_multi(const void* entries_dev, int32_t n, int32_t total_tiles, int32_t dtype, gan_stream_t stream) {
+  if (!entries_dev || n <= 0 || total_tiles <= 0) return GAN_E_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == GAN_F32)
+    hipLaunchKernelGGL(wprep_multi_kernel<float>, dim3((unsigned)total_tiles), dim3(256), 0, st, (const PrepEntry*)entries_dev, n);
+  else
+    hipLaunchKernelGGL(wprep_multi_kernel<bf16_t>, dim3((unsigned)total_tiles), dim3(256), 0, st, (const PrepEntry*)entries_dev, n);
   GAN_CHECK_LAUNCH();
   return 0;
 }

@@ -135,12 +135,18 @@ class ParamSet:
                 A, B = shape[2], shape[3]
                 self.nat[name] = torch.zeros((16, A, pad8(B)), dtype=ctx.tdtype, device=dev)
                 self.tr[name] = torch.zeros((16, B, pad8(A)), dtype=ctx.tdtype, device=dev)
-        self._prep_ops = []
+        # one launch refreshes every NK copy of the network (device table of GanPrepEntry)
+        ents, tiles = [], 0
         for name in self.nat:
             o, shape = self.entries[name]
-            self._prep_ops.append((ctx.lib.gan_weights_prepare,
-                                   (self.master.data_ptr() + 4 * o, shape[2], shape[3], ctx.dt,
-                                    self.nat[name].data_ptr(), self.tr[name].data_ptr()), f"weights_prepare({name})"))
+            A, B = shape[2], shape[3]
+            tb = (pad8(B) + 63) // 64
+            ents.append(L.GanPrepEntry(self.master.data_ptr() + 4 * o, self.nat[name].data_ptr(), self.tr[name].data_ptr(), A, B, tiles, tb))
+            tiles += 16 * ((pad8(A) + 63) // 64) * tb
+        arr = (L.GanPrepEntry * len(ents))(*ents)
+        self._prep_table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+        self._prep_ops = [(ctx.lib.gan_weights_prepare_multi, (self._prep_table.data_ptr(), len(ents), tiles, ctx.dt),
+                           "weights_prepare_multi")]
 
     def ptr(self, name, which='master'):
         return getattr(self, which).data_ptr() + 4 * self.entries[name][0]

@@ -92,6 +92,14 @@ int gan_wgrad_plan_info(const GanWgradDesc* d, int32_t* info /* {TA, TB, splitM,
 int gan_weights_prepare(const float* master, int32_t A, int32_t B, int32_t dtype,
                         void* nk_native, void* nk_transposed, gan_stream_t stream);
 
+/* The same for every kernel of a network in one launch.  entries_dev: device array of n GanPrepEntry; tile_start =
+ * running sum of 16 * ceil(pad8(A)/64) * ceil(pad8(B)/64) over the preceding entries, tiles_b = ceil(pad8(B)/64). */
+typedef struct GanPrepEntry {
+  const float* master; void* nk_native; void* nk_transposed;
+  int32_t A, B, tile_start, tiles_b;
+} GanPrepEntry;
+int gan_weights_prepare_multi(const void* entries_dev, int32_t n, int32_t total_tiles, int32_t dtype, gan_stream_t stream);
+
 /* ---- normalisation + activation ------------------------------------------------------------- */
 typedef struct GanNormDesc {
   int32_t dtype;
