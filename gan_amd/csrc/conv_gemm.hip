@@ -101,13 +101,16 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_gemm_kernel(const
 
   // XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch); give each XCD a contiguous
   // run of logical tiles, N tiles fastest, so an A tile is fetched into ONE L2 and re-used by its N tiles.
+  // blockIdx.x enumerates (M tile, N tile, parity) with the parity fastest: the 4 parity sub-GEMMs of a tile
+  // gather the same source rows, so they run next to each other on one XCD and share them in L2.
+  const int P = p.parity ? 4 : 1;
   int bid = blockIdx.x;
-  const int nb = p.tilesM * p.tilesN;
+  const int nb = p.tilesM * p.tilesN * P;
   if ((nb & 7) == 0) bid = (bid & 7) * (nb >> 3) + (bid >> 3);
+  const int par = bid % P;
+  bid /= P;
   const int bm0 = (bid / p.tilesN) * BM, bn0 = (bid % p.tilesN) * BN;
-
-  int par = 0, split = blockIdx.z;
-  if (p.parity) { par = blockIdx.z / p.splits; split = blockIdx.z % p.splits; }
+  const int split = blockIdx.z;
   const int py = par >> 1, px = par & 1;
   int dy0 = p.dy0, dx0 = p.dx0, wy0 = p.wy0, wx0 = p.wx0;
   if (p.parity) { dy0 = py; dx0 = px; wy0 = 1 - py; wx0 = 1 - px; }
@@ -265,7 +268,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_gemm_kernel(const
 
   // epilogue: C/D layout of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg
   if (p.splits > 1) {
-    float* slab = p.slab + (size_t)blockIdx.z * p.M * p.NslabPitch;
+    float* slab = p.slab + (size_t)(par * p.splits + split) * p.M * p.NslabPitch;
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -442,7 +445,7 @@ static int plan_gemm(const GanConvDesc* d, int op, GemmPlan* pl) {
   p.NslabPitch = tilesN * BN;
   p.tilesM = (int)tilesM; p.tilesN = tilesN;
   pl->BM = BM; pl->BN = BN;
-  pl->grid = dim3((unsigned)(tilesM * tilesN), 1, (unsigned)(P * splits));
+  pl->grid = dim3((unsigned)(tilesM * tilesN * P), 1, (unsigned)splits);
   pl->slab_bytes = splits > 1 ? (size_t)P * splits * (size_t)M * p.NslabPitch * sizeof(float) : 0;
   return 0;
 }
