@@ -125,7 +125,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_gemm_kernel(const
   // 0x80000000 for zero padding / rows past M.  Loads go through buffer descriptors, whose range check turns
   // such offsets into zeros, so the K loop spends one LDS read + one add per 1-KiB piece on addressing.
   int* tbl = (int*)(smem + NS * STAGE);       // [T][BM]
-  for (int e = tid; e < p.T * BM; e += NTHREADS) {
+  for (int e = tid; e < ((p.debug & 8) ? 0 : p.T * BM); e += NTHREADS) {
     const int row = e % BM, tap = e / BM;
     const int m = bm0 + row;
     int off = (int)0x80000000;
@@ -267,6 +267,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_gemm_kernel(const
   __syncthreads();
 
   // epilogue: C/D layout of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg
+  if (p.debug & 4) return;   // timing experiment: no epilogue
   if (p.splits > 1) {
     float* slab = p.slab + (size_t)(par * p.splits + split) * p.M * p.NslabPitch;
 #pragma unroll
@@ -283,10 +284,15 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_gemm_kernel(const
         }
       }
   } else if (p.vec_store) {
-    // stage 16 rows per wave-row at a time (bias + activation applied) as T in LDS, then coalesced 16-byte
-    // row stores: MT passes over a [WAVES_M*16][BN] staging tile
+    // stage the tile (bias + activation applied) as T in LDS, then coalesced 16-byte row stores.  The whole
+    // stage/table area is free now, so as many 16-row groups per wave-row as fit are staged per pass (one
+    // pass for bf16 tiles): IPP = largest divisor of MT whose rows fit.
     constexpr int CS = BN * (int)sizeof(T) + (sizeof(T) == 2 ? 32 : 16);
     constexpr int VPR = BN / VEC;
+    constexpr int SMEMB = NS * STAGE + 16 * BM * 4;
+    constexpr int MAXG = SMEMB / (CS * WAVES_M * 16);          // 16-row groups per wave-row that fit
+    constexpr int IPP = MAXG >= MT ? MT : (MAXG >= MT / 2 && MT % 2 == 0 ? MT / 2 : (MAXG >= MT / 4 && MT % 4 == 0 ? MT / 4 : 1));
+    static_assert(MAXG >= 1, "staging tile does not fit");
     unsigned char* Cs = smem;
     float bv[NT];
 #pragma unroll
@@ -295,17 +301,21 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_gemm_kernel(const
       bv[j] = (p.bias && n < p.Cout) ? p.bias[n] : 0.f;
     }
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      if (i) __syncthreads();
+    for (int ip = 0; ip < MT / IPP; ++ip) {
+      if (ip) __syncthreads();
 #pragma unroll
-      for (int j = 0; j < NT; ++j)
+      for (int ii = 0; ii < IPP; ++ii)
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-          st_f((T*)(Cs + (wm * 16 + q * 4 + e) * CS) + wn * WTN + j * 16 + r, apply_act(acc[i][j][e] + bv[j], p.act, p.slope));
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            st_f((T*)(Cs + ((wm * IPP + ii) * 16 + q * 4 + e) * CS) + wn * WTN + j * 16 + r,
+                 apply_act(acc[ip * IPP + ii][j][e] + bv[j], p.act, p.slope));
       __syncthreads();
-      for (int idx = tid; idx < WAVES_M * 16 * VPR; idx += NTHREADS) {
+      for (int idx = tid; idx < WAVES_M * IPP * 16 * VPR; idx += NTHREADS) {
         const int sr = idx / VPR, v = idx % VPR;
-        const int m = bm0 + (sr >> 4) * WTM + i * 16 + (sr & 15), n = bn0 + v * VEC;
+        const int g16 = sr >> 4;
+        const int m = bm0 + (g16 / IPP) * WTM + (ip * IPP + g16 % IPP) * 16 + (sr & 15), n = bn0 + v * VEC;
         if (m < p.M && n < p.Cout)
           *(uint4*)((T*)p.y + out_pixel_offset(p, m, py, px) + n) = *(const uint4*)(Cs + sr * CS + v * 16);
       }
@@ -455,8 +465,7 @@ static int launch_cfg(const GemmPlan& pl, hipStream_t st) {
   static bool attr_set = false;
   constexpr int BKB = cfg_bkb(BM, BN), NS = cfg_ns(BM, BN);
   constexpr size_t stage2 = (size_t)NS * (BM + BN) * BKB + 16 * BM * sizeof(int);   // stages + gather table
-  constexpr size_t cs = (size_t)WM * 16 * (BN * sizeof(T) + (sizeof(T) == 2 ? 32 : 16));
-  constexpr size_t smem = stage2 > cs ? stage2 : cs;
+  constexpr size_t smem = stage2;   // the epilogue staging tile is carved out of the same area
   auto kern = conv_gemm_kernel<T, BM, BN, WM, WN, BKB, NS>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);

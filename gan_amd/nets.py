@@ -301,6 +301,9 @@ class _Builder:
                           mean.data_ptr(), rstd.data_ptr(), mm, mv, BN_MOMENTUM, mask_ptr, L.ACTS[act], LEAKY_ALPHA,
                           self.ws_ptr, self.ws_bytes)
         r = self._desc(d)
+        import os
+        if os.environ.get('GAN_AMD_EXPERIMENT_SKIP_STATS'):      # timing experiment only (wrong results)
+            return [(self.lib.gan_norm_act_fwd, (r,), f"norm_act_fwd({name})")]
         return [(self.lib.gan_norm_stats, (r,), f"norm_stats({name})"),
                 (self.lib.gan_norm_act_fwd, (r,), f"norm_act_fwd({name})")]
 
