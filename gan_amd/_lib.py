@@ -30,7 +30,8 @@ class GanPrepEntry(C.Structure):
 class GanConvDesc(C.Structure):
     _fields_ = [("dtype", C.c_int32), ("stride", C.c_int32), ("x", GanTensor), ("y", GanTensor), ("w", C.c_void_p),
                 ("w_rows", C.c_int32), ("bias", C.c_void_p), ("act", C.c_int32), ("slope", C.c_float),
-                ("y_f32", C.c_int32), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
+                ("y_f32", C.c_int32), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+                ("stats_partial", C.c_void_p), ("stats_groups", C.c_int32)]
 
 
 class GanWgradDesc(C.Structure):
@@ -75,6 +76,7 @@ SYMBOLS = {
     "gan_weights_prepare": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gan_weights_prepare_multi": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "gan_norm_stats": (C.c_int, [C.POINTER(GanNormDesc), C.c_void_p]),
+    "gan_norm_stats_finalize": (C.c_int, [C.POINTER(GanNormDesc), C.c_int32, C.c_void_p]),
     "gan_norm_act_fwd": (C.c_int, [C.POINTER(GanNormDesc), C.c_void_p]),
     "gan_norm_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int64]),
     "gan_norm_act_bwd": (C.c_int, [C.POINTER(GanNormBwdDesc), C.c_void_p]),

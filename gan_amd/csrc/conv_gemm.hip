@@ -33,6 +33,7 @@ struct GemmParams {
   int tilesM, tilesN;
   int act; float slope; int out_f32; int vec_store;
   unsigned xbytes, wbytes;   // extents for the buffer descriptors (out-of-range offsets read zeros)
+  float* stats; int stats_tpg, stats_C;   // fused per-channel (sum, sum^2) partials: tiles per group, channel count
   int debug;                 // timing experiments only (GAN_AMD_GEMM_DEBUG): 1 = skip MFMA phase, 2 = skip loads
 };
 
@@ -300,6 +301,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_gemm_kernel(const
       const int n = bn0 + wn * WTN + j * 16 + r;
       bv[j] = (p.bias && n < p.Cout) ? p.bias[n] : 0.f;
     }
+    // fused normalisation statistics: per-column (sum, sum of squares) of the STORED values of this tile
+    constexpr int SL = NTHREADS / BN;                         // row slices per column (NTHREADS >= BN)
+    const int scol = tid % BN, sslice = tid / BN;
+    float ssum = 0.f, ssq = 0.f;
 #pragma unroll
     for (int ip = 0; ip < MT / IPP; ++ip) {
       if (ip) __syncthreads();
@@ -318,6 +323,28 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_gemm_kernel(const
         const int m = bm0 + (g16 / IPP) * WTM + (ip * IPP + g16 % IPP) * 16 + (sr & 15), n = bn0 + v * VEC;
         if (m < p.M && n < p.Cout)
           *(uint4*)((T*)p.y + out_pixel_offset(p, m, py, px) + n) = *(const uint4*)(Cs + sr * CS + v * 16);
+      }
+      if (p.stats && SL >= 1 && sslice < SL) {
+        for (int sr = sslice; sr < WAVES_M * IPP * 16; sr += SL) {
+          const int g16 = sr >> 4;
+          const int m = bm0 + (g16 / IPP) * WTM + (ip * IPP + g16 % IPP) * 16 + (sr & 15);
+          if (m < p.M) { const float v = ld_f((const T*)(Cs + sr * CS) + scol); ssum += v; ssq += v * v; }
+        }
+      }
+    }
+    if (p.stats) {
+      __syncthreads();
+      float* red = (float*)smem;                               // [SL][BN][2]
+      if (sslice < SL) { red[(sslice * BN + scol) * 2] = ssum; red[(sslice * BN + scol) * 2 + 1] = ssq; }
+      __syncthreads();
+      if (tid < BN && bn0 + tid < p.Cout) {
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int k = 0; k < SL; ++k) { a += red[(k * BN + tid) * 2]; b += red[(k * BN + tid) * 2 + 1]; }
+        // chunk index: (tile within its group) * P + parity; groups are whole numbers of M tiles
+        const int tm = bm0 / BM, grp = tm / p.stats_tpg, chunk = (tm % p.stats_tpg) * P + par;
+        float* dst = p.stats + (((size_t)grp * p.stats_tpg * P + chunk) * p.stats_C + bn0 + tid) * 2;
+        dst[0] = a; dst[1] = b;
       }
     }
   } else {
@@ -371,7 +398,7 @@ static int tune(const char* name, int dflt) {   // GAN_AMD_<name> overrides a pl
 
 struct GemmPlan {
   GemmParams p;
-  int BM, BN, P;
+  int BM, BN, P, stats_chunks;
   dim3 grid;
   size_t slab_bytes;
 };
@@ -452,6 +479,16 @@ static int plan_gemm(const GanConvDesc* d, int op, GemmPlan* pl) {
     if (splits > 64) splits = 64;
   }
   p.splits = splits;
+  p.stats = nullptr; p.stats_tpg = 0; p.stats_C = y.c;
+  pl->stats_chunks = 0;
+  if (d->stats_groups > 0 && splits == 1 && p.vec_store && BN <= 64 * 8 && x.n % d->stats_groups == 0) {
+    const long long rpg = M / d->stats_groups;            // GEMM rows per statistics group (per parity)
+    if (rpg % BM == 0 && (BM == 256 ? 512 : 256) >= BN) {
+      p.stats_tpg = (int)(rpg / BM);
+      pl->stats_chunks = p.stats_tpg * P;
+      p.stats = d->stats_partial;
+    }
+  }
   p.NslabPitch = tilesN * BN;
   p.tilesM = (int)tilesM; p.tilesN = tilesN;
   pl->BM = BM; pl->BN = BN;
@@ -523,13 +560,14 @@ int gan_conv2d_fwd(const GanConvDesc* d, gan_stream_t s) { return run_gemm(d, 0,
 int gan_conv2d_dgrad(const GanConvDesc* d, gan_stream_t s) { return run_gemm(d, 1, s); }
 int gan_convT2d_fwd(const GanConvDesc* d, gan_stream_t s) { return run_gemm(d, 2, s); }
 int gan_convT2d_dgrad(const GanConvDesc* d, gan_stream_t s) { return run_gemm(d, 3, s); }
-int gan_conv_plan_info(const GanConvDesc* d, int op, int32_t* info /*[4]: BM, BN, splits, parities*/) {
+int gan_conv_plan_info(const GanConvDesc* d, int op, int32_t* info /*[5]: BM, BN, splits, parities, stats chunks*/) {
   GemmPlan pl;
   GanConvDesc t = *d;
   plan_only_desc(&t);
   int rc = plan_gemm(&t, op, &pl);
   if (rc) return rc;
   info[0] = pl.BM; info[1] = pl.BN; info[2] = pl.p.splits; info[3] = pl.P;
+  info[4] = pl.stats_chunks;          // > 0: this launch can emit normalisation-statistics partials (chunks per group)
   return 0;
 }
 size_t gan_conv_workspace_bytes(const GanConvDesc* d, int op) {

@@ -357,6 +357,18 @@ int gan_norm_stats(const GanNormDesc* d, gan_stream_t stream) {
   return 0;
 }
 
+int gan_norm_stats_finalize(const GanNormDesc* d, int32_t chunks, gan_stream_t stream) {
+  if (!d || !d->y.ptr || !d->mean || !d->rstd || !d->workspace || chunks <= 0) return GAN_E_ARG;
+  RedGeom g;
+  int rc = red_geom(d->y, d->groups, d->dtype, &g);
+  if (rc) return rc;
+  hipLaunchKernelGGL(stats_finalize_kernel, dim3((g.C + FC - 1) / FC, d->moving_mean ? 1 : d->groups), dim3(256), 0, (hipStream_t)stream,
+                     (const float*)d->workspace, d->groups, chunks, g.C, g.rows_per_group, d->eps, d->mean, d->rstd,
+                     d->moving_mean, d->moving_var, d->momentum);
+  GAN_CHECK_LAUNCH();
+  return 0;
+}
+
 int gan_norm_act_fwd(const GanNormDesc* d, gan_stream_t stream) {
   if (!d || !d->y.ptr || !d->a.ptr || !d->mean || !d->rstd || !d->gamma || !d->beta) return GAN_E_ARG;
   RedGeom g;

@@ -12,6 +12,7 @@ activation are written by their producers straight into channel slices of one NH
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -255,16 +256,21 @@ class _Builder:
         self.keep.append(d)
         return C.byref(d)
 
-    def conv(self, op, x, y, w, w_rows, stride=2, bias=None, act=None, y_f32=0, k_real=None):
+    def conv(self, op, x, y, w, w_rows, stride=2, bias=None, act=None, y_f32=0, k_real=None, stats_groups=0):
+        """stats_groups > 0: ask the GEMM epilogue to also emit normalisation-statistics partials; the number of
+        chunks it will write (0 = not fusable for this shape) is left in self.last_stats_chunks."""
         d = L.GanConvDesc(self.ctx.dt, stride, x, y, w, w_rows, bias, L.ACTS[act], LEAKY_ALPHA, y_f32,
-                          self.ws_ptr, self.ws_bytes)
+                          self.ws_ptr, self.ws_bytes, self.ws_ptr if stats_groups else None, stats_groups)
         opi = {'conv_fwd': 0, 'conv_dgrad': 1, 'convT_fwd': 2, 'convT_dgrad': 3}[op]
         fn = [self.lib.gan_conv2d_fwd, self.lib.gan_conv2d_dgrad, self.lib.gan_convT2d_fwd, self.lib.gan_convT2d_dgrad][opi]
         need = self.lib.gan_conv_workspace_bytes(C.byref(d), opi)
         if need > self.ws_bytes:
             raise L.GanAmdError(f"workspace too small for {op}: need {need}")
-        info = (C.c_int32 * 4)()
+        info = (C.c_int32 * 5)()
         self.lib.gan_conv_plan_info(C.byref(d), opi, info)
+        self.last_stats_chunks = info[4] if (stats_groups and not os.environ.get('GAN_AMD_NO_FUSED_STATS')) else 0
+        if stats_groups and not self.last_stats_chunks:
+            d.stats_partial, d.stats_groups = None, 0
         T = 4 if info[3] == 4 else 16
         # algorithmic FLOPs, SURVEY.md 8(d) convention: real channel counts, border taps not discounted
         creal = k_real or x.c
@@ -290,7 +296,7 @@ class _Builder:
     def norm_names(self):
         return ('.gamma', '.beta') if self.norm == 'batchnorm' else ('.scale', '.offset')
 
-    def norm_fwd(self, name, y, a, groups, mean, rstd, act, mask_ptr, stat_groups_update=True):
+    def norm_fwd(self, name, y, a, groups, mean, rstd, act, mask_ptr, stat_groups_update=True, fused_chunks=0):
         gk, bk = self.norm_names()
         eps = BN_EPS if self.norm == 'batchnorm' else IN_EPS
         mm = mv = None
@@ -301,9 +307,9 @@ class _Builder:
                           mean.data_ptr(), rstd.data_ptr(), mm, mv, BN_MOMENTUM, mask_ptr, L.ACTS[act], LEAKY_ALPHA,
                           self.ws_ptr, self.ws_bytes)
         r = self._desc(d)
-        import os
-        if os.environ.get('GAN_AMD_EXPERIMENT_SKIP_STATS'):      # timing experiment only (wrong results)
-            return [(self.lib.gan_norm_act_fwd, (r,), f"norm_act_fwd({name})")]
+        if fused_chunks:       # the producing convolution's epilogue already wrote the partials into the workspace
+            return [(self.lib.gan_norm_stats_finalize, (r, fused_chunks), f"norm_stats_finalize({name})"),
+                    (self.lib.gan_norm_act_fwd, (r,), f"norm_act_fwd({name})")]
         return [(self.lib.gan_norm_stats, (r,), f"norm_stats({name})"),
                 (self.lib.gan_norm_act_fwd, (r,), f"norm_act_fwd({name})")]
 
@@ -392,18 +398,20 @@ class GenCall:
             if i == 0:      # conv -> LeakyReLU fused in the GEMM epilogue (apply_norm=False, base_gan.py:180)
                 fwd.append(bd.conv('conv_fwd', x, a_down(0), w.data_ptr(), G_DOWN[0], 2, None, 'lrelu', k_real=C_))
             else:
-                fwd.append(bd.conv('conv_fwd', x, self.y_down[i].view(), w.data_ptr(), G_DOWN[i], 2))
+                fwd.append(bd.conv('conv_fwd', x, self.y_down[i].view(), w.data_ptr(), G_DOWN[i], 2, stats_groups=groups))
                 mean, rstd = stat(name, G_DOWN[i])
-                fwd += bd.norm_fwd(name, self.y_down[i].view(), a_down(i), groups, mean, rstd, 'lrelu', None)
+                fwd += bd.norm_fwd(name, self.y_down[i].view(), a_down(i), groups, mean, rstd, 'lrelu', None,
+                                   fused_chunks=bd.last_stats_chunks)
             x = a_down(i)
         for j in range(7):
             name = f'up{j}'
             xin = self.a7.view() if j == 0 else self.cat[j - 1].view()
             w = P.nat[name + '.kernel']
-            fwd.append(bd.conv('convT_fwd', xin, self.y_up[j].view(), w.data_ptr(), G_UP[j], 2))
+            fwd.append(bd.conv('convT_fwd', xin, self.y_up[j].view(), w.data_ptr(), G_UP[j], 2, stats_groups=groups))
             mean, rstd = stat(name, G_UP[j])
             mptr = self.masks[j].data_ptr() if (dropout and j < 3) else None
-            fwd += bd.norm_fwd(name, self.y_up[j].view(), self.cat[j].view(0, G_UP[j]), groups, mean, rstd, 'relu', mptr)
+            fwd += bd.norm_fwd(name, self.y_up[j].view(), self.cat[j].view(0, G_UP[j]), groups, mean, rstd, 'relu', mptr,
+                               fused_chunks=bd.last_stats_chunks)
         fwd.append(bd.conv('convT_fwd', self.cat[6].view(), self.out.view(0, C_), P.nat['last.kernel'].data_ptr(), C_, 2,
                            P.ptr('last.bias'), 'tanh'))
         self.fwd_ops = fwd
@@ -566,9 +574,11 @@ class DiscCall:
         fwd = [bd.conv('conv_fwd', self.xin.view(), self.a0.view(), P.tr['down0.kernel'].data_ptr(), 64, 2, None, 'lrelu', k_real=net.cin)]
         prev = self.a0
         for name, co, stride in self.LAYERS[1:4]:
-            fwd.append(bd.conv('conv_fwd', prev.view(), self.y[name].view(), P.tr[name + '.kernel'].data_ptr(), co, stride))
+            fwd.append(bd.conv('conv_fwd', prev.view(), self.y[name].view(), P.tr[name + '.kernel'].data_ptr(), co, stride,
+                               stats_groups=groups))
             mean, rstd = self.stats[name]
-            fwd += bd.norm_fwd(name, self.y[name].view(), self.a[name].view(), groups, mean, rstd, 'lrelu', None)
+            fwd += bd.norm_fwd(name, self.y[name].view(), self.a[name].view(), groups, mean, rstd, 'lrelu', None,
+                               fused_chunks=bd.last_stats_chunks)
             prev = self.a[name]
         fwd.append(bd.conv('conv_fwd', prev.view(), self.logits.view(), P.tr['last.kernel'].data_ptr(), 1, 1,
                            P.ptr('last.bias'), None, 1))

@@ -52,6 +52,8 @@ typedef struct GanConvDesc {
   int32_t y_f32;         /* 1: write y as fp32 whatever dtype is (used for logits) */
   void* workspace;       /* split-K slabs; size from gan_conv_workspace_bytes() */
   size_t workspace_bytes;
+  float* stats_partial;  /* optional: fused normalisation statistics — per-tile (sum, sum^2) partials of y,   */
+  int32_t stats_groups;  /* laid out [group][chunk][y.c][2]; emitted only if gan_conv_plan_info()[4] > 0     */
 } GanConvDesc;
 
 /* Conv2D(k4, strides=s, no bias | bias) — base_gan.py:77-79 ('same', s=2), :145-148 and :157-161
@@ -67,7 +69,7 @@ int gan_convT2d_fwd(const GanConvDesc* d, gan_stream_t stream);
  * w = transposed NK copy ([tap][cin][cout]). */
 int gan_convT2d_dgrad(const GanConvDesc* d, gan_stream_t stream);
 size_t gan_conv_workspace_bytes(const GanConvDesc* d, int op /*0 conv_fwd,1 conv_dgrad,2 convT_fwd,3 convT_dgrad*/);
-/* launch plan the library picks for this problem (profiling / bench bookkeeping): info = {BM, BN, splitK, parities} */
+/* launch plan the library picks for this problem: info[5] = {BM, BN, splitK, parities, fused-stats chunks per group} */
 int gan_conv_plan_info(const GanConvDesc* d, int op, int32_t* info);
 
 typedef struct GanWgradDesc {
@@ -124,6 +126,8 @@ typedef struct GanNormDesc {
   size_t workspace_bytes;
 } GanNormDesc;
 int gan_norm_stats(const GanNormDesc* d, gan_stream_t stream);
+/* finalize only: d->workspace already holds `chunks` partials per group written by a convolution epilogue */
+int gan_norm_stats_finalize(const GanNormDesc* d, int32_t chunks, gan_stream_t stream);
 int gan_norm_act_fwd(const GanNormDesc* d, gan_stream_t stream);
 size_t gan_norm_workspace_bytes(int32_t groups, int32_t c, int64_t rows_per_group);
 
