@@ -49,17 +49,19 @@ def gemm_profile(step, inputs, reps=5):
                 recs.setdefault(meta['kernel'], []).append((e0, e1, meta['flops']))
             if rc:
                 raise RuntimeError(f"{op[2]} failed rc={rc}")
-    step._run(*inputs, training=True)          # untimed eager pass (first eager launches pay one-time costs)
-    torch.cuda.synchronize()
-    ctx.run = timed_run
     ms_saved, ctx.ms_mode, ctx.multistream = ctx.ms_mode, 0, False   # instrumented passes: every launch on one stream
+    sync_saved, step.sync = step.sync, None    # rank-local measurement: no collectives (the other ranks are not here)
     try:
+        step._run(*inputs, training=True)      # untimed eager pass (first eager launches pay one-time costs)
+        torch.cuda.synchronize()
+        ctx.run = timed_run
         for _ in range(reps):
             step._run(*inputs, training=True)
         torch.cuda.synchronize()
     finally:
         ctx.run = orig_run
         ctx.ms_mode, ctx.multistream = ms_saved, ms_saved == 2
+        step.sync = sync_saved
     out = {}
     for k, lst in recs.items():
         n = len(lst) // reps                   # launches of this kernel per step
@@ -112,10 +114,15 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    local = local % max(1, torch.cuda.device_count())        # (rehearsals with several ranks on one GPU)
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local)
-        dist.init_process_group('nccl', device_id=torch.device(f'cuda:{local}'))
+        backend = os.environ.get('GAN_AMD_DIST_BACKEND', 'nccl')     # "nccl" is RCCL on ROCm; gloo only for rehearsals
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device(f'cuda:{local}'))
+        else:
+            dist.init_process_group(backend)
     if args.gpus != world and rank == 0 and world > 1:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
 
