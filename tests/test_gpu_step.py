@@ -283,3 +283,29 @@ def test_ddp_two_ranks_equal_sharded_single_process():
         acc = g if acc is None else acc + g
     ref = acc / 2
     assert np.abs(res[0][1] - ref).max() <= 1e-5 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("size,channels,batch", [(256, 3, 2), (512, 1, 1)])
+def test_pix2pix_other_configs_f32(size, channels, batch):
+    """RGB (D sees 6 input channels, 3-channel tanh head) and 512x512 (2x2 bottleneck) against the oracle."""
+    from gan_amd.nets import Ctx
+    from gan_amd.steps import Pix2PixStep
+    ctx = Ctx('cuda:0', 'f32')
+    st = Pix2PixStep(ctx, batch, size, channels, lam=100.0, seed=123)
+    Gp, Dp = O.init_generator(channels, seed=31), O.init_discriminator(channels, True, seed=32)
+    st.G.params.load_numpy(Gp); st.D.params.load_numpy(Dp)
+    inp, tar = O.synthetic_pair(batch, size, channels, seed=77)
+    masks = O.dropout_masks(batch, size, seed=8)
+    st.g.set_dropmasks(masks)
+    ref = O.pix2pix_train_step(Gp, Dp, O.AdamTF(), O.AdamTF(), inp, tar, 100.0, masks, True, return_grads=True)
+    losses = st.train_step(torch.from_numpy(inp).to(ctx.device), torch.from_numpy(tar).to(ctx.device), True).cpu().numpy()
+    gen = st.g.output_f32().cpu().numpy()
+    err = float(np.abs(gen - ref[4]).max())
+    print(f"[{size}px C={channels} B={batch}] gen max-abs err {err:.3e}; losses {losses}")
+    assert gen.shape == (batch, size, size, channels)
+    assert err < 1e-3 and np.allclose(losses, np.array(ref[:4], np.float64), rtol=1e-3)
+    got = st.G.params.to_numpy('grad')
+    for k in ('last.kernel', 'down0.kernel', 'up3.kernel'):
+        assert cosine(got[k], ref[5][k]) > 0.999, k
+    gd = st.D.params.to_numpy('grad')
+    assert cosine(gd['down0.kernel'], ref[6]['down0.kernel']) > 0.999
