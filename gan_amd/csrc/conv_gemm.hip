@@ -34,6 +34,7 @@ struct GemmParams {
   int act; float slope; int out_f32; int vec_store;
   unsigned xbytes, wbytes;   // extents for the buffer descriptors (out-of-range offsets read zeros)
   float* stats; int stats_tpg, stats_C;   // fused per-channel (sum, sum^2) partials: tiles per group, channel count
+  FastDiv divWg, divHg;      // GEMM-grid width / height (row -> (image, gy, gx) decode)
   int debug;                 // timing experiments only (GAN_AMD_GEMM_DEBUG): 1 = skip MFMA phase, 2 = skip loads
 };
 
@@ -63,10 +64,10 @@ __device__ __forceinline__ void store_out(const GemmParams& p, size_t pix_off, i
 }
 
 __device__ __forceinline__ size_t out_pixel_offset(const GemmParams& p, int m, int py, int px) {
-  int gx = m % p.Wg;
-  int t = m / p.Wg;
-  int gy = t % p.Hg;
-  int img = t / p.Hg;
+  const unsigned t = fdiv((unsigned)m, p.divWg);
+  const int gx = m - t * p.Wg;
+  const unsigned img = fdiv(t, p.divHg);
+  const int gy = t - img * p.Hg;
   return ((size_t)(img * p.Ho + gy * p.OS + py) * p.Wo + (gx * p.OS + px)) * (size_t)p.ypitch;
 }
 
@@ -444,6 +445,7 @@ static int plan_gemm(const GanConvDesc* d, int op, GemmPlan* pl) {
   long long M = (long long)x.n * p.Hg * p.Wg;
   if (M <= 0 || M > 0x7fffffffLL) return GAN_E_SHAPE;
   p.M = (int)M;
+  p.divWg = make_fastdiv((uint32_t)p.Wg); p.divHg = make_fastdiv((uint32_t)p.Hg);
   const long long Kbytes = (long long)p.T * x.c * (d->dtype == GAN_F32 ? 4 : 2);
   if (Kbytes % 128) return GAN_E_SHAPE;
   const int P = parity ? 4 : 1;
