@@ -52,7 +52,7 @@ class Ctx:
         # 0: everything on one stream; 1: one fork/join per step (deferred generator wgrads beside the
         # discriminator's parameter pass); 2: per-op wgrad side stream + second chain
         import os
-        self.ms_mode = int(os.environ.get('GAN_AMD_MS', '3'))
+        self.ms_mode = int(os.environ.get('GAN_AMD_MS', '4'))
         self.multistream = self.ms_mode == 2
 
     def stream(self):
