@@ -19,24 +19,7 @@
 // slabs + a reduce kernel.  Block ids are remapped so that each XCD (own L2) works on a contiguous range
 // of M tiles and all their N tiles.
 #include "common.h"
-
-struct GemmParams {
-  const void* x; const void* w; void* y; float* slab; const float* bias;
-  int Nimg, Hs, Ws, xpitch, Cin, log2_cvecs;
-  int Hg, Wg, M;
-  int S, TWlog2, T, log2T;
-  int dy0, dx0, dstep, wy0, wx0, wstep;
-  int parity;
-  int Wrows;
-  int Ho, Wo, ypitch, Cout, OS;
-  int splits, kchunks, NslabPitch;
-  int tilesM, tilesN;
-  int act; float slope; int out_f32; int vec_store;
-  unsigned xbytes, wbytes;   // extents for the buffer descriptors (out-of-range offsets read zeros)
-  float* stats; int stats_tpg, stats_C;   // fused per-channel (sum, sum^2) partials: tiles per group, channel count
-  FastDiv divWg, divHg;      // GEMM-grid width / height (row -> (image, gy, gx) decode)
-  int debug;                 // timing experiments only (GAN_AMD_GEMM_DEBUG): 1 = skip MFMA phase, 2 = skip loads
-};
+#include "conv_params.h"
 
 __device__ uint4 g_zero_page[8];   // 128 B of zeros: source of padding taps / out-of-range rows
 
@@ -472,8 +455,10 @@ static int plan_gemm(const GanConvDesc* d, int op, GemmPlan* pl) {
   long long tilesM = (M + BM - 1) / BM;
   long long blocks = tilesM * tilesN * P;
   int splits = 1;
-  static const int t_small = tune("CONV_TARGET", 512), t_skinny = tune("SKINNY_TARGET", 1024);
-  const long long target = BM == 256 ? 128 : (BN == 16 ? t_skinny : t_small);   // BN=16: streaming layers want more, shorter blocks
+  static const int t_small = tune("CONV_TARGET", 512), t_skinny = tune("SKINNY_TARGET", 1024), t_big = tune("BIG_TARGET", 256);
+  // 256-row tiles: a half-full chip (128..255 blocks) is worth a 2-way K split only when K is long enough
+  // to amortise the fp32 slab round trip (measured: K>=4096 +25..40 %, K=2048 neutral)
+  const long long target = BM == 256 ? (p.kchunks >= 48 ? t_big : 128) : (BN == 16 ? t_skinny : t_small);   // BN=16: streaming layers want more, shorter blocks
   if (blocks < target) {
     splits = (int)((target + blocks - 1) / blocks);
     int maxs = p.kchunks / 4; if (maxs < 1) maxs = 1;
@@ -546,8 +531,9 @@ static int run_gemm(const GanConvDesc* d, int op, gan_stream_t stream) {
   GemmPlan pl;
   int rc = plan_gemm(d, op, &pl);
   if (rc) return rc;
-  if (pl.slab_bytes > d->workspace_bytes || (pl.slab_bytes && !d->workspace)) return GAN_E_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
+  if (const int fam = thin_family(d, op, pl.p)) return thin_launch(fam, d, pl.p, st);   // <= 8-channel streaming layers
+  if (pl.slab_bytes > d->workspace_bytes || (pl.slab_bytes && !d->workspace)) return GAN_E_WORKSPACE;
   return d->dtype == GAN_F32 ? launch_gemm<float>(pl, st) : launch_gemm<bf16_t>(pl, st);
 }
 
@@ -570,6 +556,7 @@ int gan_conv_plan_info(const GanConvDesc* d, int op, int32_t* info /*[5]: BM, BN
   if (rc) return rc;
   info[0] = pl.BM; info[1] = pl.BN; info[2] = pl.p.splits; info[3] = pl.P;
   info[4] = pl.stats_chunks;          // > 0: this launch can emit normalisation-statistics partials (chunks per group)
+  if (const int fam = thin_family(&t, op, pl.p)) { info[0] = 0; info[1] = fam; info[2] = 1; info[4] = 0; }   // thin.hip kernels
   return 0;
 }
 size_t gan_conv_workspace_bytes(const GanConvDesc* d, int op) {
@@ -577,6 +564,7 @@ size_t gan_conv_workspace_bytes(const GanConvDesc* d, int op) {
   GanConvDesc t = *d;
   plan_only_desc(&t);
   if (plan_gemm(&t, op, &pl)) return 0;
+  if (const int fam = thin_family(&t, op, pl.p)) return thin_workspace_bytes(fam, &t, pl.p);
   return pl.slab_bytes;
 }
 }

@@ -1,0 +1,27 @@
+// Launch parameters of the convolution kernels (conv_gemm.hip plans them; thin.hip reuses the geometry).
+#pragma once
+#include "common.h"
+
+struct GemmParams {
+  const void* x; const void* w; void* y; float* slab; const float* bias;
+  int Nimg, Hs, Ws, xpitch, Cin, log2_cvecs;
+  int Hg, Wg, M;
+  int S, TWlog2, T, log2T;
+  int dy0, dx0, dstep, wy0, wx0, wstep;
+  int parity;
+  int Wrows;
+  int Ho, Wo, ypitch, Cout, OS;
+  int splits, kchunks, NslabPitch;
+  int tilesM, tilesN;
+  int act; float slope; int out_f32; int vec_store;
+  unsigned xbytes, wbytes;   // extents for the buffer descriptors (out-of-range offsets read zeros)
+  float* stats; int stats_tpg, stats_C;   // fused per-channel (sum, sum^2) partials: tiles per group, channel count
+  FastDiv divWg, divHg;      // GEMM-grid width / height (row -> (image, gy, gx) decode)
+  int debug;                 // timing experiments only (GAN_AMD_GEMM_DEBUG): 1 = skip MFMA phase, 2 = skip loads
+};
+
+// thin.hip: streaming kernels for the layers with <= 8 channels on one side (HBM-bound, no LDS tiling).
+// thin_family(): 0 = use the tiled implicit GEMM, 1 = "thin-N" (few output channels), 2 = "thin-K" (8-channel input)
+int thin_family(const GanConvDesc* d, int op, const GemmParams& p);
+size_t thin_workspace_bytes(int family, const GanConvDesc* d, const GemmParams& p);
+int thin_launch(int family, const GanConvDesc* d, const GemmParams& p, hipStream_t st);

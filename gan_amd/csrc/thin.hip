@@ -1,0 +1,249 @@
+// Streaming convolution kernels for the layers that have <= 8 channels on one side (bf16 path).
+//
+// The U-Net's first/last layers and the PatchGAN's first/last layers (base_gan.py:141-166, :176-204) move
+// 50-100 MB of activations for a few GFLOP: they are HBM-bound, and the LDS-tiled implicit GEMM spends its
+// time staging each thick pixel 16 times.  Two formulations read/write the thick tensor exactly once:
+//
+//  * thin-K (8-channel input -> thick output; Conv2D of the image, dgrad of the tanh head, dgrad of the
+//    logits layer): the 4x4x8 im2col patch of a pixel is gathered straight into MFMA operand registers
+//    (one 16-byte load per tap), the weights live in registers for the whole kernel, and the accumulators
+//    are stored as whole 16-byte channel vectors.  No LDS at all.
+//  * thin-N (thick input -> <= 6 output channels; tanh head, logits layer, dgrad into the image): the
+//    convolution is split into Z[pixel][c][tap] = x[pixel,:] . W[tap][c][:]  (a plain streaming GEMM, x read
+//    once, 16 taps = one MFMA tile) followed by a col2im gather of Z (a few MB, cache resident) with bias
+//    and activation fused.
+//
+// Both keep the tap / padding / parity conventions of conv_gemm.hip (GemmParams), so they are drop-in
+// replacements selected by thin_family(); the fp32 parity path always uses the tiled kernel.
+#include "common.h"
+#include "conv_params.h"
+#include <stdlib.h>
+
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+
+__device__ __forceinline__ f32x4 mfma_bf16(const uint4& a, const uint4& b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&a, *(const bf16x8*)&b, c, 0, 0, 0);
+}
+
+// ------------------------------------------------------------------------------------------------
+// thin-K: Y[pixel, co] = act(bias + sum_{tap, c<8} X[src(pixel, tap), c] * W[tap][co][c])
+// MFMA roles: A = weights (16 output channels x K), B = im2col patch (K x 16 pixels), K = 16 taps x 8.
+// A wave owns 64 output channels (blockIdx.y) and walks 16-pixel tiles.  The 16 A rows of an MFMA pair are
+// mapped to channels so that a lane ends up with 8 consecutive channels of its pixel: one 16-byte store.
+struct ThinKParams {
+  const bf16_t* x; const bf16_t* w; bf16_t* y; const float* bias;
+  int Hs, Ws, xpitch, Hg, Wg, M, S, dy0, dstep, Wrows, ypitch, act, tiles;
+  float slope;
+  FastDiv divWg, divHg;
+};
+
+__global__ __launch_bounds__(256) void conv_thin_k_kernel(const ThinKParams p) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = lane & 15, q = lane >> 4;
+  const int cbase = blockIdx.y * 64;
+  uint4 wf[4][4];          // [channel tile][k step = tap row]
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct) {
+    const int ch = cbase + (ct >> 1) * 32 + (n >> 2) * 8 + (ct & 1) * 4 + (n & 3);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) wf[ct][s] = *(const uint4*)(p.w + ((size_t)(s * 4 + q) * p.Wrows + ch) * 8);
+  }
+  float bv[2][8];
+#pragma unroll
+  for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) bv[pr][i] = p.bias ? p.bias[cbase + pr * 32 + q * 8 + i] : 0.f;
+
+  for (int tile = blockIdx.x * 4 + wave; tile < p.tiles; tile += gridDim.x * 4) {
+    const int m = tile * 16 + n;
+    const unsigned t = fdiv((unsigned)m, p.divWg);
+    const int gx = m - (int)t * p.Wg;
+    const unsigned img = fdiv(t, p.divHg);
+    const int gy = (int)t - (int)img * p.Hg;
+    const bool rowok = m < p.M;
+    const int sx = gx * p.S + p.dy0 + q * p.dstep;       // dx0 == dy0 for every supported op
+    uint4 xf[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int sy = gy * p.S + p.dy0 + s * p.dstep;
+      xf[s] = make_uint4(0, 0, 0, 0);
+      if (rowok && (unsigned)sy < (unsigned)p.Hs && (unsigned)sx < (unsigned)p.Ws)
+        xf[s] = *(const uint4*)(p.x + ((size_t)(img * p.Hs + sy) * p.Ws + sx) * p.xpitch);
+    }
+    f32x4 acc[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+      acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < 4; ++s) acc[ct] = mfma_bf16(wf[ct][s], xf[s], acc[ct]);
+    }
+    if (rowok) {
+      bf16_t* yp = p.y + ((size_t)(img * p.Hg + gy) * p.Wg + gx) * p.ypitch + cbase + q * 8;
+#pragma unroll
+      for (int pr = 0; pr < 2; ++pr) {
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          v[i] = apply_act(acc[2 * pr][i] + bv[pr][i], p.act, p.slope);
+          v[4 + i] = apply_act(acc[2 * pr + 1][i] + bv[pr][4 + i], p.act, p.slope);
+        }
+        *(uint4*)(yp + pr * 32) = pack16<bf16_t>(v);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// thin-N step 1: Z[pixel][c][tap] = sum_ci X[pixel, ci] * W[tap][c][ci]   (fp32 Z, taps = the MFMA's 16 rows)
+// Weight fragments sit in LDS in operand order (CO * KS KiB); x is read once with 16-byte loads.
+struct ThinNParams {
+  const bf16_t* x; const bf16_t* w; float* z;
+  int Mx, xpitch, Cin, Wrows, CO, tiles;
+};
+
+template <int KS>      // Cin = 32 * KS
+__global__ __launch_bounds__(256) void conv_thin_n_kernel(const ThinNParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint4* wl = (uint4*)smem;                                // [c][s][lane]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = lane & 15, q = lane >> 4;
+  for (int e = threadIdx.x; e < p.CO * KS * 64; e += 256) {
+    const int l = e & 63, s = (e >> 6) % KS, c = (e >> 6) / KS;
+    wl[e] = *(const uint4*)(p.w + ((size_t)(l & 15) * p.Wrows + c) * p.Cin + s * 32 + (l >> 4) * 8);
+  }
+  __syncthreads();
+  for (int tile = blockIdx.x * 4 + wave; tile < p.tiles; tile += gridDim.x * 4) {
+    const int pix = tile * 16 + n;
+    const bool ok = pix < p.Mx;
+    uint4 xf[KS];
+    const bf16_t* xp = p.x + (size_t)pix * p.xpitch + q * 8;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) xf[s] = ok ? *(const uint4*)(xp + s * 32) : make_uint4(0, 0, 0, 0);
+    for (int c = 0; c < p.CO; ++c) {
+      f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < KS; ++s) acc = mfma_bf16(wl[(c * KS + s) * 64 + lane], xf[s], acc);
+      if (ok) *(f32x4*)(p.z + ((size_t)pix * p.CO + c) * 16 + q * 4) = acc;
+    }
+  }
+}
+
+// thin-N step 2: Y[out pixel, c] = act(bias[c] + sum over the valid taps of Z[src pixel][c][tap])
+struct Col2imParams {
+  const float* z; void* y; const float* bias;
+  int Hs, Ws, Ho, Wo, CO, ypitch, out_f32, act, parity, S, dy0, dstep;
+  float slope;
+  long long total;
+  FastDiv divWo, divHo;
+};
+
+__global__ __launch_bounds__(256) void conv_thin_col2im_kernel(const Col2imParams p) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= p.total) return;
+  const unsigned t = fdiv((unsigned)idx, p.divWo);
+  const int X = (int)idx - (int)t * p.Wo;
+  const unsigned img = fdiv(t, p.divHo);
+  const int Y = (int)t - (int)img * p.Ho;
+  int iy[4], ky[4], ix[4], kx[4], ny, nx;
+  if (p.parity) {          // y[2g+py] = sum_ty x[g + py - ty] * w[1 - py + 2 ty]   (conv_gemm.hip parity taps)
+    ny = nx = 2;
+    const int py = Y & 1, gy = Y >> 1, px = X & 1, gx = X >> 1;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      iy[a] = gy + py - a; ky[a] = 1 - py + 2 * a;
+      ix[a] = gx + px - a; kx[a] = 1 - px + 2 * a;
+    }
+  } else {                 // y[g] = sum_t x[g*S + dy0 + t*dstep] * w[t]
+    ny = nx = 4;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      iy[a] = Y * p.S + p.dy0 + a * p.dstep; ky[a] = a;
+      ix[a] = X * p.S + p.dy0 + a * p.dstep; kx[a] = a;
+    }
+  }
+  float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int a = 0; a < ny; ++a) {
+    if ((unsigned)iy[a] >= (unsigned)p.Hs) continue;
+    for (int b = 0; b < nx; ++b) {
+      if ((unsigned)ix[b] >= (unsigned)p.Ws) continue;
+      const float* zp = p.z + ((size_t)(img * p.Hs + iy[a]) * p.Ws + ix[b]) * p.CO * 16 + ky[a] * 4 + kx[b];
+#pragma unroll
+      for (int c = 0; c < 6; ++c)
+        if (c < p.CO) acc[c] += zp[c * 16];
+    }
+  }
+  const size_t o = ((size_t)(img * p.Ho + Y) * p.Wo + X) * p.ypitch;
+#pragma unroll
+  for (int c = 0; c < 6; ++c) {
+    if (c >= p.CO) break;
+    float v = acc[c] + (p.bias ? p.bias[c] : 0.f);
+    v = apply_act(v, p.act, p.slope);
+    if (p.out_f32) ((float*)p.y)[o + c] = v;
+    else ((bf16_t*)p.y)[o + c] = (bf16_t)v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+int thin_family(const GanConvDesc* d, int op, const GemmParams& p) {
+  static int off = -1;
+  if (off < 0) { const char* e = getenv("GAN_AMD_NO_THIN"); off = e ? atoi(e) : 0; }
+  if (off == 1 || d->dtype != GAN_BF16) return 0;
+  const GanTensor &x = d->x, &y = d->y;
+  // thin-N: few output channels.  Z needs one MFMA tile per output channel; weights CO*KS KiB of LDS.
+  if (!(off & 2) && y.c <= 6 && (x.c == 64 || x.c == 128 || x.c == 512) && (x.c / 32) * y.c <= 48 &&
+      x.pitch % 8 == 0 && ((uintptr_t)x.ptr & 15) == 0 && (p.parity || (p.dstep == 1 && p.dy0 == -1)))
+    return 1;
+  // thin-K: one 16-byte vector per input pixel, output channels in 64-wide groups, 16-byte stores
+  if (!(off & 4) && !p.parity && x.c == 8 && x.pitch % 8 == 0 && y.c % 64 == 0 && !d->y_f32 && p.vec_store &&
+      d->w_rows >= y.c && p.dx0 == p.dy0)
+    return 2;
+  return 0;
+}
+
+size_t thin_workspace_bytes(int family, const GanConvDesc* d, const GemmParams& p) {
+  if (family != 1) return 0;
+  return (size_t)d->x.n * d->x.h * d->x.w * d->y.c * 16 * sizeof(float);
+}
+
+int thin_launch(int family, const GanConvDesc* d, const GemmParams& p, hipStream_t st) {
+  const GanTensor &x = d->x, &y = d->y;
+  if (family == 2) {
+    ThinKParams k;
+    k.x = (const bf16_t*)p.x; k.w = (const bf16_t*)p.w; k.y = (bf16_t*)p.y; k.bias = p.bias;
+    k.Hs = p.Hs; k.Ws = p.Ws; k.xpitch = p.xpitch; k.Hg = p.Hg; k.Wg = p.Wg; k.M = p.M; k.S = p.S;
+    k.dy0 = p.dy0; k.dstep = p.dstep; k.Wrows = p.Wrows; k.ypitch = p.ypitch; k.act = p.act; k.slope = p.slope;
+    k.tiles = (p.M + 15) / 16;
+    k.divWg = p.divWg; k.divHg = p.divHg;
+    const int groups = y.c / 64;
+    int gx = (k.tiles + 3) / 4;
+    const int cap = 2048 / groups > 256 ? 2048 / groups : 256;
+    if (gx > cap) gx = cap;
+    hipLaunchKernelGGL(conv_thin_k_kernel, dim3((unsigned)gx, (unsigned)groups), dim3(256), 0, st, k);
+    GAN_CHECK_LAUNCH();
+    return 0;
+  }
+  if (family != 1) return GAN_E_ARG;
+  const size_t zbytes = thin_workspace_bytes(1, d, p);
+  if (!d->workspace || d->workspace_bytes < zbytes) return GAN_E_WORKSPACE;
+  ThinNParams n;
+  n.x = (const bf16_t*)p.x; n.w = (const bf16_t*)p.w; n.z = (float*)d->workspace;
+  n.Mx = x.n * x.h * x.w; n.xpitch = p.xpitch; n.Cin = x.c; n.Wrows = p.Wrows; n.CO = y.c;
+  n.tiles = (n.Mx + 15) / 16;
+  const int KS = x.c / 32;
+  int gx = (n.tiles + 3) / 4;
+  if (gx > 2048) gx = 2048;
+  const size_t smem = (size_t)n.CO * KS * 1024;
+  if (KS == 2) hipLaunchKernelGGL(conv_thin_n_kernel<2>, dim3((unsigned)gx), dim3(256), smem, st, n);
+  else if (KS == 4) hipLaunchKernelGGL(conv_thin_n_kernel<4>, dim3((unsigned)gx), dim3(256), smem, st, n);
+  else hipLaunchKernelGGL(conv_thin_n_kernel<16>, dim3((unsigned)gx), dim3(256), smem, st, n);
+  GAN_CHECK_LAUNCH();
+  Col2imParams c;
+  c.z = n.z; c.y = p.y; c.bias = p.bias;
+  c.Hs = p.Hs; c.Ws = p.Ws; c.Ho = p.Ho; c.Wo = p.Wo; c.CO = y.c; c.ypitch = p.ypitch; c.out_f32 = p.out_f32;
+  c.act = p.act; c.parity = p.parity; c.S = p.S; c.dy0 = p.dy0; c.dstep = p.dstep; c.slope = p.slope;
+  c.total = (long long)x.n * p.Ho * p.Wo;
+  c.divWo = make_fastdiv((uint32_t)p.Wo); c.divHo = make_fastdiv((uint32_t)p.Ho);
+  hipLaunchKernelGGL(conv_thin_col2im_kernel, dim3((unsigned)((c.total + 255) / 256)), dim3(256), 0, st, c);
+  GAN_CHECK_LAUNCH();
+  return 0;
+}

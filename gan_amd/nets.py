@@ -276,7 +276,9 @@ class _Builder:
         creal = k_real or x.c
         M = x.n * (x.h * x.w if info[3] == 4 else y.h * y.w)
         flops = 2.0 * M * info[3] * T * y.c * creal
-        meta = dict(kind='gemm', kernel=f"conv_gemm<{self.ctx.dtype},{info[0]},{info[1]}>", flops=flops, splits=info[2],
+        kname = (f"conv_gemm<{self.ctx.dtype},{info[0]},{info[1]}>" if info[0] else
+                 f"conv_thin_{'n' if info[1] == 1 else 'k'}<{self.ctx.dtype}>")        # csrc/thin.hip streaming kernels
+        meta = dict(kind='gemm', kernel=kname, flops=flops, splits=info[2],
                     shape=f"{op} M{M}{'x4' if info[3] == 4 else ''} N{y.c} K{T * x.c} s{info[2]}")
         return (fn, (self._desc(d),), op, meta)
 

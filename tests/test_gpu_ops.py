@@ -81,6 +81,9 @@ CONV_CASES = [  # (N, H, Cin, Cout, stride)
     (8, 128, 64, 256, 2),   # M = 32768, N = 256: 256x256 tile (8 waves)
     (8, 128, 64, 128, 2),   # M = 32768, N = 128: 256x128 tile
     (5, 100, 64, 128, 2),   # M = 12500: ragged last tile
+    (3, 18, 3, 64, 2),      # thin-K streaming kernel, M = 243 (ragged 16-pixel tiles), C = 3
+    (3, 18, 2, 128, 2),     # thin-K with two 64-channel groups; dgrad into 2 channels (thin-N, parity form)
+    (1, 13, 512, 3, 1),     # thin-N, stride 1, three output channels, ragged
 ]
 
 
@@ -137,7 +140,25 @@ CONVT_CASES = [  # (N, h, Cin, Cout)
     (2, 32, 128, 1),        # head: Cout = 1, bias + tanh
     (1, 16, 128, 3),        # head, 3 channels
     (4, 64, 128, 128),      # M = 16384 x 4 parities: 256x128 tile
+    (3, 5, 128, 2),         # thin-N head, ragged pixel tiles
 ]
+
+
+def test_thin_layers_take_streaming_kernels():
+    """The <= 8-channel layers of the bf16 path must run on csrc/thin.hip (plan info: BM = 0, BN = family)."""
+    from gan_amd import _lib as L
+    from gan_amd.nets import Ctx, Buf
+    c = Ctx('cuda:0', 'bf16')
+    info = (C.c_int32 * 5)()
+    x8, y64, x128, y1 = Buf(c, 2, 32, 32, 8), Buf(c, 2, 16, 16, 64), Buf(c, 2, 16, 16, 128), Buf(c, 2, 32, 32, 8)
+    d = L.GanConvDesc(c.dt, 2, x8.view(), y64.view(), 16, 64, None, 0, 0.3, 0, c.ws_ptr, c.ws_bytes)
+    assert c.lib.gan_conv_plan_info(C.byref(d), 0, info) == 0 and (info[0], info[1]) == (0, 2)
+    d = L.GanConvDesc(c.dt, 2, x128.view(), y1.view(0, 1), 16, 1, None, 0, 0.3, 0, c.ws_ptr, c.ws_bytes)
+    assert c.lib.gan_conv_plan_info(C.byref(d), 2, info) == 0 and (info[0], info[1]) == (0, 1)
+    assert c.lib.gan_conv_workspace_bytes(C.byref(d), 2) == 2 * 16 * 16 * 16 * 4
+    c32 = Ctx('cuda:0', 'f32')
+    d = L.GanConvDesc(c32.dt, 2, x8.view(), y64.view(), 16, 64, None, 0, 0.3, 0, c.ws_ptr, c.ws_bytes)
+    assert c32.lib.gan_conv_plan_info(C.byref(d), 0, info) == 0 and info[0] > 0      # fp32 parity path: tiled kernel
 
 
 @pytest.mark.parametrize("case", CONVT_CASES)

@@ -21,7 +21,7 @@ elif op == 'convT_fwd':
 x.t.copy_(torch.randn_like(x.t.float()).to(ctx.tdtype))
 d = L.GanConvDesc(ctx.dt, s, x.view(), y.view(), w.data_ptr(), rows, None, 0, 0.3, 0, ctx.ws_ptr, ctx.ws_bytes)
 fn = {'conv_fwd': ctx.lib.gan_conv2d_fwd, 'convT_fwd': ctx.lib.gan_convT2d_fwd}[op]
-info = (C.c_int32 * 4)()
+info = (C.c_int32 * 5)()
 ctx.lib.gan_conv_plan_info(C.byref(d), {'conv_fwd': 0, 'convT_fwd': 2}[op], info)
 for _ in range(3):
     assert fn(C.byref(d), ctx.stream()) == 0
