@@ -456,9 +456,9 @@ static int plan_gemm(const GanConvDesc* d, int op, GemmPlan* pl) {
   long long blocks = tilesM * tilesN * P;
   int splits = 1;
   static const int t_small = tune("CONV_TARGET", 512), t_skinny = tune("SKINNY_TARGET", 1024), t_big = tune("BIG_TARGET", 256);
-  // 256-row tiles: a half-full chip (128..255 blocks) is worth a 2-way K split only when K is long enough
+  // 256-row tiles: a half-full chip (128..160 blocks) is worth a 2-way K split only when K is long enough
   // to amortise the fp32 slab round trip (measured: K>=4096 +25..40 %, K=2048 neutral)
-  const long long target = BM == 256 ? (p.kchunks >= 48 ? t_big : 128) : (BN == 16 ? t_skinny : t_small);   // BN=16: streaming layers want more, shorter blocks
+  const long long target = BM == 256 ? (p.kchunks >= 48 && blocks <= 160 ? t_big : 128) : (BN == 16 ? t_skinny : t_small);   // BN=16: streaming layers want more, shorter blocks
   if (blocks < target) {
     splits = (int)((target + blocks - 1) / blocks);
     int maxs = p.kchunks / 4; if (maxs < 1) maxs = 1;

@@ -144,6 +144,37 @@ CONVT_CASES = [  # (N, h, Cin, Cout)
 ]
 
 
+@pytest.mark.parametrize("case", [('conv_fwd', 8, 128, 64, 128, 1), ('conv_fwd', 8, 128, 64, 128, 2), ('convT_fwd', 2, 64, 128, 128, 1),
+                                  ('convT_fwd', 4, 64, 128, 128, 4)])
+def test_conv_epilogue_statistics_partials(ctx, case):
+    """Fused normalisation statistics (GanConvDesc.stats_partial): per-channel (sum, sum of squares) of the STORED
+    output, summed over the chunks the plan reports, per statistics group."""
+    from gan_amd import _lib as L
+    from gan_amd.nets import Buf
+    op, N, H, ci, co, groups = case
+    rng = np.random.default_rng(7)
+    x = q(ctx, rng.standard_normal((N, H, H, ci)))
+    w = q(ctx, 0.05 * rng.standard_normal((4, 4, ci, co) if op == 'conv_fwd' else (4, 4, co, ci)))
+    xb, xv = dev(ctx, x)
+    nat, tr = prep(ctx, w)
+    Ho = H // 2 if op == 'conv_fwd' else 2 * H
+    yb = Buf(ctx, N, Ho, Ho, co)
+    part = torch.full((4 << 20,), 9.0, dtype=torch.float32, device=ctx.device)
+    d = L.GanConvDesc(ctx.dt, 2, xv, yb.view(), (tr if op == 'conv_fwd' else nat).data_ptr(), co, None, 0, 0.3, 0,
+                      ctx.ws_ptr, ctx.ws_bytes, part.data_ptr(), groups)
+    opi = 0 if op == 'conv_fwd' else 2
+    info = (C.c_int32 * 5)()
+    assert ctx.lib.gan_conv_plan_info(C.byref(d), opi, info) == 0
+    chunks = info[4]
+    assert chunks > 0, "shape chosen to be fusable"
+    fn = ctx.lib.gan_conv2d_fwd if op == 'conv_fwd' else ctx.lib.gan_convT2d_fwd
+    assert fn(C.byref(d), ctx.stream()) == 0
+    torch.cuda.synchronize()
+    got = part[:groups * chunks * co * 2].cpu().numpy().reshape(groups, chunks, co, 2).astype(np.float64).sum(1)
+    y = host(yb).reshape(groups, -1, co)
+    assert rel(got[..., 0], y.sum(1)) < 1e-4 and rel(got[..., 1], (y * y).sum(1)) < 1e-4
+
+
 def test_thin_layers_take_streaming_kernels():
     """The <= 8-channel layers of the bf16 path must run on csrc/thin.hip (plan info: BM = 0, BN = family)."""
     from gan_amd import _lib as L
