@@ -365,6 +365,36 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p, 
   store_out<T>(p, out_pixel_offset(p, m, par >> 1, par & 1), n, s);
 }
 
+// 4 channels per thread: float4 slab reads (4 splits in flight), one 8/16-byte store.  Needs Cout % 4 == 0 and
+// a 4-element aligned destination (vec_store layers).
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_reduce4_kernel(const GemmParams p, int P) {
+  const int c4 = p.Cout >> 2;
+  long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  long long total = (long long)P * p.M * c4;
+  if (idx >= total) return;
+  const int n = (int)(idx % c4) * 4;
+  long long t = idx / c4;
+  const int m = (int)(t % p.M);
+  const int par = (int)(t / p.M);
+  const size_t sstride = (size_t)p.M * p.NslabPitch;
+  const float* src = p.slab + ((size_t)par * p.splits * p.M + m) * p.NslabPitch + n;
+  f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
+  int k = 0;
+  for (; k + 4 <= p.splits; k += 4) {
+    const f32x4 a = *(const f32x4*)(src + (size_t)k * sstride), b = *(const f32x4*)(src + (size_t)(k + 1) * sstride);
+    const f32x4 c = *(const f32x4*)(src + (size_t)(k + 2) * sstride), d = *(const f32x4*)(src + (size_t)(k + 3) * sstride);
+    s += a; s += b; s += c; s += d;
+  }
+  for (; k < p.splits; ++k) s += *(const f32x4*)(src + (size_t)k * sstride);
+  float v[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] = apply_act(s[e] + (p.bias ? p.bias[n + e] : 0.f), p.act, p.slope);
+  const size_t o = out_pixel_offset(p, m, par >> 1, par & 1) + n;
+  if (p.out_f32) *(f32x4*)((float*)p.y + o) = f32x4{v[0], v[1], v[2], v[3]};
+  else *(uint2*)((T*)p.y + o) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+}
+
 // ------------------------------------------------------------------------------------------------
 // pipeline shape per tile: big (one block per CU) tiles use 64-byte K rows and 4-5 stages so ~100 KB of
 // LDS-DMA stays in flight per CU; small tiles (several blocks per CU) use 128-byte rows, 2 stages.
@@ -520,8 +550,13 @@ static int launch_gemm(const GemmPlan& pl, hipStream_t st) {
   }
   if (rc) return rc;
   if (pl.p.splits > 1) {
-    long long total = (long long)pl.P * pl.p.M * pl.p.Cout;
-    hipLaunchKernelGGL(splitk_reduce_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, pl.p, pl.P);
+    if (pl.p.vec_store && pl.p.Cout % 4 == 0 && (pl.p.out_f32 || sizeof(T) == 2)) {
+      long long total = (long long)pl.P * pl.p.M * (pl.p.Cout / 4);
+      hipLaunchKernelGGL(splitk_reduce4_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, pl.p, pl.P);
+    } else {
+      long long total = (long long)pl.P * pl.p.M * pl.p.Cout;
+      hipLaunchKernelGGL(splitk_reduce_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, pl.p, pl.P);
+    }
     GAN_CHECK_LAUNCH();
   }
   return 0;

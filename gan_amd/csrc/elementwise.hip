@@ -12,13 +12,21 @@ __global__ __launch_bounds__(1024) void bce_kernel(const float* x, long long cou
   __shared__ float red[16];
   float s = 0.f;
   const float inv = 1.0f / (float)count;
-  for (long long i = threadIdx.x; i < count; i += 1024) {
-    float v = x[i];
-    float e = expf(-fabsf(v));
-    s += fmaxf(v, 0.f) - v * target + log1pf(e);
-    if (dx) {
-      float sig = v >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
-      st_f(dx + i * dx_pitch, grad_scale * (sig - target) * inv);
+  // one block (the logit maps are a few 10^4 values): 8 independent loads in flight per thread per round
+  for (long long i0 = threadIdx.x; i0 < count; i0 += 8 * 1024) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = i0 + u * 1024 < count ? x[i0 + u * 1024] : 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const long long i = i0 + u * 1024;
+      if (i >= count) break;
+      const float e = expf(-fabsf(v[u]));
+      s += fmaxf(v[u], 0.f) - v[u] * target + log1pf(e);
+      if (dx) {
+        const float sig = v[u] >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
+        st_f(dx + i * dx_pitch, grad_scale * (sig - target) * inv);
+      }
     }
   }
   s = wave_sum(s);

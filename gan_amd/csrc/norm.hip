@@ -136,11 +136,19 @@ constexpr int FC = 8, FL = 32;
 __device__ __forceinline__ void chunk_sum(const float* partial, int g, int chunks, int C, int c, int kl, double* red,
                                           double& s1, double& s2) {
   double a = 0, b = 0;
-  if (c < C)
-    for (int k = kl; k < chunks; k += FL) {
+  if (c < C) {
+    int k = kl;
+    for (; k + 3 * FL < chunks; k += 4 * FL) {          // 4 independent loads in flight per lane
+      const float* q = partial + (((size_t)g * chunks + k) * C + c) * 2;
+      const float2 v0 = *(const float2*)q, v1 = *(const float2*)(q + (size_t)FL * C * 2);
+      const float2 v2 = *(const float2*)(q + (size_t)2 * FL * C * 2), v3 = *(const float2*)(q + (size_t)3 * FL * C * 2);
+      a += v0.x; b += v0.y; a += v1.x; b += v1.y; a += v2.x; b += v2.y; a += v3.x; b += v3.y;
+    }
+    for (; k < chunks; k += FL) {
       float2 v = *(const float2*)(partial + (((size_t)g * chunks + k) * C + c) * 2);
       a += v.x; b += v.y;
     }
+  }
   const int cl = threadIdx.x % FC;
   red[(kl * FC + cl) * 2] = a; red[(kl * FC + cl) * 2 + 1] = b;
   __syncthreads();
@@ -294,7 +302,9 @@ __global__ __launch_bounds__(256) void norm_act_bwd_kernel(const NormP p, const 
 
 // ------------------------------------------------------------------------------------------------
 static int pick_chunks(long long rows_per_group, int rslots, int groups) {
-  long long ch = (rows_per_group + (long long)rslots * 16 - 1) / ((long long)rslots * 16);
+  // one 4-row round per thread while the tensor is small (a block's serial rounds are pure latency), more rows
+  // per block only once the chunk count hits the cap
+  long long ch = (rows_per_group + (long long)rslots * 4 - 1) / ((long long)rslots * 4);
   long long cap = 512 / groups; if (cap < 1) cap = 1;   // finalize walks the chunks: keep it short
   if (ch > cap) ch = cap;
   if (ch < 1) ch = 1;

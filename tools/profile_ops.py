@@ -38,6 +38,8 @@ for i in range(n):
     tot += ms
     if meta:
         print(f"{i:4d} {ms*1e3:9.1f} us  {meta['flops']/ms/1e9:8.1f} TF/s  {meta['kernel']:28s} {meta['shape']}")
+    else:
+        print(f"{i:4d} {ms*1e3:9.1f} us  {lab}")
     key = meta['kernel'] if meta else lab.split('(')[0]
     agg[key] = agg.get(key, 0) + ms
 print("---- per kernel family (ms/step)")
