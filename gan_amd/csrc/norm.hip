@@ -11,6 +11,8 @@ struct RedGeom {
   int chunks;              // row chunks per group (gridDim.x)
   int hw, gsize;           // pixels per image, images per group
   int rslots;              // row slots per 256-thread block = 256 / min(cvecs, 256)
+  int log2cv;              // cvecs is a power of two
+  FastDiv divRpg;          // row -> statistics group (rows < 2^31; 64-bit divisions cost more than the arithmetic)
 };
 
 struct NormP {
@@ -47,17 +49,25 @@ __device__ __forceinline__ void ld_mask(const uint8_t* m, float* out) {  // VEC 
   }
 }
 
-__device__ __forceinline__ float bwd_dz(float da, float z, float mk, int act, float slope) {
-  float zd = z * mk;                // mk = 2*mask or 1
-  float g;
-  if (act == GAN_ACT_LRELU) g = zd > 0.f ? 1.f : slope;
-  else if (act == GAN_ACT_RELU) g = zd > 0.f ? 1.f : 0.f;
-  else g = 1.f;
-  return da * g * mk;
+// Activation and mask are compile-time in the streaming kernels: with run-time selects these passes were VALU-bound
+// (56 instructions per element), not HBM-bound.
+template <int ACT> __device__ __forceinline__ float act_c(float z, float slope) {
+  if (ACT == GAN_ACT_LRELU) return z > 0.f ? z : z * slope;
+  if (ACT == GAN_ACT_RELU) return z > 0.f ? z : 0.f;
+  if (ACT == GAN_ACT_TANH) return tanhf(z);
+  return z;
+}
+// dz = d(loss)/d(z) for a = act(mk * z): da * act'(mk*z) * mk   (mk = 2*mask, or 1 without dropout)
+template <int ACT, bool MASK> __device__ __forceinline__ float dz_c(float da, float z, float mk, float slope) {
+  const float zd = MASK ? z * mk : z;
+  float d = MASK ? da * mk : da;
+  if (ACT == GAN_ACT_LRELU) d = zd > 0.f ? d : d * slope;
+  else if (ACT == GAN_ACT_RELU) d = zd > 0.f ? d : 0.f;
+  return d;
 }
 
 // MODE 0: stats (y, y^2).  MODE 1: norm backward sums (dz, dz*xhat).  MODE 2: column sum of `da` (bias grad).
-template <typename T, int MODE>
+template <typename T, int MODE, int ACT = GAN_ACT_NONE, bool MASK = false>
 __global__ __launch_bounds__(256) void reduce_partial_kernel(const NormP p, const RedGeom g, float* partial) {
   constexpr int VEC = VecOf<T>::N;
   constexpr int U = 4;
@@ -72,6 +82,7 @@ __global__ __launch_bounds__(256) void reduce_partial_kernel(const NormP p, cons
   float s1[VEC], s2[VEC];
 #pragma unroll
   for (int e = 0; e < VEC; ++e) s1[e] = s2[e] = 0.f;
+  // xhat = (y - mu)*rs with the subtraction first: y*rs - mu*rs cancels catastrophically when |mu| >> sigma
   float ga[VEC], be[VEC], mu[VEC], rs[VEC];
   if (MODE == 1) {
     ldp<VEC>(p.mean + grp * g.C + cv * VEC, mu); ldp<VEC>(p.rstd + grp * g.C + cv * VEC, rs);
@@ -101,14 +112,19 @@ __global__ __launch_bounds__(256) void reduce_partial_kernel(const NormP p, cons
         for (int e = 0; e < VEC; ++e) { s1[e] += v[e]; s2[e] += v[e] * v[e]; }
       } else if (MODE == 1) {
         float yv[VEC], dv[VEC], d2[VEC], mk[VEC];
-        unpack16<T>(vy[u], yv); unpack16<T>(vd[u], dv); unpack16<T>(v2[u], d2);
-        if (p.mask) ld_mask<VEC>(p.mask + (rowbase + rr + (long long)u * rslots) * g.C + cv * VEC, mk);
+        unpack16<T>(vy[u], yv); unpack16<T>(vd[u], dv);
+        if (p.da2) {
+          unpack16<T>(v2[u], d2);
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) dv[e] += d2[e];
+        }
+        if (MASK) ld_mask<VEC>(p.mask + (rowbase + rr + (long long)u * rslots) * g.C + cv * VEC, mk);
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
-          float xh = (yv[e] - mu[e]) * rs[e];
-          float z = ga[e] * xh + be[e];
-          float dz = bwd_dz(dv[e] + d2[e], z, p.mask ? mk[e] : 1.f, p.act, p.slope);
-          s1[e] += dz; s2[e] += dz * xh;
+          const float xh = (yv[e] - mu[e]) * rs[e];
+          const float z = fmaf(ga[e], xh, be[e]);
+          const float dz = dz_c<ACT, MASK>(dv[e], z, MASK ? mk[e] : 1.f, p.slope);
+          s1[e] += dz; s2[e] = fmaf(dz, xh, s2[e]);
         }
       } else {
         float dv[VEC];
@@ -203,50 +219,59 @@ __global__ __launch_bounds__(256) void bwd_finalize_kernel(const float* partial,
   }
 }
 
-// forward: a = act(dropout(gamma*(y-mean)*rstd + beta)); each thread: one channel vector x 4 rows
-template <typename T>
+// forward: a = act(dropout(gamma*(y-mean)*rstd + beta)) = act(mk * ((y-mean)*A + beta)); each thread: one channel vector x 4 rows.
+// The per-(group, channel) constants are loaded once when the thread's rows lie in one statistics group (always,
+// except at group boundaries / 1x1 InstanceNorm maps).
+template <typename T, int ACT, bool MASK>
 __global__ __launch_bounds__(256) void norm_act_fwd_kernel(const NormP p, const RedGeom g, long long rows) {
   constexpr int VEC = VecOf<T>::N;
   constexpr int U = 4;
-  long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-  const int cv = (int)(idx % g.cvecs);
-  const long long rb = idx / g.cvecs * U;
+  const unsigned idx = blockIdx.x * 256u + threadIdx.x;
+  const int cv = (int)(idx & (unsigned)(g.cvecs - 1));
+  const long long rb = (long long)(idx >> g.log2cv) * U;
   if (rb >= rows) return;
   uint4 vy[U];
 #pragma unroll
   for (int u = 0; u < U; ++u)
     vy[u] = rb + u < rows ? *(const uint4*)((const T*)p.y + (rb + u) * p.ypitch + cv * VEC) : make_uint4(0, 0, 0, 0);
-  float ga[VEC], be[VEC], mu[VEC], rs[VEC];
-  ldp<VEC>(p.gamma + cv * VEC, ga); ldp<VEC>(p.beta + cv * VEC, be);
-  int cur = -1;
+  float A[VEC], be[VEC], mu[VEC];        // z = (y - mu)*A + beta, subtraction first (no cancellation when |mu| >> sigma)
+  auto consts = [&](int grp) {
+    float ga[VEC], rs[VEC];
+    ldp<VEC>(p.gamma + cv * VEC, ga); ldp<VEC>(p.beta + cv * VEC, be);
+    ldp<VEC>(p.mean + grp * g.C + cv * VEC, mu); ldp<VEC>(p.rstd + grp * g.C + cv * VEC, rs);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) A[e] = ga[e] * rs[e];
+  };
+  const long long rl = rb + U - 1 < rows ? rb + U - 1 : rows - 1;
+  const int g0 = (int)fdiv((unsigned)rb, g.divRpg), gl = (int)fdiv((unsigned)rl, g.divRpg);
+  const bool uni = g0 == gl;
+  if (uni) consts(g0);
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const long long row = rb + u;
     if (row >= rows) break;
-    const int grp = (int)((row / g.hw) / g.gsize);
-    if (grp != cur) { ldp<VEC>(p.mean + grp * g.C + cv * VEC, mu); ldp<VEC>(p.rstd + grp * g.C + cv * VEC, rs); cur = grp; }
+    if (!uni) consts((int)fdiv((unsigned)row, g.divRpg));
     float v[VEC], o[VEC], mk[VEC];
     unpack16<T>(vy[u], v);
-    if (p.mask) ld_mask<VEC>(p.mask + row * g.C + cv * VEC, mk);
+    if (MASK) ld_mask<VEC>(p.mask + row * g.C + cv * VEC, mk);
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
-      float z = ga[e] * ((v[e] - mu[e]) * rs[e]) + be[e];
-      if (p.mask) z *= mk[e];
-      o[e] = apply_act(z, p.act, p.slope);
+      float z = fmaf(v[e] - mu[e], A[e], be[e]);
+      if (MASK) z *= mk[e];
+      o[e] = act_c<ACT>(z, p.slope);
     }
     *(uint4*)((T*)p.out + row * p.outpitch + cv * VEC) = pack16<T>(o);
   }
 }
 
-// backward apply: dy = gamma*rstd*(dz - S1/R - xhat*S2/R)      (has_norm)
-//                 dy = (da+da2) * act'(a)                       (!has_norm; y holds the saved activation a)
-template <typename T>
+// backward apply: dy = gamma*rstd*(dz - S1/R - xhat*S2/R) = dz*A + xhat*N2 + N1
+template <typename T, int ACT, bool MASK>
 __global__ __launch_bounds__(256) void norm_act_bwd_kernel(const NormP p, const RedGeom g, long long rows) {
   constexpr int VEC = VecOf<T>::N;
   constexpr int U = 4;
-  long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-  const int cv = (int)(idx % g.cvecs);
-  const long long rb = idx / g.cvecs * U;
+  const unsigned idx = blockIdx.x * 256u + threadIdx.x;
+  const int cv = (int)(idx & (unsigned)(g.cvecs - 1));
+  const long long rb = (long long)(idx >> g.log2cv) * U;
   if (rb >= rows) return;
   uint4 vy[U], vd[U], v2[U];
 #pragma unroll
@@ -256,45 +281,78 @@ __global__ __launch_bounds__(256) void norm_act_bwd_kernel(const NormP p, const 
     vd[u] = ok ? *(const uint4*)((const T*)p.da + (rb + u) * p.dapitch + cv * VEC) : make_uint4(0, 0, 0, 0);
     v2[u] = (ok && p.da2) ? *(const uint4*)((const T*)p.da2 + (rb + u) * p.da2pitch + cv * VEC) : make_uint4(0, 0, 0, 0);
   }
-  float ga[VEC], be[VEC], mu[VEC], rs[VEC], q1[VEC], q2[VEC];
-  if (p.has_norm) { ldp<VEC>(p.gamma + cv * VEC, ga); ldp<VEC>(p.beta + cv * VEC, be); }
+  float ga[VEC], be[VEC], rs[VEC], mu[VEC], A[VEC], N1[VEC], N2[VEC];
   const float invR = 1.0f / (float)g.rows_per_group;
-  int cur = -1;
+  auto consts = [&](int grp) {
+    float t[2 * VEC];
+    ldp<VEC>(p.gamma + cv * VEC, ga); ldp<VEC>(p.beta + cv * VEC, be);
+    ldp<VEC>(p.mean + grp * g.C + cv * VEC, mu); ldp<VEC>(p.rstd + grp * g.C + cv * VEC, rs);
+    ldp<2 * VEC>(p.sums + ((size_t)grp * g.C + cv * VEC) * 2, t);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      A[e] = ga[e] * rs[e];
+      N1[e] = -A[e] * (t[2 * e] * invR);
+      N2[e] = -A[e] * (t[2 * e + 1] * invR);
+    }
+  };
+  const long long rl = rb + U - 1 < rows ? rb + U - 1 : rows - 1;
+  const int g0 = (int)fdiv((unsigned)rb, g.divRpg), gl = (int)fdiv((unsigned)rl, g.divRpg);
+  const bool uni = g0 == gl;
+  if (uni) consts(g0);
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const long long row = rb + u;
     if (row >= rows) break;
-    float yv[VEC], dv[VEC], d2[VEC], o[VEC];
-    unpack16<T>(vy[u], yv); unpack16<T>(vd[u], dv); unpack16<T>(v2[u], d2);
-    if (p.has_norm) {
-      const int grp = (int)((row / g.hw) / g.gsize);
-      if (grp != cur) {
-        ldp<VEC>(p.mean + grp * g.C + cv * VEC, mu); ldp<VEC>(p.rstd + grp * g.C + cv * VEC, rs);
-        float t[2 * VEC];
-        ldp<2 * VEC>(p.sums + ((size_t)grp * g.C + cv * VEC) * 2, t);
+    if (!uni) consts((int)fdiv((unsigned)row, g.divRpg));
+    float yv[VEC], dv[VEC], d2[VEC], o[VEC], mk[VEC];
+    unpack16<T>(vy[u], yv); unpack16<T>(vd[u], dv);
+    if (p.da2) {
+      unpack16<T>(v2[u], d2);
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) { q1[e] = t[2 * e] * invR; q2[e] = t[2 * e + 1] * invR; }
-        cur = grp;
-      }
-      float mk[VEC];
-      if (p.mask) ld_mask<VEC>(p.mask + row * g.C + cv * VEC, mk);
+      for (int e = 0; e < VEC; ++e) dv[e] += d2[e];
+    }
+    if (MASK) ld_mask<VEC>(p.mask + row * g.C + cv * VEC, mk);
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) {
-        float xh = (yv[e] - mu[e]) * rs[e];
-        float z = ga[e] * xh + be[e];
-        float dz = bwd_dz(dv[e] + d2[e], z, p.mask ? mk[e] : 1.f, p.act, p.slope);
-        o[e] = ga[e] * rs[e] * (dz - q1[e] - xh * q2[e]);
-      }
-    } else {
+    for (int e = 0; e < VEC; ++e) {
+      const float xh = (yv[e] - mu[e]) * rs[e];
+      const float z = fmaf(ga[e], xh, be[e]);
+      const float dz = dz_c<ACT, MASK>(dv[e], z, MASK ? mk[e] : 1.f, p.slope);
+      o[e] = fmaf(dz, A[e], fmaf(xh, N2[e], N1[e]));
+    }
+    *(uint4*)((T*)p.out + row * p.outpitch + cv * VEC) = pack16<T>(o);
+  }
+}
+
+// activation-only backward on the saved activation a: dy = (da + da2) * act'(a)
+template <typename T, int ACT>
+__global__ __launch_bounds__(256) void act_bwd_kernel(const NormP p, const RedGeom g, long long rows) {
+  constexpr int VEC = VecOf<T>::N;
+  constexpr int U = 4;
+  const unsigned idx = blockIdx.x * 256u + threadIdx.x;
+  const int cv = (int)(idx & (unsigned)(g.cvecs - 1));
+  const long long rb = (long long)(idx >> g.log2cv) * U;
+  if (rb >= rows) return;
+  uint4 vy[U], vd[U], v2[U];
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) {
-        float a = yv[e], gq;
-        if (p.act == GAN_ACT_LRELU) gq = a > 0.f ? 1.f : p.slope;
-        else if (p.act == GAN_ACT_RELU) gq = a > 0.f ? 1.f : 0.f;
-        else if (p.act == GAN_ACT_TANH) gq = 1.f - a * a;
-        else gq = 1.f;
-        o[e] = (dv[e] + d2[e]) * gq;
-      }
+  for (int u = 0; u < U; ++u) {
+    const bool ok = rb + u < rows;
+    vy[u] = ok ? *(const uint4*)((const T*)p.y + (rb + u) * p.ypitch + cv * VEC) : make_uint4(0, 0, 0, 0);
+    vd[u] = ok ? *(const uint4*)((const T*)p.da + (rb + u) * p.dapitch + cv * VEC) : make_uint4(0, 0, 0, 0);
+    v2[u] = (ok && p.da2) ? *(const uint4*)((const T*)p.da2 + (rb + u) * p.da2pitch + cv * VEC) : make_uint4(0, 0, 0, 0);
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const long long row = rb + u;
+    if (row >= rows) break;
+    float av[VEC], dv[VEC], d2[VEC], o[VEC];
+    unpack16<T>(vy[u], av); unpack16<T>(vd[u], dv); unpack16<T>(v2[u], d2);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const float a = av[e], d = dv[e] + d2[e];
+      if (ACT == GAN_ACT_LRELU) o[e] = a > 0.f ? d : d * p.slope;
+      else if (ACT == GAN_ACT_RELU) o[e] = a > 0.f ? d : 0.f;
+      else if (ACT == GAN_ACT_TANH) o[e] = d * (1.f - a * a);
+      else o[e] = d;
     }
     *(uint4*)((T*)p.out + row * p.outpitch + cv * VEC) = pack16<T>(o);
   }
@@ -305,7 +363,8 @@ static int pick_chunks(long long rows_per_group, int rslots, int groups) {
   // one 4-row round per thread while the tensor is small (a block's serial rounds are pure latency), more rows
   // per block only once the chunk count hits the cap
   long long ch = (rows_per_group + (long long)rslots * 4 - 1) / ((long long)rslots * 4);
-  long long cap = 512 / groups; if (cap < 1) cap = 1;   // finalize walks the chunks: keep it short
+  // finalize walks the chunks: keep it short, but big tensors need >2 blocks per CU in flight to stream at HBM rate
+  long long cap = (rows_per_group * groups >= (1 << 18) ? 2048 : 512) / groups; if (cap < 1) cap = 1;
   if (ch > cap) ch = cap;
   if (ch < 1) ch = 1;
   return (int)ch;
@@ -317,6 +376,9 @@ static int red_geom(const GanTensor& t, int groups, int dtype, RedGeom* g) {
   if (g->cvecs > 256 || (g->cvecs & (g->cvecs - 1))) return GAN_E_SHAPE;
   g->rslots = 256 / g->cvecs;
   g->rows_per_group = (long long)g->gsize * g->hw;
+  if ((long long)t.n * g->hw >= 0x7fffffffLL / 4) return GAN_E_SHAPE;      // 32-bit row / thread indices
+  g->log2cv = ilog2_exact(g->cvecs);
+  g->divRpg = make_fastdiv((uint32_t)g->rows_per_group);
   g->chunks = pick_chunks(g->rows_per_group, g->rslots, groups);
   return 0;
 }
@@ -324,20 +386,61 @@ static size_t red_ws_bytes(int groups, int chunks, int c) {
   return ((size_t)groups * chunks * c * 2 + (size_t)groups * c * 2) * sizeof(float);
 }
 
-template <typename T, int MODE>
+template <typename T, int MODE, int ACT = GAN_ACT_NONE, bool MASK = false>
 static int launch_partial(const NormP& p, const RedGeom& g, int groups, float* partial, hipStream_t st) {
   size_t lds = (size_t)g.rslots * g.C * 2 * sizeof(float);
-  hipLaunchKernelGGL((reduce_partial_kernel<T, MODE>), dim3(g.chunks, groups), dim3(256), lds, st, p, g, partial);
+  hipLaunchKernelGGL((reduce_partial_kernel<T, MODE, ACT, MASK>), dim3(g.chunks, groups), dim3(256), lds, st, p, g, partial);
   GAN_CHECK_LAUNCH();
   return 0;
 }
 
-template <typename T, typename K>
+template <typename K>
 static int launch_rows(K kern, const NormP& p, const RedGeom& g, long long rows, hipStream_t st) {
   long long threads = (rows + 3) / 4 * g.cvecs;
   hipLaunchKernelGGL(kern, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, p, g, rows);
   GAN_CHECK_LAUNCH();
   return 0;
+}
+
+// run F<ACT, MASK>() for the run-time (act, mask) pair
+#define GAN_ACT_MASK_SWITCH(act, mask, F)                                                                   \
+  switch ((act) * 2 + ((mask) ? 1 : 0)) {                                                                   \
+    case GAN_ACT_LRELU * 2: return F(GAN_ACT_LRELU, false);                                                 \
+    case GAN_ACT_LRELU * 2 + 1: return F(GAN_ACT_LRELU, true);                                              \
+    case GAN_ACT_RELU * 2: return F(GAN_ACT_RELU, false);                                                   \
+    case GAN_ACT_RELU * 2 + 1: return F(GAN_ACT_RELU, true);                                                \
+    case GAN_ACT_TANH * 2: return F(GAN_ACT_TANH, false);                                                   \
+    case GAN_ACT_TANH * 2 + 1: return F(GAN_ACT_TANH, true);                                                \
+    case GAN_ACT_NONE * 2 + 1: return F(GAN_ACT_NONE, true);                                                \
+    default: return F(GAN_ACT_NONE, false);                                                                 \
+  }
+
+template <typename T>
+static int launch_fwd(const NormP& p, const RedGeom& g, long long rows, hipStream_t st) {
+#define F(A, M) launch_rows(norm_act_fwd_kernel<T, A, M>, p, g, rows, st)
+  GAN_ACT_MASK_SWITCH(p.act, p.mask != nullptr, F)
+#undef F
+}
+template <typename T>
+static int launch_bwd_apply(const NormP& p, const RedGeom& g, long long rows, hipStream_t st) {
+#define F(A, M) launch_rows(norm_act_bwd_kernel<T, A, M>, p, g, rows, st)
+  GAN_ACT_MASK_SWITCH(p.act, p.mask != nullptr, F)
+#undef F
+}
+template <typename T>
+static int launch_bwd_partial(const NormP& p, const RedGeom& g, int groups, float* partial, hipStream_t st) {
+#define F(A, M) launch_partial<T, 1, A, M>(p, g, groups, partial, st)
+  GAN_ACT_MASK_SWITCH(p.act, p.mask != nullptr, F)
+#undef F
+}
+template <typename T>
+static int launch_act_bwd(const NormP& p, const RedGeom& g, long long rows, hipStream_t st) {
+  switch (p.act) {
+    case GAN_ACT_LRELU: return launch_rows(act_bwd_kernel<T, GAN_ACT_LRELU>, p, g, rows, st);
+    case GAN_ACT_RELU: return launch_rows(act_bwd_kernel<T, GAN_ACT_RELU>, p, g, rows, st);
+    case GAN_ACT_TANH: return launch_rows(act_bwd_kernel<T, GAN_ACT_TANH>, p, g, rows, st);
+    default: return launch_rows(act_bwd_kernel<T, GAN_ACT_NONE>, p, g, rows, st);
+  }
 }
 
 extern "C" {
@@ -391,8 +494,7 @@ int gan_norm_act_fwd(const GanNormDesc* d, gan_stream_t stream) {
   p.act = d->act; p.slope = d->slope;
   long long rows = (long long)d->y.n * g.hw;
   hipStream_t st = (hipStream_t)stream;
-  return d->dtype == GAN_F32 ? launch_rows<float>(norm_act_fwd_kernel<float>, p, g, rows, st)
-                             : launch_rows<bf16_t>(norm_act_fwd_kernel<bf16_t>, p, g, rows, st);
+  return d->dtype == GAN_F32 ? launch_fwd<float>(p, g, rows, st) : launch_fwd<bf16_t>(p, g, rows, st);
 }
 
 int gan_norm_act_bwd(const GanNormBwdDesc* d, gan_stream_t stream) {
@@ -412,15 +514,14 @@ int gan_norm_act_bwd(const GanNormBwdDesc* d, gan_stream_t stream) {
   float* sums = partial + (size_t)d->groups * g.chunks * g.C * 2;
   p.sums = sums;
   hipStream_t st = (hipStream_t)stream;
-  rc = d->dtype == GAN_F32 ? launch_partial<float, 1>(p, g, d->groups, partial, st)
-                           : launch_partial<bf16_t, 1>(p, g, d->groups, partial, st);
+  rc = d->dtype == GAN_F32 ? launch_bwd_partial<float>(p, g, d->groups, partial, st)
+                           : launch_bwd_partial<bf16_t>(p, g, d->groups, partial, st);
   if (rc) return rc;
   hipLaunchKernelGGL(bwd_finalize_kernel, dim3((g.C + FC - 1) / FC), dim3(256), 0, st, (const float*)partial, d->groups,
                      g.chunks, g.C, sums, d->dgamma, d->dbeta, d->accumulate);
   GAN_CHECK_LAUNCH();
   long long rows = (long long)d->y.n * g.hw;
-  return d->dtype == GAN_F32 ? launch_rows<float>(norm_act_bwd_kernel<float>, p, g, rows, st)
-                             : launch_rows<bf16_t>(norm_act_bwd_kernel<bf16_t>, p, g, rows, st);
+  return d->dtype == GAN_F32 ? launch_bwd_apply<float>(p, g, rows, st) : launch_bwd_apply<bf16_t>(p, g, rows, st);
 }
 
 static int bias_grad_impl(int32_t dtype, const GanTensor& dy, float* dbias, int32_t accumulate, void* workspace,
@@ -452,8 +553,7 @@ int gan_act_bwd(const GanActBwdDesc* d, gan_stream_t stream) {
   p.act = d->act; p.slope = d->slope; p.has_norm = 0;
   hipStream_t st = (hipStream_t)stream;
   long long rows = (long long)d->a.n * g.hw;
-  rc = d->dtype == GAN_F32 ? launch_rows<float>(norm_act_bwd_kernel<float>, p, g, rows, st)
-                           : launch_rows<bf16_t>(norm_act_bwd_kernel<bf16_t>, p, g, rows, st);
+  rc = d->dtype == GAN_F32 ? launch_act_bwd<float>(p, g, rows, st) : launch_act_bwd<bf16_t>(p, g, rows, st);
   if (rc) return rc;
   if (d->dbias) return bias_grad_impl(d->dtype, d->dy, d->dbias, d->accumulate, d->workspace, d->workspace_bytes, st);
   return 0;
