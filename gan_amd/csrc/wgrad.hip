@@ -25,6 +25,7 @@ struct WgradParams {
   int tilesB;
   int splits, kchunks;
   int accumulate, fold;
+  int swap, shift;  // swap: roles exchanged (thin SMALL tensor folded, thick BIG tensor streamed), taps flipped, rows shifted
   int debug;     // timing experiments (GAN_AMD_WGRAD_DEBUG): 1 skip the MFMA phase, 2 skip global loads + LDS stores
 };
 
@@ -210,38 +211,45 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
     }
 }
 
-// few slabs: one thread per element, coalesced; many slabs (fold mode): 32 elements x 8 slab-lanes per block so
-// the sum is not one long dependent chain
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* slab, float* dw, long long count, int splits, int accumulate) {
-  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= count) return;
-  float s = 0.f;
-  for (int k = 0; k < splits; ++k) s += slab[(size_t)k * count + i];
-  dw[i] = accumulate ? dw[i] + s : s;
-}
-__global__ __launch_bounds__(256) void wgrad_reduce_wide_kernel(const float* slab, float* dw, long long count, int splits, int accumulate) {
-  // 4 elements x 64 slab-lanes per block: hundreds of slabs of a small tensor -> many short chains, many blocks
-  __shared__ float red[64][5];
-  const int el = threadIdx.x & 3, sl = threadIdx.x >> 2;
-  const long long i = (long long)blockIdx.x * 4 + el;
-  float s = 0.f;
-  if (i < count)
-    for (int k = sl; k < splits; k += 64) s += slab[(size_t)k * count + i];
-  red[sl][el] = s;
-  __syncthreads();
-  if (sl == 0 && i < count) {
-    float t = 0.f;
-#pragma unroll 8
-    for (int k = 0; k < 64; ++k) t += red[k][el];
-    dw[i] = accumulate ? dw[i] + t : t;
+// Sum of the split slabs: a block is EV float4 element-vectors x SG split-groups (EV * SG = 256, consecutive
+// threads on consecutive vectors: coalesced 16-byte reads).  A thread adds its splits 4 at a time (independent
+// loads), the SG partial sums meet in LDS and are added in a fixed order: deterministic.  SG is chosen on the
+// host so that small tensors with hundreds of slabs still spread over >= 64K threads.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* slab, float* dw, long long count4, int splits,
+                                                           int accumulate, int log2sg) {
+  __shared__ f32x4 red[256];
+  const int EV = 256 >> log2sg, SG = 1 << log2sg;
+  const int ev = threadIdx.x & (EV - 1), sg = threadIdx.x >> (8 - log2sg);
+  const long long e = (long long)blockIdx.x * EV + ev;
+  f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (e < count4) {
+    const f32x4* src = (const f32x4*)slab + e;
+    int k = sg;
+    for (; k + 3 * SG < splits; k += 4 * SG) {
+      const f32x4 a = src[(size_t)k * count4], b = src[(size_t)(k + SG) * count4];
+      const f32x4 c = src[(size_t)(k + 2 * SG) * count4], d = src[(size_t)(k + 3 * SG) * count4];
+      s += a; s += b; s += c; s += d;
+    }
+    for (; k < splits; k += SG) s += src[(size_t)k * count4];
+  }
+  if (SG > 1) {
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (sg != 0) return;
+    for (int j = 1; j < SG; ++j) s += red[ev + EV * j];
+  }
+  if (e < count4) {
+    f32x4* o = (f32x4*)dw + e;
+    *o = accumulate ? *o + s : s;
   }
 }
 
 struct WgradPlan { WgradParams p; int TA, TB; dim3 grid; size_t slab_bytes; };
 
-static int plan_wgrad(const GanWgradDesc* d, WgradPlan* pl) {
+static int plan_wgrad(const GanWgradDesc* d, WgradPlan* pl, bool allow_swap = true) {
   if (!d || !d->big.ptr || !d->small.ptr || !d->dw) return GAN_E_ARG;
   if (d->dtype != GAN_F32 && d->dtype != GAN_BF16) return GAN_E_ARG;
+  if (((uintptr_t)d->dw | (uintptr_t)d->workspace) & 15) return GAN_E_ARG;      // float4 slab reduction
   const GanTensor &b = d->big, &s = d->small;
   if (b.c % 8 || s.c % 8 || b.pitch % 8 || s.pitch % 8 || b.pitch < b.c || s.pitch < s.c) return GAN_E_SHAPE;
   if (d->big_c > b.c || d->small_c > s.c || d->big_c <= 0 || d->small_c <= 0 || b.n != s.n) return GAN_E_SHAPE;
@@ -256,8 +264,21 @@ static int plan_wgrad(const GanWgradDesc* d, WgradPlan* pl) {
   p.CaReal = d->big_c; p.CbReal = d->small_c; p.accumulate = d->accumulate;
   { static int dbg = -1; if (dbg < 0) { const char* e = getenv("GAN_AMD_WGRAD_DEBUG"); dbg = e ? atoi(e) : 0; } p.debug = dbg; }
   p.fold = (b.c == 8) ? 1 : 0;
+  p.swap = 0; p.shift = 0;
   int TA, TB, tilesA, taps;
-  if (p.fold) { TA = 128; tilesA = 1; taps = 1; TB = s.c >= 128 ? 128 : (s.c >= 64 ? 64 : 16); if (TB == 16) return GAN_E_SHAPE; }
+  if (allow_swap && !p.fold && d->stride == 1 && s.c == 8 && b.c >= 64) {
+    // Thin SMALL tensor (the logits layer's dy): iterate over the BIG grid instead and fold the 16 taps of the thin
+    // tensor into the tile's channel axis, so the thick tensor is streamed once instead of once per tap.
+    // dW[kh][kw] = sum_P big[P] * small[P + 1 - k]: with the folded tap index f = 3 - k that is the usual
+    // gather P + f - 1, shifted by -1; the epilogue un-flips the taps and writes [tap][thick][thin].
+    p.swap = 1; p.fold = 1; p.shift = -1;
+    p.big = s.ptr; p.Hb = s.h; p.Wb = s.w; p.bpitch = s.pitch; p.Ca = s.c;
+    p.small = b.ptr; p.spitch = b.pitch; p.Cb = b.c;
+    M = (long long)b.n * b.h * b.w;
+    p.M = (int)M; p.divW = make_fastdiv(b.w); p.divH = make_fastdiv(b.h);
+    p.CaReal = d->small_c; p.CbReal = d->big_c;
+    TA = 128; tilesA = 1; taps = 1; TB = b.c >= 128 ? 128 : 64;
+  } else if (p.fold) { TA = 128; tilesA = 1; taps = 1; TB = s.c >= 128 ? 128 : (s.c >= 64 ? 64 : 16); if (TB == 16) return GAN_E_SHAPE; }
   else {
     taps = 16;
     TB = s.c >= 128 ? 128 : (s.c >= 64 ? 64 : 16);
@@ -269,7 +290,7 @@ static int plan_wgrad(const GanWgradDesc* d, WgradPlan* pl) {
     if (TA == 16 && TB == 16) return GAN_E_SHAPE;
     tilesA = (b.c + TA - 1) / TA;
   }
-  int tilesB = (s.c + TB - 1) / TB;
+  int tilesB = (p.Cb + TB - 1) / TB;
   p.tilesB = tilesB;
   const int bkm = d->dtype == GAN_F32 ? 32 : 64;
   p.kchunks = (int)((M + bkm - 1) / bkm);
@@ -378,7 +399,7 @@ __global__ __launch_bounds__(64 * WAVES_A * WAVES_B) void wgrad_dma_kernel(const
           const int ce = (aslot ^ swz(row, LPA)) * VEC;          // element index inside the tile row
           int akh = kh, akw = kw, c = ca0 + ce;
           if (p.fold) { const int ft = ce >> 3; akh = ft >> 2; akw = ft & 3; c = ce & 7; }
-          const int sy = gy * p.S + akh - 1, sx = gx * p.S + akw - 1;
+          const int sy = gy * p.S + akh - 1 + p.shift, sx = gx * p.S + akw - 1 + p.shift;
           if ((unsigned)sy < (unsigned)p.Hb && (unsigned)sx < (unsigned)p.Wb && c < p.Ca)
             off = (int)((((size_t)(img * p.Hb + sy) * p.Wb + sx) * (size_t)p.bpitch + c) * ES);
         }
@@ -500,7 +521,8 @@ __global__ __launch_bounds__(64 * WAVES_A * WAVES_B) void wgrad_dma_kernel(const
         for (int j = 0; j < NT; ++j) {
           int cb = cb0 + wb * WTB + j * 16 + r;
           if (cb < p.CbReal) {
-            size_t o = ((size_t)otap * p.CaReal + oc) * p.CbReal + cb;
+            size_t o = p.swap ? ((size_t)(15 - otap) * p.CbReal + cb) * p.CaReal + oc
+                              : ((size_t)otap * p.CaReal + oc) * p.CbReal + cb;
             if (p.splits == 1 && p.accumulate) out[o] += acc[i][j][e];
             else out[o] = acc[i][j][e];
           }
@@ -549,30 +571,31 @@ static bool wgrad_use_tr() {
 
 extern "C" {
 int gan_conv_wgrad(const GanWgradDesc* d, gan_stream_t stream) {
-  WgradPlan pl;
-  int rc = plan_wgrad(d, &pl);
-  if (rc) return rc;
-  if (pl.slab_bytes > d->workspace_bytes || (pl.slab_bytes && !d->workspace)) return GAN_E_WORKSPACE;
+  if (!d) return GAN_E_ARG;
   hipStream_t st = (hipStream_t)stream;
   static int v1 = -1;
   if (v1 < 0) { const char* e = getenv("GAN_AMD_WGRAD_V1"); v1 = (e && e[0] == '1') ? 1 : 0; }
   const size_t es = d->dtype == GAN_F32 ? 4 : 2;
-  const size_t bb = (((size_t)d->big.n * d->big.h * d->big.w - 1) * d->big.pitch + d->big.c) * es;
-  const size_t sb = (((size_t)d->small.n * d->small.h * d->small.w - 1) * d->small.pitch + d->small.c) * es;
+  size_t bb = (((size_t)d->big.n * d->big.h * d->big.w - 1) * d->big.pitch + d->big.c) * es;
+  size_t sb = (((size_t)d->small.n * d->small.h * d->small.w - 1) * d->small.pitch + d->small.c) * es;
   const bool dma_ok = !v1 && bb < 0x7fffffffull && sb < 0x7fffffffull && !(((uintptr_t)d->big.ptr | (uintptr_t)d->small.ptr) & 15);
+  WgradPlan pl;
+  int rc = plan_wgrad(d, &pl, dma_ok);         // the role-swapped plan exists only in the LDS-DMA kernel
+  if (rc) return rc;
+  if (pl.slab_bytes > d->workspace_bytes || (pl.slab_bytes && !d->workspace)) return GAN_E_WORKSPACE;
+  if (pl.p.swap) { const size_t t = bb; bb = sb; sb = t; }
   if (dma_ok) rc = d->dtype == GAN_F32 ? launch_wgrad_dma<float>(pl, (unsigned)bb, (unsigned)sb, st)
                                        : launch_wgrad_dma<bf16_t>(pl, (unsigned)bb, (unsigned)sb, st);
   else if (d->dtype == GAN_F32) rc = launch_wgrad<float, false>(pl, st);
   else rc = wgrad_use_tr() ? launch_wgrad<bf16_t, true>(pl, st) : launch_wgrad<bf16_t, false>(pl, st);
   if (rc) return rc;
   if (pl.p.splits > 1) {
-    long long count = (long long)16 * pl.p.CaReal * pl.p.CbReal;
-    if (pl.p.splits <= 16)
-      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st,
-                         (const float*)pl.p.slab, pl.p.dw, count, pl.p.splits, pl.p.accumulate);
-    else
-      hipLaunchKernelGGL(wgrad_reduce_wide_kernel, dim3((unsigned)((count + 3) / 4)), dim3(256), 0, st,
-                         (const float*)pl.p.slab, pl.p.dw, count, pl.p.splits, pl.p.accumulate);
+    const long long count4 = (long long)4 * pl.p.CaReal * pl.p.CbReal;     // 16 taps * Ca * Cb floats, as float4
+    int log2sg = 0;
+    while (log2sg < 6 && (count4 << log2sg) < 65536 && (8 << log2sg) <= pl.p.splits) ++log2sg;
+    const int EV = 256 >> log2sg;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((count4 + EV - 1) / EV)), dim3(256), 0, st,
+                       (const float*)pl.p.slab, pl.p.dw, count4, pl.p.splits, pl.p.accumulate, log2sg);
     GAN_CHECK_LAUNCH();
   }
   return 0;

@@ -77,7 +77,7 @@ typedef struct GanWgradDesc {
   int32_t stride;        /* 1 or 2 */
   GanTensor big;         /* tensor on the fine grid  (Conv2D: layer input x;  Conv2DTranspose: dy) */
   GanTensor small;       /* tensor on the coarse grid (Conv2D: dy;            Conv2DTranspose: layer input x) */
-  float* dw;             /* fp32 [16][big_c][small_c]: HWIO for Conv2D, (kh,kw,cout,cin) for Conv2DTranspose */
+  float* dw;             /* fp32 [16][big_c][small_c]: HWIO for Conv2D, (kh,kw,cout,cin) for Conv2DTranspose; 16-byte aligned */
   int32_t big_c, small_c;/* real channel counts written (<= big.c, small.c which are 8-padded) */
   int32_t accumulate;    /* 1: dw += result (a net called several times per step, cycle_gan.py:252-255) */
   void* workspace;
