@@ -7,37 +7,26 @@
 // losses
 // ------------------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(1024) void bce_kernel(const float* x, long long count, float target, float loss_scale,
-                                                   int loss_acc, float* loss_out, float grad_scale, T* dx, int dx_pitch) {
-  __shared__ float red[16];
+__global__ __launch_bounds__(256) void bce_kernel(const float* x, long long count, float target, float grad_scale, T* dx,
+                                                  int dx_pitch, float* partial) {
+  // one logit per thread and step (a single 1024-thread block spent 16 us in libm on one CU); block sums go to
+  // `partial`, l1_finalize_kernel adds them in a fixed order
+  __shared__ float red[4];
   float s = 0.f;
   const float inv = 1.0f / (float)count;
-  // one block (the logit maps are a few 10^4 values): 8 independent loads in flight per thread per round
-  for (long long i0 = threadIdx.x; i0 < count; i0 += 8 * 1024) {
-    float v[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = i0 + u * 1024 < count ? x[i0 + u * 1024] : 0.f;
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const long long i = i0 + u * 1024;
-      if (i >= count) break;
-      const float e = expf(-fabsf(v[u]));
-      s += fmaxf(v[u], 0.f) - v[u] * target + log1pf(e);
-      if (dx) {
-        const float sig = v[u] >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
-        st_f(dx + i * dx_pitch, grad_scale * (sig - target) * inv);
-      }
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < count; i += (long long)gridDim.x * 256) {
+    const float v = x[i];
+    const float e = expf(-fabsf(v));
+    s += fmaxf(v, 0.f) - v * target + log1pf(e);
+    if (dx) {
+      const float sig = v >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
+      st_f(dx + i * dx_pitch, grad_scale * (sig - target) * inv);
     }
   }
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    float t = 0.f;
-    for (int i = 0; i < 16; ++i) t += red[i];
-    t = t * inv * loss_scale;
-    loss_out[0] = loss_acc ? loss_out[0] + t : t;
-  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
 template <typename T>
@@ -202,15 +191,22 @@ __global__ __launch_bounds__(256) void copy_view_kernel(const T* src, int spitch
 extern "C" {
 
 int gan_bce_logits(const float* x, int64_t count, float target, float loss_scale, int32_t loss_accumulate,
-                   float* loss_out, float grad_scale, int32_t dtype, void* dx, int32_t dx_pitch, gan_stream_t stream) {
-  if (!x || count <= 0 || !loss_out) return GAN_E_ARG;
+                   float* loss_out, float grad_scale, int32_t dtype, void* dx, int32_t dx_pitch, float* workspace,
+                   gan_stream_t stream) {
+  if (!x || !loss_out || !workspace || count <= 0) return GAN_E_ARG;
+  if (dtype != GAN_F32 && dtype != GAN_BF16) return GAN_E_ARG;
   hipStream_t st = (hipStream_t)stream;
+  int blocks = (int)((count + 255) / 256);
+  if (blocks > 1024) blocks = 1024;
   if (dtype == GAN_F32)
-    hipLaunchKernelGGL(bce_kernel<float>, dim3(1), dim3(1024), 0, st, x, (long long)count, target, loss_scale,
-                       loss_accumulate, loss_out, grad_scale, (float*)dx, dx_pitch);
+    hipLaunchKernelGGL(bce_kernel<float>, dim3(blocks), dim3(256), 0, st, x, (long long)count, target, grad_scale, (float*)dx,
+                       dx_pitch, workspace);
   else
-    hipLaunchKernelGGL(bce_kernel<bf16_t>, dim3(1), dim3(1024), 0, st, x, (long long)count, target, loss_scale,
-                       loss_accumulate, loss_out, grad_scale, (bf16_t*)dx, dx_pitch);
+    hipLaunchKernelGGL(bce_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, x, (long long)count, target, grad_scale,
+                       (bf16_t*)dx, dx_pitch, workspace);
+  GAN_CHECK_LAUNCH();
+  hipLaunchKernelGGL(l1_finalize_kernel, dim3(1), dim3(256), 0, st, (const float*)workspace, blocks, 1.0 / (double)count,
+                     loss_scale, loss_accumulate, loss_out);
   GAN_CHECK_LAUNCH();
   return 0;
 }

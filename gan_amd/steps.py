@@ -21,7 +21,7 @@ class _StepBase:
     def _bce(self, logits_ptr, count, target, loss_idx, loss_scale, acc, grad_scale, dx_ptr):
         lib, ctx = self.ctx.lib, self.ctx
         rc = lib.gan_bce_logits(logits_ptr, count, target, loss_scale, int(acc), self.losses.data_ptr() + 4 * loss_idx,
-                                grad_scale, ctx.dt, dx_ptr, 8, ctx.stream())
+                                grad_scale, ctx.dt, dx_ptr, 8, self.bce_ws.data_ptr(), ctx.stream())
         L.check(rc, "bce_logits")
 
     def _l1(self, a, b, loss_idx, loss_scale, acc, grad_scale, da):
@@ -113,6 +113,7 @@ class Pix2PixStep(_StepBase):
         self.d = self.D.new_call(batch, size, calls=2)
         self.losses = torch.zeros(8, dtype=torch.float32, device=ctx.device)
         self.l1_ws = torch.zeros(4096, dtype=torch.float32, device=ctx.device)
+        self.bce_ws = torch.zeros(1024, dtype=torch.float32, device=ctx.device)
         self.sync = None             # GradSync for data-parallel runs
 
     def nets(self):
@@ -217,6 +218,7 @@ class CycleGANStep(_StepBase):
         self.dy = self.Dy.new_call(batch, size, calls=2)
         self.losses = torch.zeros(12, dtype=torch.float32, device=ctx.device)
         self.l1_ws = torch.zeros(4096, dtype=torch.float32, device=ctx.device)
+        self.bce_ws = torch.zeros(1024, dtype=torch.float32, device=ctx.device)
         self.sync = None
 
     def nets(self):

@@ -171,9 +171,10 @@ int gan_act_bwd(const GanActBwdDesc* d, gan_stream_t stream);
 /* ---- losses --------------------------------------------------------------------------------- */
 /* tf.keras.losses.BinaryCrossentropy(from_logits=True) against a constant target (base_gan.py:227-245).
  * x: fp32 logits [count]. loss_out[0] (+)= loss_scale * mean(bce). If dx != NULL:
- * dx[i*dx_pitch] = grad_scale * (sigmoid(x)-target)/count in `dtype`. */
+ * dx[i*dx_pitch] = grad_scale * (sigmoid(x)-target)/count in `dtype`.  workspace >= 1024 floats (block partial
+ * sums, added in a fixed order by a finalize launch). */
 int gan_bce_logits(const float* x, int64_t count, float target, float loss_scale, int32_t loss_accumulate,
-                   float* loss_out, float grad_scale, int32_t dtype, void* dx, int32_t dx_pitch,
+                   float* loss_out, float grad_scale, int32_t dtype, void* dx, int32_t dx_pitch, float* workspace,
                    gan_stream_t stream);
 /* tf.reduce_mean(tf.abs(a - b)) (pix2pix.py:181, cycle_gan.py:167,176). loss_out (+)= loss_scale*mean.
  * da (optional, dtype, own pitch) = grad_scale * sign(a-b)/count. workspace >= 4096 floats. */

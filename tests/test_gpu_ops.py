@@ -349,7 +349,7 @@ def test_act_bwd_bias_grad_losses(ctx):
     loss = torch.zeros(2, dtype=torch.float32, device=ctx.device)
     dxb = Buf(ctx, N, 30, 30, 8)
     for tgt in (1.0, 0.0):
-        rc = ctx.lib.gan_bce_logits(xt.data_ptr(), x.size, tgt, 0.5, 0, loss.data_ptr(), 0.5, ctx.dt, dxb.t.data_ptr(), 8, ctx.stream())
+        rc = ctx.lib.gan_bce_logits(xt.data_ptr(), x.size, tgt, 0.5, 0, loss.data_ptr(), 0.5, ctx.dt, dxb.t.data_ptr(), 8, ctx.ws_ptr, ctx.stream())
         assert rc == 0
         torch.cuda.synchronize()
         l, g = O.bce_logits(x.astype(np.float64), tgt)
@@ -357,7 +357,7 @@ def test_act_bwd_bias_grad_losses(ctx):
         assert rel(host(dxb, 0, 1), 0.5 * g) < (1e-5 if ctx.dtype == 'f32' else 1e-2)
     # KAT: BCE(logit 0) = ln 2
     z = torch.zeros(900, dtype=torch.float32, device=ctx.device)
-    ctx.lib.gan_bce_logits(z.data_ptr(), 900, 1.0, 1.0, 0, loss.data_ptr(), 1.0, ctx.dt, None, 8, ctx.stream())
+    ctx.lib.gan_bce_logits(z.data_ptr(), 900, 1.0, 1.0, 0, loss.data_ptr(), 1.0, ctx.dt, None, 8, ctx.ws_ptr, ctx.stream())
     torch.cuda.synchronize()
     assert abs(loss[0].item() - np.log(2)) < 1e-6
     # L1 mean + sign gradient, accumulate flag
