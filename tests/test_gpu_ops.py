@@ -141,6 +141,7 @@ CONVT_CASES = [  # (N, h, Cin, Cout)
     (1, 16, 128, 3),        # head, 3 channels
     (4, 64, 128, 128),      # M = 16384 x 4 parities: 256x128 tile
     (3, 5, 128, 2),         # thin-N head, ragged pixel tiles
+    (16, 64, 64, 64),       # 64 output channels on a big map: 256x64 tile (1024 tiles)
 ]
 
 
