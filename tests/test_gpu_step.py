@@ -309,3 +309,34 @@ def test_pix2pix_other_configs_f32(size, channels, batch):
         assert cosine(got[k], ref[5][k]) > 0.999, k
     gd = st.D.params.to_numpy('grad')
     assert cosine(gd['down0.kernel'], ref[6]['down0.kernel']) > 0.999
+
+
+@pytest.mark.parametrize("dtype,step,tol", [('f32', 2e-3, 0.05), ('bf16', 3e-2, 0.2)])
+def test_full_size_gradients_are_directional_derivatives(dtype, step, tol):
+    """BASELINE config 1 at its full size (Pix2Pix 256x256, batch 16; fp32 exact path and the benchmarked bf16 path
+    with its streaming / tiled kernel mix) is far beyond what the numpy
+    oracle finishes in seconds, so the backward pass is checked through a size-independent property: along the
+    gradient direction the loss must change by <grad, delta> (central difference of two forward-only steps).
+    Covers every dgrad / wgrad / normalisation-backward kernel at the benchmark's shapes."""
+    ctx, st, Gp, Dp, inp, tar, masks = _setup_p2p(dtype, B=16)
+    ti, tt = torch.from_numpy(inp).to(ctx.device), torch.from_numpy(tar).to(ctx.device)
+    st._forward_backward(ti, tt, True)                      # gradients only, no Adam
+    torch.cuda.synchronize()
+    base = st.losses.clone()
+    for net, li in ((st.G, 0), (st.D, 3)):                  # gen_total_loss w.r.t. G, disc_loss w.r.t. D
+        P = net.params
+        g = P.grad.clone()
+        w0 = P.master.clone()
+        g2 = float((g.double() ** 2).sum())
+        eps = step * abs(float(base[li])) / g2             # predicted change: `step` of the loss (bf16 needs a larger one)
+        vals = []
+        for sgn in (+1.0, -1.0):
+            P.master.copy_(w0 + sgn * eps * g)
+            P.prepare()
+            vals.append(float(st.train_step(ti, tt, False)[li] if li < 4 else 0.0))
+        P.master.copy_(w0)
+        P.prepare()
+        fd = (vals[0] - vals[1]) / 2.0
+        pred = eps * g2
+        print(f"loss[{li}] = {float(base[li]):.5f}: finite difference {fd:.6e} vs <g,delta> {pred:.6e}")
+        assert abs(fd - pred) < tol * abs(pred), (li, fd, pred)
