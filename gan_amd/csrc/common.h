@@ -56,6 +56,14 @@ __device__ __forceinline__ float apply_act(float v, int act, float slope) {
   return v;
 }
 
+// compile-time activation (the run-time form costs a chain of selects per element in streaming epilogues)
+template <int ACT> __device__ __forceinline__ float act_c(float z, float slope) {
+  if (ACT == GAN_ACT_LRELU) return z > 0.f ? z : z * slope;
+  if (ACT == GAN_ACT_RELU) return z > 0.f ? z : 0.f;
+  if (ACT == GAN_ACT_TANH) return tanhf(z);
+  return z;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -19,6 +19,7 @@
 // slabs + a reduce kernel.  Block ids are remapped so that each XCD (own L2) works on a contiguous range
 // of M tiles and all their N tiles.
 #include "common.h"
+#include <type_traits>
 #include "conv_params.h"
 
 __device__ uint4 g_zero_page[8];   // 128 B of zeros: source of padding taps / out-of-range rows
@@ -213,7 +214,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_gemm_kernel(const
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
 #pragma unroll
-        for (int j = 0; j < NT; ++j) Mma<T>::run(acc[i][j], af[s][i], bfr[s][j]);
+        for (int j = 0; j < NT; ++j) Mma<T>::run(acc[i][j], bfr[s][j], af[s][i]);   // D^T: lane = pixel, 4 channels
         // spread this wave's PT piece issues over the KSTEPS*MT row groups of MFMAs
         constexpr int G = KSTEPS * MT;
         const int g = s * MT + i;
@@ -251,23 +252,21 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_gemm_kernel(const
   }
   __syncthreads();
 
-  // epilogue: C/D layout of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg
+  // epilogue.  The MFMAs ran with the weights as the "A" operand, so the accumulators hold the transposed tile:
+  // acc[i][j][e] = Y[pixel row i*16 + (lane & 15)][channel j*16 + (lane >> 4)*4 + e] - four consecutive channels of
+  // one pixel per lane, which pack into one 8-byte (bf16) / 16-byte (fp32) write.
   if (p.debug & 4) return;   // timing experiment: no epilogue
   if (p.splits > 1) {
     float* slab = p.slab + (size_t)(par * p.splits + split) * p.M * p.NslabPitch;
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
+    for (int i = 0; i < MT; ++i) {
+      const int m = bm0 + wm * WTM + i * 16 + r;
+      if (m < p.M) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        int m = bm0 + wm * WTM + i * 16 + q * 4 + e;
-        if (m < p.M) {
-#pragma unroll
-          for (int j = 0; j < NT; ++j) {
-            int n = bn0 + wn * WTN + j * 16 + r;
-            slab[(size_t)m * p.NslabPitch + n] = acc[i][j][e];
-          }
-        }
+        for (int j = 0; j < NT; ++j)
+          *(f32x4*)(slab + (size_t)m * p.NslabPitch + bn0 + wn * WTN + j * 16 + q * 4) = acc[i][j];
       }
+    }
   } else if (p.vec_store) {
     // stage the tile (bias + activation applied) as T in LDS, then coalesced 16-byte row stores.  The whole
     // stage/table area is free now, so as many 16-row groups per wave-row as fit are staged per pass (one
@@ -279,12 +278,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_gemm_kernel(const
     constexpr int IPP = MAXG >= MT ? MT : (MAXG >= MT / 2 && MT % 2 == 0 ? MT / 2 : (MAXG >= MT / 4 && MT % 4 == 0 ? MT / 4 : 1));
     static_assert(MAXG >= 1, "staging tile does not fit");
     unsigned char* Cs = smem;
-    float bv[NT];
+    float bv[NT][4];
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int n = bn0 + wn * WTN + j * 16 + r;
-      bv[j] = (p.bias && n < p.Cout) ? p.bias[n] : 0.f;
-    }
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int n = bn0 + wn * WTN + j * 16 + q * 4 + e;
+        bv[j][e] = (p.bias && n < p.Cout) ? p.bias[n] : 0.f;
+      }
     // fused normalisation statistics: per-column (sum, sum of squares) of the STORED values of this tile
     constexpr int SL = NTHREADS / BN;                         // row slices per column (NTHREADS >= BN)
     const int scol = tid % BN, sslice = tid / BN;
@@ -292,14 +293,26 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_gemm_kernel(const
 #pragma unroll
     for (int ip = 0; ip < MT / IPP; ++ip) {
       if (ip) __syncthreads();
+      // activation resolved once per pass, not per element (the run-time select chain over 64 accumulators per
+      // lane was ~3 us of the epilogue)
+      auto stage = [&](auto actc) {
+        constexpr int ACT = decltype(actc)::value;
 #pragma unroll
-      for (int ii = 0; ii < IPP; ++ii)
+        for (int ii = 0; ii < IPP; ++ii)
 #pragma unroll
-        for (int j = 0; j < NT; ++j)
+          for (int j = 0; j < NT; ++j) {
+            float v[4];
 #pragma unroll
-          for (int e = 0; e < 4; ++e)
-            st_f((T*)(Cs + ((wm * IPP + ii) * 16 + q * 4 + e) * CS) + wn * WTN + j * 16 + r,
-                 apply_act(acc[ip * IPP + ii][j][e] + bv[j], p.act, p.slope));
+            for (int e = 0; e < 4; ++e) v[e] = act_c<ACT>(acc[ip * IPP + ii][j][e] + bv[j][e], p.slope);
+            T* dst = (T*)(Cs + ((wm * IPP + ii) * 16 + r) * CS) + wn * WTN + j * 16 + q * 4;
+            if constexpr (sizeof(T) == 2) *(uint2*)dst = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+            else *(f32x4*)dst = f32x4{v[0], v[1], v[2], v[3]};
+          }
+      };
+      if (p.act == GAN_ACT_NONE) stage(std::integral_constant<int, GAN_ACT_NONE>{});
+      else if (p.act == GAN_ACT_LRELU) stage(std::integral_constant<int, GAN_ACT_LRELU>{});
+      else if (p.act == GAN_ACT_RELU) stage(std::integral_constant<int, GAN_ACT_RELU>{});
+      else stage(std::integral_constant<int, GAN_ACT_TANH>{});
       __syncthreads();
       for (int idx = tid; idx < WAVES_M * IPP * 16 * VPR; idx += NTHREADS) {
         const int sr = idx / VPR, v = idx % VPR;
@@ -333,19 +346,19 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_gemm_kernel(const
     }
   } else {
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
+    for (int i = 0; i < MT; ++i) {
+      const int m = bm0 + wm * WTM + i * 16 + r;
+      if (m < p.M) {
+        const size_t po = out_pixel_offset(p, m, py, px);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        int m = bm0 + wm * WTM + i * 16 + q * 4 + e;
-        if (m < p.M) {
-          size_t po = out_pixel_offset(p, m, py, px);
+        for (int j = 0; j < NT; ++j)
 #pragma unroll
-          for (int j = 0; j < NT; ++j) {
-            int n = bn0 + wn * WTN + j * 16 + r;
+          for (int e = 0; e < 4; ++e) {
+            const int n = bn0 + wn * WTN + j * 16 + q * 4 + e;
             if (n < p.Cout) store_out<T>(p, po, n, acc[i][j][e]);
           }
-        }
       }
+    }
   }
 #endif
 }

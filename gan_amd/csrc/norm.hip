@@ -51,12 +51,6 @@ __device__ __forceinline__ void ld_mask(const uint8_t* m, float* out) {  // VEC 
 
 // Activation and mask are compile-time in the streaming kernels: with run-time selects these passes were VALU-bound
 // (56 instructions per element), not HBM-bound.
-template <int ACT> __device__ __forceinline__ float act_c(float z, float slope) {
-  if (ACT == GAN_ACT_LRELU) return z > 0.f ? z : z * slope;
-  if (ACT == GAN_ACT_RELU) return z > 0.f ? z : 0.f;
-  if (ACT == GAN_ACT_TANH) return tanhf(z);
-  return z;
-}
 // dz = d(loss)/d(z) for a = act(mk * z): da * act'(mk*z) * mk   (mk = 2*mask, or 1 without dropout)
 template <int ACT, bool MASK> __device__ __forceinline__ float dz_c(float da, float z, float mk, float slope) {
   const float zd = MASK ? z * mk : z;
