@@ -449,7 +449,7 @@ __global__ __launch_bounds__(64 * WAVES_A * WAVES_B) void wgrad_dma_kernel(const
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
-          for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bfv[j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bfv[j], af[i], acc[i][j], 0, 0, 0);   // transposed: lane = row a, 4 cols
       }
     } else {
       // bf16: 16-lane group q reads rows ks*32+8q+{0..3} then {4..7} with ds_read_b64_tr_b16; lane i of the group
@@ -480,7 +480,7 @@ __global__ __launch_bounds__(64 * WAVES_A * WAVES_B) void wgrad_dma_kernel(const
 #pragma unroll
           for (int j = 0; j < NT; ++j) {
             s16x8 bv = __builtin_shufflevector(blo[j], bhi[j], 0, 1, 2, 3, 4, 5, 6, 7);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(bf16x8*)&av, *(bf16x8*)&bv, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(bf16x8*)&bv, *(bf16x8*)&av, acc[i][j], 0, 0, 0);
           }
         }
       }
@@ -509,26 +509,35 @@ __global__ __launch_bounds__(64 * WAVES_A * WAVES_B) void wgrad_dma_kernel(const
 
   const size_t per_split = (size_t)16 * p.CaReal * p.CbReal;
   float* out = p.splits > 1 ? p.slab + (size_t)split * per_split : p.dw;
+  // The MFMAs ran with the SMALL-tensor fragment as the "A" operand, so acc[i][j][e] = dW[a = i*16 + (lane & 15)]
+  // [cb = j*16 + (lane >> 4)*4 + e]: four consecutive cb per lane -> one 16-byte store where the layout allows.
+  const bool vec4 = !p.swap && p.CbReal % 4 == 0;
 #pragma unroll
-  for (int i = 0; i < MT; ++i)
+  for (int i = 0; i < MT; ++i) {
+    const int a = ca0 + wa * WTA + i * 16 + r;
+    int otap = tap, oc = a;
+    if (p.fold) { otap = a >> 3; oc = a & 7; }
+    if (oc >= p.CaReal) continue;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      int a = ca0 + wa * WTA + i * 16 + q * 4 + e;
-      int otap = tap, oc = a;
-      if (p.fold) { otap = a >> 3; oc = a & 7; }
-      if (oc < p.CaReal) {
+    for (int j = 0; j < NT; ++j) {
+      const int cb = cb0 + wb * WTB + j * 16 + q * 4;
+      if (vec4) {
+        if (cb < p.CbReal) {
+          f32x4* o = (f32x4*)(out + ((size_t)otap * p.CaReal + oc) * p.CbReal + cb);
+          *o = (p.splits == 1 && p.accumulate) ? *o + acc[i][j] : acc[i][j];
+        }
+      } else {
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-          int cb = cb0 + wb * WTB + j * 16 + r;
-          if (cb < p.CbReal) {
-            size_t o = p.swap ? ((size_t)(15 - otap) * p.CbReal + cb) * p.CaReal + oc
-                              : ((size_t)otap * p.CaReal + oc) * p.CbReal + cb;
+        for (int e = 0; e < 4; ++e)
+          if (cb + e < p.CbReal) {
+            const size_t o = p.swap ? ((size_t)(15 - otap) * p.CbReal + cb + e) * p.CaReal + oc
+                                    : ((size_t)otap * p.CaReal + oc) * p.CbReal + cb + e;
             if (p.splits == 1 && p.accumulate) out[o] += acc[i][j][e];
             else out[o] = acc[i][j][e];
           }
-        }
       }
     }
+  }
 #endif
 }
 
