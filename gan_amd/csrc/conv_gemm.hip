@@ -406,6 +406,33 @@ __global__ __launch_bounds__(256) void splitk_reduce4_kernel(const GemmParams p,
   const size_t o = out_pixel_offset(p, m, par >> 1, par & 1) + n;
   if (p.out_f32) *(f32x4*)((float*)p.y + o) = f32x4{v[0], v[1], v[2], v[3]};
   else *(uint2*)((T*)p.y + o) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+  if (p.stats) {
+    // fused normalisation statistics of a split-K layer: a block covers RB = 256 / c4 whole rows of one parity and
+    // one statistics group (the planner guarantees it); per-channel (sum, sum^2) of the STORED values over those
+    // rows = one chunk, laid out like the tile partials of the unsplit epilogue: [group][chunk][C][2]
+    __shared__ float red[256][8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float w = p.out_f32 ? v[e] : (float)(T)v[e];                  // as stored (bf16-rounded on the fast path)
+      red[threadIdx.x][2 * e] = w; red[threadIdx.x][2 * e + 1] = w * w;
+    }
+    __syncthreads();
+    const int RB = 256 / c4;
+    if ((int)threadIdx.x < c4) {
+      float acc8[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc8[e] = 0.f;
+      for (int rr = 0; rr < RB; ++rr)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc8[e] += red[rr * c4 + threadIdx.x][e];
+      const int mb = m / RB;                                   // this thread's row is the block's first row
+      const int rpb = p.stats_tpg;                             // row blocks per group (per parity)
+      const int grp = mb / rpb, chunk = (mb % rpb) * P + par;
+      float* dst = p.stats + (((size_t)grp * rpb * P + chunk) * p.stats_C + n) * 2;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dst[e] = acc8[e];
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -518,6 +545,15 @@ static int plan_gemm(const GanConvDesc* d, int op, GemmPlan* pl) {
     const long long rpg = M / d->stats_groups;            // GEMM rows per statistics group (per parity)
     if (rpg % BM == 0 && (BM == 256 ? 512 : 256) >= BN) {
       p.stats_tpg = (int)(rpg / BM);
+      pl->stats_chunks = p.stats_tpg * P;
+      p.stats = d->stats_partial;
+    }
+  } else if (d->stats_groups > 0 && splits > 1 && p.vec_store && x.n % d->stats_groups == 0) {
+    // split-K layer: the slab-reduce kernel emits the partials (one chunk per 256-thread block = RB whole rows)
+    const int c4 = y.c / 4;
+    const long long rpg = M / d->stats_groups;
+    if (y.c % 4 == 0 && c4 <= 256 && 256 % c4 == 0 && rpg % (256 / c4) == 0) {
+      p.stats_tpg = (int)(rpg / (256 / c4));
       pl->stats_chunks = p.stats_tpg * P;
       p.stats = d->stats_partial;
     }

@@ -25,6 +25,9 @@ LEAKY_ALPHA = 0.3                                    # Keras LeakyReLU() default
 BN_EPS, IN_EPS, BN_MOMENTUM = 1e-3, 1e-5, 0.99       # Keras BatchNormalization defaults; utils.py:9
 
 
+STATS_RESERVE = 8 << 20      # room kept behind a conv's split-K slabs for its fused statistics partials
+
+
 def pad8(c):
     return (c + 7) // 8 * 8
 
@@ -264,8 +267,12 @@ class _Builder:
         opi = {'conv_fwd': 0, 'conv_dgrad': 1, 'convT_fwd': 2, 'convT_dgrad': 3}[op]
         fn = [self.lib.gan_conv2d_fwd, self.lib.gan_conv2d_dgrad, self.lib.gan_convT2d_fwd, self.lib.gan_convT2d_dgrad][opi]
         need = self.lib.gan_conv_workspace_bytes(C.byref(d), opi)
-        if need > self.ws_bytes:
+        if need + STATS_RESERVE > self.ws_bytes:
             raise L.GanAmdError(f"workspace too small for {op}: need {need}")
+        # fused statistics partials live behind the launch's own scratch (split-K slabs) in the lane workspace
+        self.last_stats_ptr = self.ws_ptr + (need + 255) // 256 * 256
+        if stats_groups:
+            d.stats_partial = self.last_stats_ptr
         info = (C.c_int32 * 5)()
         self.lib.gan_conv_plan_info(C.byref(d), opi, info)
         self.last_stats_chunks = info[4] if (stats_groups and not os.environ.get('GAN_AMD_NO_FUSED_STATS')) else 0
@@ -298,7 +305,7 @@ class _Builder:
     def norm_names(self):
         return ('.gamma', '.beta') if self.norm == 'batchnorm' else ('.scale', '.offset')
 
-    def norm_fwd(self, name, y, a, groups, mean, rstd, act, mask_ptr, stat_groups_update=True, fused_chunks=0):
+    def norm_fwd(self, name, y, a, groups, mean, rstd, act, mask_ptr, stat_groups_update=True, fused_chunks=0, fused_ptr=None):
         gk, bk = self.norm_names()
         eps = BN_EPS if self.norm == 'batchnorm' else IN_EPS
         mm = mv = None
@@ -309,8 +316,10 @@ class _Builder:
                           mean.data_ptr(), rstd.data_ptr(), mm, mv, BN_MOMENTUM, mask_ptr, L.ACTS[act], LEAKY_ALPHA,
                           self.ws_ptr, self.ws_bytes)
         r = self._desc(d)
-        if fused_chunks:       # the producing convolution's epilogue already wrote the partials into the workspace
-            return [(self.lib.gan_norm_stats_finalize, (r, fused_chunks), f"norm_stats_finalize({name})"),
+        if fused_chunks:       # the producing convolution (epilogue or split-K reduce) already wrote the partials
+            df = L.GanNormDesc.from_buffer_copy(d)
+            df.workspace = fused_ptr or self.ws_ptr
+            return [(self.lib.gan_norm_stats_finalize, (self._desc(df), fused_chunks), f"norm_stats_finalize({name})"),
                     (self.lib.gan_norm_act_fwd, (r,), f"norm_act_fwd({name})")]
         return [(self.lib.gan_norm_stats, (r,), f"norm_stats({name})"),
                 (self.lib.gan_norm_act_fwd, (r,), f"norm_act_fwd({name})")]
@@ -403,7 +412,7 @@ class GenCall:
                 fwd.append(bd.conv('conv_fwd', x, self.y_down[i].view(), w.data_ptr(), G_DOWN[i], 2, stats_groups=groups))
                 mean, rstd = stat(name, G_DOWN[i])
                 fwd += bd.norm_fwd(name, self.y_down[i].view(), a_down(i), groups, mean, rstd, 'lrelu', None,
-                                   fused_chunks=bd.last_stats_chunks)
+                                   fused_chunks=bd.last_stats_chunks, fused_ptr=bd.last_stats_ptr)
             x = a_down(i)
         for j in range(7):
             name = f'up{j}'
@@ -413,7 +422,7 @@ class GenCall:
             mean, rstd = stat(name, G_UP[j])
             mptr = self.masks[j].data_ptr() if (dropout and j < 3) else None
             fwd += bd.norm_fwd(name, self.y_up[j].view(), self.cat[j].view(0, G_UP[j]), groups, mean, rstd, 'relu', mptr,
-                               fused_chunks=bd.last_stats_chunks)
+                               fused_chunks=bd.last_stats_chunks, fused_ptr=bd.last_stats_ptr)
         fwd.append(bd.conv('convT_fwd', self.cat[6].view(), self.out.view(0, C_), P.nat['last.kernel'].data_ptr(), C_, 2,
                            P.ptr('last.bias'), 'tanh'))
         self.fwd_ops = fwd
@@ -580,7 +589,7 @@ class DiscCall:
                                stats_groups=groups))
             mean, rstd = self.stats[name]
             fwd += bd.norm_fwd(name, self.y[name].view(), self.a[name].view(), groups, mean, rstd, 'lrelu', None,
-                               fused_chunks=bd.last_stats_chunks)
+                               fused_chunks=bd.last_stats_chunks, fused_ptr=bd.last_stats_ptr)
             prev = self.a[name]
         fwd.append(bd.conv('conv_fwd', prev.view(), self.logits.view(), P.tr['last.kernel'].data_ptr(), 1, 1,
                            P.ptr('last.bias'), None, 1))

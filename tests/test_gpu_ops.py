@@ -146,10 +146,14 @@ CONVT_CASES = [  # (N, h, Cin, Cout)
 
 
 @pytest.mark.parametrize("case", [('conv_fwd', 8, 128, 64, 128, 1), ('conv_fwd', 8, 128, 64, 128, 2), ('convT_fwd', 2, 64, 128, 128, 1),
-                                  ('convT_fwd', 4, 64, 128, 128, 4)])
+                                  ('convT_fwd', 4, 64, 128, 128, 4),
+                                  # split-K layers: the slab-reduce kernel emits the partials
+                                  ('conv_fwd', 4, 16, 128, 256, 2), ('convT_fwd', 4, 8, 512, 256, 2), ('conv_fwd', 16, 4, 512, 512, 1),
+                                  ('conv_fwd', 4, 4, 512, 512, 4)])
 def test_conv_epilogue_statistics_partials(ctx, case):
     """Fused normalisation statistics (GanConvDesc.stats_partial): per-channel (sum, sum of squares) of the STORED
-    output, summed over the chunks the plan reports, per statistics group."""
+    output, summed over the chunks the plan reports, per statistics group (tile partials from the epilogue, or row-block
+    partials from the slab-reduce kernel of a split-K layer)."""
     from gan_amd import _lib as L
     from gan_amd.nets import Buf
     op, N, H, ci, co, groups = case
