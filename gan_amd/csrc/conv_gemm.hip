@@ -19,6 +19,13 @@
 // slabs + a reduce kernel.  Block ids are remapped so that each XCD (own L2) works on a contiguous range
 // of M tiles and all their N tiles.
 #include "common.h"
+#ifndef CFG_BKB_25664
+#define CFG_BKB_25664 64
+#endif
+#define CFG_WN_25664 2
+#ifndef CFG_BKB_256128
+#define CFG_BKB_256128 128
+#endif
 #include <type_traits>
 #include "conv_params.h"
 
@@ -438,7 +445,7 @@ __global__ __launch_bounds__(256) void splitk_reduce4_kernel(const GemmParams p,
 // ------------------------------------------------------------------------------------------------
 // pipeline shape per tile: big (one block per CU) tiles use 64-byte K rows and 4-5 stages so ~100 KB of
 // LDS-DMA stays in flight per CU; small tiles (several blocks per CU) use 128-byte rows, 2 stages.
-static constexpr int cfg_bkb(int BM, int BN) { return 128; }
+static constexpr int cfg_bkb(int BM, int BN) { return (BM == 256 && BN == 64) ? CFG_BKB_25664 : (BM == 256 && BN == 128) ? CFG_BKB_256128 : 128; }
 static constexpr int cfg_ns(int BM, int BN) {
   return BM == 256 ? 2 : ((BM == 128 && BN >= 64) || (BM == 64 && BN == 128)) ? 3 : 2;
 }
@@ -591,7 +598,7 @@ static int launch_gemm(const GemmPlan& pl, hipStream_t st) {
     case 256256: rc = launch_cfg<T, 256, 256, 2, 4>(pl, st); break;
     case 256128: rc = launch_cfg<T, 256, 128, 4, 2>(pl, st); break;
     case 128128: rc = launch_cfg<T, 128, 128, 2, 2>(pl, st); break;
-    case 256064: rc = launch_cfg<T, 256, 64, 4, 2>(pl, st); break;
+    case 256064: rc = launch_cfg<T, 256, 64, 4, CFG_WN_25664>(pl, st); break;
     case 128064: rc = launch_cfg<T, 128, 64, 2, 2>(pl, st); break;
     case 128016: rc = launch_cfg<T, 128, 16, 4, 1>(pl, st); break;
     case 64128: rc = launch_cfg<T, 64, 128, 2, 2>(pl, st); break;
