@@ -447,7 +447,7 @@ __global__ __launch_bounds__(256) void splitk_reduce4_kernel(const GemmParams p,
 // LDS-DMA stays in flight per CU; small tiles (several blocks per CU) use 128-byte rows, 2 stages.
 static constexpr int cfg_bkb(int BM, int BN) { return (BM == 256 && BN == 64) ? CFG_BKB_25664 : (BM == 256 && BN == 128) ? CFG_BKB_256128 : 128; }
 static constexpr int cfg_ns(int BM, int BN) {
-  return BM == 256 ? 2 : ((BM == 128 && BN >= 64) || (BM == 64 && BN == 128)) ? 3 : 2;
+  return BM == 256 ? 2 : (BM == 128 && BN == 128) ? 2 : ((BM == 128 && BN >= 64) || (BM == 64 && BN == 128)) ? 3 : 2;
 }
 
 static int tune(const char* name, int dflt) {   // GAN_AMD_<name> overrides a planner constant (tuning experiments)
