@@ -559,7 +559,8 @@ static int plan_gemm(const GanConvDesc* d, int op, GemmPlan* pl) {
     // split-K layer: the slab-reduce kernel emits the partials (one chunk per 256-thread block = RB whole rows)
     const int c4 = y.c / 4;
     const long long rpg = M / d->stats_groups;
-    if (y.c % 4 == 0 && c4 <= 256 && 256 % c4 == 0 && rpg % (256 / c4) == 0) {
+    if (y.c % 4 == 0 && c4 <= 256 && 256 % c4 == 0 && rpg % (256 / c4) == 0 &&
+        rpg / (256 / c4) * P <= 1024) {        // beyond ~1k chunks the finalize's walk costs more than a separate pass
       p.stats_tpg = (int)(rpg / (256 / c4));
       pl->stats_chunks = p.stats_tpg * P;
       p.stats = d->stats_partial;
