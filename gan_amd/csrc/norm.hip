@@ -358,7 +358,7 @@ static int pick_chunks(long long rows_per_group, int rslots, int groups) {
   // per block only once the chunk count hits the cap
   long long ch = (rows_per_group + (long long)rslots * 4 - 1) / ((long long)rslots * 4);
   // finalize walks the chunks: keep it short, but big tensors need >2 blocks per CU in flight to stream at HBM rate
-  long long cap = (rows_per_group * groups >= (1 << 18) ? 2048 : 512) / groups; if (cap < 1) cap = 1;
+  long long cap = 512 / groups; if (cap < 1) cap = 1;
   if (ch > cap) ch = cap;
   if (ch < 1) ch = 1;
   return (int)ch;
