@@ -44,7 +44,7 @@ class _Model:
 
     @property
     def trainable_variables(self):
-        return [self.net.params.tensor(n) for n in self.net.params.entries]
+        return [self.net.params.tensor(n) for n in self.net.params.names]
 
     def count_params(self):
         return self.net.params.trainable_count()

@@ -152,6 +152,82 @@ __global__ __launch_bounds__(256) void wprep_multi_kernel(const PrepEntry* ents,
   }
 }
 
+// TF-form Adam fused with the NK weight prep: one 64x64 tile of one kernel tensor per block.  Each weight is read
+// once with its gradient and moments, updated, and leaves as fp32 master + moments and as the two typed copies the
+// GEMMs consume (the transposed one through the LDS tile), instead of Adam (28 B/param) followed by a prep pass that
+// re-reads the master (8 B/param more).  16-byte accesses along the contiguous axis when the tensor allows.
+struct AdamBases { float* master; float* m; float* v; const float* grad; };
+template <typename T>
+__global__ __launch_bounds__(256) void adam_prep_multi_kernel(const PrepEntry* ents, int n, AdamBases ab, const float* lr_t,
+                                                              float omb1, float omb2, float eps, float gscale) {
+  __shared__ float tile[64][65];
+  int e = 0;
+  while (e + 1 < n && (int)blockIdx.x >= ents[e + 1].tile_start) ++e;
+  const PrepEntry en = ents[e];
+  const int A = en.A, B = en.B;
+  const int B8 = (B + 7) & ~7, A8 = (A + 7) & ~7;
+  const int tiles_a = (A8 + 63) / 64;
+  int t = blockIdx.x - en.tile_start;
+  const int tb = t % en.tiles_b; t /= en.tiles_b;
+  const int ta = t % tiles_a, tap = t / tiles_a;
+  const int b0 = tb * 64, a0 = ta * 64;
+  const size_t base = (size_t)(en.master - ab.master);        // this tensor's offset in the flat buffers
+  const float lr = *lr_t;
+  T* nat = (T*)en.nat;
+  T* tr = (T*)en.tr;
+  auto adam1 = [&](float& p, float& m, float& v, float g) {
+    const float gr = g * gscale;
+    m += (gr - m) * omb1;
+    v += (gr * gr - v) * omb2;
+    p -= (m * lr) / (sqrtf(v) + eps);
+  };
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;     // 4 consecutive b per thread, 16 rows per pass
+  const bool vecB = (B & 3) == 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int a = a0 + ty + 16 * i, b = b0 + tx * 4;
+    float w[4] = {0.f, 0.f, 0.f, 0.f};
+    if (a < A && b < B) {
+      const size_t o = base + ((size_t)tap * A + a) * B + b;
+      if (vecB) {
+        float4 pp = *(const float4*)(ab.master + o), mm = *(const float4*)(ab.m + o), vv = *(const float4*)(ab.v + o);
+        const float4 gg = *(const float4*)(ab.grad + o);
+        adam1(pp.x, mm.x, vv.x, gg.x); adam1(pp.y, mm.y, vv.y, gg.y); adam1(pp.z, mm.z, vv.z, gg.z); adam1(pp.w, mm.w, vv.w, gg.w);
+        *(float4*)(ab.master + o) = pp; *(float4*)(ab.m + o) = mm; *(float4*)(ab.v + o) = vv;
+        w[0] = pp.x; w[1] = pp.y; w[2] = pp.z; w[3] = pp.w;
+      } else {
+        for (int k = 0; k < 4 && b + k < B; ++k) {
+          float pp = ab.master[o + k], mm = ab.m[o + k], vv = ab.v[o + k];
+          adam1(pp, mm, vv, ab.grad[o + k]);
+          ab.master[o + k] = pp; ab.m[o + k] = mm; ab.v[o + k] = vv;
+          w[k] = pp;
+        }
+      }
+      if (nat) {
+        T* dst = nat + ((size_t)tap * A + a) * B8 + b;           // B8 % 8 == 0, b % 4 == 0: 8-byte (bf16) / 16-byte aligned
+        if constexpr (sizeof(T) == 2) *(uint2*)dst = make_uint2(pack_bf2(w[0], w[1]), pack_bf2(w[2], w[3]));
+        else *(float4*)dst = make_float4(w[0], w[1], w[2], w[3]);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) tile[ty + 16 * i][tx * 4 + k] = w[k];
+  }
+  __syncthreads();
+  if (tr) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int b = b0 + ty + 16 * i, a = a0 + tx * 4;         // 4 consecutive a per thread
+      if (b < B && a < A8) {
+        T* dst = tr + ((size_t)tap * B + b) * A8 + a;
+        const float w0 = tile[tx * 4][ty + 16 * i], w1 = tile[tx * 4 + 1][ty + 16 * i];
+        const float w2 = tile[tx * 4 + 2][ty + 16 * i], w3 = tile[tx * 4 + 3][ty + 16 * i];
+        if constexpr (sizeof(T) == 2) *(uint2*)dst = make_uint2(pack_bf2(w0, w1), pack_bf2(w2, w3));
+        else *(float4*)dst = make_float4(w0, w1, w2, w3);
+      }
+    }
+  }
+}
+
 __device__ __forceinline__ uint64_t mix64(uint64_t z) {
   z += 0x9E3779B97F4A7C15ull;
   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
@@ -275,6 +351,24 @@ int gan_weights_prepare_multi(const void* entries_dev, int32_t n, int32_t total_
     hipLaunchKernelGGL(wprep_multi_kernel<float>, dim3((unsigned)total_tiles), dim3(256), 0, st, (const PrepEntry*)entries_dev, n);
   else
     hipLaunchKernelGGL(wprep_multi_kernel<bf16_t>, dim3((unsigned)total_tiles), dim3(256), 0, st, (const PrepEntry*)entries_dev, n);
+  GAN_CHECK_LAUNCH();
+  return 0;
+}
+
+int gan_adam_prepare_multi(const void* entries_dev, int32_t n, int32_t total_tiles, int32_t dtype, float* master, float* m,
+                           float* v, const float* grad, const float* lr_t, float beta1, float beta2, float eps,
+                           float grad_scale, gan_stream_t stream) {
+  if (!entries_dev || n <= 0 || total_tiles <= 0 || !master || !m || !v || !grad || !lr_t) return GAN_E_ARG;
+  if (dtype != GAN_F32 && dtype != GAN_BF16) return GAN_E_ARG;
+  if (((uintptr_t)master | (uintptr_t)m | (uintptr_t)v | (uintptr_t)grad) & 15) return GAN_E_ARG;
+  const AdamBases ab = {master, m, v, grad};
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == GAN_F32)
+    hipLaunchKernelGGL(adam_prep_multi_kernel<float>, dim3((unsigned)total_tiles), dim3(256), 0, st, (const PrepEntry*)entries_dev,
+                       n, ab, lr_t, 1.f - beta1, 1.f - beta2, eps, grad_scale);
+  else
+    hipLaunchKernelGGL(adam_prep_multi_kernel<bf16_t>, dim3((unsigned)total_tiles), dim3(256), 0, st,
+                       (const PrepEntry*)entries_dev, n, ab, lr_t, 1.f - beta1, 1.f - beta2, eps, grad_scale);
   GAN_CHECK_LAUNCH();
   return 0;
 }

@@ -116,13 +116,18 @@ class ParamSet:
         self.ctx = ctx
         self.entries = {}
         off = 0
-        for name, shape, trainable in spec:
-            if not trainable:
-                continue
+        # flat layout: every conv kernel first, then the vectors (norm scales/offsets, biases), so that the fused
+        # Adam + NK-prep launch covers [0, vec_start) and one plain Adam launch the rest
+        train = [(n_, s_) for n_, s_, t_ in spec if t_]
+        self.names = [n_ for n_, _ in train]              # the reference's variable order (trainable_variables)
+        for name, shape in [e for e in train if e[0].endswith('.kernel')] + [e for e in train if not e[0].endswith('.kernel')]:
+            if not name.endswith('.kernel') and 'vec_start' not in self.__dict__:
+                self.vec_start = off
             n = int(np.prod(shape))
             self.entries[name] = (off, tuple(shape))
             off += (n + self.ALIGN - 1) // self.ALIGN * self.ALIGN
         self.total = off
+        self.__dict__.setdefault('vec_start', off)
         dev = ctx.device
         self.master = torch.zeros(off, dtype=torch.float32, device=dev)
         self.grad = torch.zeros(off, dtype=torch.float32, device=dev)
@@ -181,13 +186,19 @@ class ParamSet:
         self.ctx.run(self._prep_ops)
 
     def adam(self, lr, b1, b2, eps=1e-7, grad_scale=1.0):
-        """Keras Adam (base_gan.py:247-252), one launch over the whole flat buffer, then refresh NK copies."""
+        """Keras Adam (base_gan.py:247-252): the kernels in one launch fused with the refresh of their NK copies, the
+        vectors (norm parameters, biases) in a second, small one."""
         lib = self.ctx.lib
+        table_ptr, n_ents, tiles, dt = self._prep_ops[0][1]
+        ptrs = (self.master.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), self.grad.data_ptr())
         ops = [(lib.gan_adam_begin, (self.step.data_ptr(), self.lr_t.data_ptr(), lr, b1, b2), "adam_begin"),
-               (lib.gan_adam_tf, (self.master.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), self.grad.data_ptr(),
-                                  self.total, self.lr_t.data_ptr(), b1, b2, eps, grad_scale), "adam_tf")]
+               (lib.gan_adam_prepare_multi, (table_ptr, n_ents, tiles, dt) + ptrs + (self.lr_t.data_ptr(), b1, b2, eps, grad_scale),
+                "adam_prepare_multi")]
+        nvec = self.total - self.vec_start
+        if nvec > 0:
+            ops.append((lib.gan_adam_tf, tuple(p_ + 4 * self.vec_start for p_ in ptrs) + (nvec, self.lr_t.data_ptr(), b1, b2, eps, grad_scale),
+                        "adam_tf"))
         self.ctx.run(ops)
-        self.prepare()
 
 
 def _norm_spec(spec, name, c, norm):

@@ -101,6 +101,13 @@ typedef struct GanPrepEntry {
   int32_t A, B, tile_start, tiles_b;
 } GanPrepEntry;
 int gan_weights_prepare_multi(const void* entries_dev, int32_t n, int32_t total_tiles, int32_t dtype, gan_stream_t stream);
+/* Keras Adam (base_gan.py:247-252) fused with the above for the kernel tensors of a network: every listed tensor (its
+ * master pointer must lie inside the flat `master` buffer; m / v / grad are indexed at the same offset) is updated in
+ * TF form and its NK copies rewritten in the same pass.  gan_adam_begin must have run this step; non-kernel parameters
+ * (norm scales/offsets, biases) are updated with gan_adam_tf.  All four buffers 16-byte aligned. */
+int gan_adam_prepare_multi(const void* entries_dev, int32_t n, int32_t total_tiles, int32_t dtype, float* master, float* m,
+                           float* v, const float* grad, const float* lr_t, float beta1, float beta2, float eps,
+                           float grad_scale, gan_stream_t stream);
 
 /* ---- normalisation + activation ------------------------------------------------------------- */
 typedef struct GanNormDesc {

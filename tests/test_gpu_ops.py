@@ -446,3 +446,47 @@ def test_bad_arguments_return_codes(ctx):
     assert ctx.lib.gan_conv2d_fwd(C.byref(d), ctx.stream()) == -2
     d2 = L.GanConvDesc(ctx.dt, 2, xb.view(), yb.view(), None, 64, None, 0, 0.3, 0, ctx.ws_ptr, ctx.ws_bytes)
     assert ctx.lib.gan_conv2d_fwd(C.byref(d2), ctx.stream()) == -1
+
+
+def test_fused_adam_prepare_equals_adam_then_prepare(ctx):
+    """gan_adam_prepare_multi (Adam + NK copies in one pass over the kernel tensors) must leave exactly what
+    gan_adam_tf followed by gan_weights_prepare leaves: master, both moments, native and transposed copies -
+    including thin tensors (3 or 1 channels on a side) that take its scalar path."""
+    from gan_amd import _lib as L
+    rng = np.random.default_rng(12)
+    shapes = [(64, 128), (3, 64), (128, 1), (100, 72)]                  # (A, B) per 4x4 kernel
+    offs, total = [], 0
+    for A, B in shapes:
+        offs.append(total)
+        total += (16 * A * B + 63) // 64 * 64
+    f32 = torch.float32
+    mk = lambda scale: torch.from_numpy((scale * rng.standard_normal(total)).astype(np.float32)).to(ctx.device)
+    master, m, v, g = mk(0.05), mk(0.01), mk(0.01).abs(), mk(1.0)
+    ref = [t.clone() for t in (master, m, v)]
+    step = torch.zeros(1, dtype=torch.int32, device=ctx.device)
+    lr_t = torch.zeros(1, dtype=f32, device=ctx.device)
+    assert ctx.lib.gan_adam_begin(step.data_ptr(), lr_t.data_ptr(), 2e-4, 0.5, 0.999, ctx.stream()) == 0
+    pad8 = lambda c: (c + 7) // 8 * 8
+    nats = [torch.zeros((16, A, pad8(B)), dtype=ctx.tdtype, device=ctx.device) for A, B in shapes]
+    trs = [torch.zeros((16, B, pad8(A)), dtype=ctx.tdtype, device=ctx.device) for A, B in shapes]
+    ents, tiles = [], 0
+    for (A, B), o, nat, tr in zip(shapes, offs, nats, trs):
+        tb = (pad8(B) + 63) // 64
+        ents.append(L.GanPrepEntry(master.data_ptr() + 4 * o, nat.data_ptr(), tr.data_ptr(), A, B, tiles, tb))
+        tiles += 16 * ((pad8(A) + 63) // 64) * tb
+    arr = (L.GanPrepEntry * len(ents))(*ents)
+    table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(ctx.device)
+    assert ctx.lib.gan_adam_prepare_multi(table.data_ptr(), len(ents), tiles, ctx.dt, master.data_ptr(), m.data_ptr(), v.data_ptr(),
+                                          g.data_ptr(), lr_t.data_ptr(), 0.5, 0.999, 1e-7, 0.5, ctx.stream()) == 0
+    # reference: plain Adam over the flat buffer, then the stand-alone prep of every tensor
+    assert ctx.lib.gan_adam_tf(ref[0].data_ptr(), ref[1].data_ptr(), ref[2].data_ptr(), g.data_ptr(), total, lr_t.data_ptr(),
+                               0.5, 0.999, 1e-7, 0.5, ctx.stream()) == 0
+    torch.cuda.synchronize()
+    for (A, B), o, nat, tr in zip(shapes, offs, nats, trs):
+        sl = slice(o, o + 16 * A * B)
+        for got, want in zip((master, m, v), ref):
+            assert torch.equal(got[sl], want[sl]), (A, B)
+        nat2, tr2 = torch.zeros_like(nat), torch.zeros_like(tr)
+        assert ctx.lib.gan_weights_prepare(ref[0].data_ptr() + 4 * o, A, B, ctx.dt, nat2.data_ptr(), tr2.data_ptr(), ctx.stream()) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(nat, nat2) and torch.equal(tr, tr2), (A, B)
