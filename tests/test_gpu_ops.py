@@ -446,6 +446,29 @@ def test_bad_arguments_return_codes(ctx):
     assert ctx.lib.gan_conv2d_fwd(C.byref(d), ctx.stream()) == -2
     d2 = L.GanConvDesc(ctx.dt, 2, xb.view(), yb.view(), None, 64, None, 0, 0.3, 0, ctx.ws_ptr, ctx.ws_bytes)
     assert ctx.lib.gan_conv2d_fwd(C.byref(d2), ctx.stream()) == -1
+    # empty batch, channel count that is not a multiple of 8, misaligned input pointer
+    y4 = Buf(ctx, 1, 4, 4, 64)
+    e = xb.view(); e.n = 0
+    ye = y4.view(); ye.n = 0
+    assert ctx.lib.gan_conv2d_fwd(C.byref(L.GanConvDesc(ctx.dt, 2, e, ye, w.data_ptr(), 64, None, 0, 0.3, 0, ctx.ws_ptr, ctx.ws_bytes)),
+                                  ctx.stream()) == -2
+    odd = xb.view(); odd.c = 6
+    assert ctx.lib.gan_conv2d_fwd(C.byref(L.GanConvDesc(ctx.dt, 2, odd, y4.view(), w.data_ptr(), 64, None, 0, 0.3, 0, ctx.ws_ptr,
+                                                        ctx.ws_bytes)), ctx.stream()) == -2
+    mis = xb.view(); mis.ptr += 2
+    assert ctx.lib.gan_conv2d_fwd(C.byref(L.GanConvDesc(ctx.dt, 2, mis, y4.view(), w.data_ptr(), 64, None, 0, 0.3, 0, ctx.ws_ptr,
+                                                        ctx.ws_bytes)), ctx.stream()) == -1
+    # a split-K layer and a thin-N layer without (enough) workspace
+    xs, ys = Buf(ctx, 4, 4, 4, 512), Buf(ctx, 4, 2, 2, 512)
+    ws_ = torch.zeros((16, 512, 512), dtype=ctx.tdtype, device=ctx.device)
+    ds = L.GanConvDesc(ctx.dt, 2, xs.view(), ys.view(), ws_.data_ptr(), 512, None, 0, 0.3, 0, ctx.ws_ptr, 1024)
+    assert ctx.lib.gan_conv_workspace_bytes(C.byref(ds), 0) > 1024
+    assert ctx.lib.gan_conv2d_fwd(C.byref(ds), ctx.stream()) == -3
+    if ctx.dtype == 'bf16':
+        xt, yt = Buf(ctx, 1, 8, 8, 128), Buf(ctx, 1, 16, 16, 8)
+        dt_ = L.GanConvDesc(ctx.dt, 2, xt.view(), yt.view(0, 1), ws_.data_ptr(), 1, None, 0, 0.3, 0, None, 0)
+        assert ctx.lib.gan_convT2d_fwd(C.byref(dt_), ctx.stream()) == -3
+    torch.cuda.synchronize()
 
 
 def test_fused_adam_prepare_equals_adam_then_prepare(ctx):
