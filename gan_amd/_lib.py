@@ -85,6 +85,8 @@ SYMBOLS = {
     "gan_act_bwd": (C.c_int, [C.POINTER(GanActBwdDesc), C.c_void_p]),
     "gan_bce_logits": (C.c_int, [C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_int32, C.c_void_p, C.c_float,
                                  C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "gan_patchgan_losses": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                      C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gan_l1": (C.c_int, [C.c_int32, C.POINTER(GanTensor), C.POINTER(GanTensor), C.c_float, C.c_int32, C.c_void_p,
                          C.c_float, C.POINTER(GanTensor), C.c_void_p, C.c_void_p]),
     "gan_adam_begin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_void_p]),

@@ -29,6 +29,52 @@ __global__ __launch_bounds__(256) void bce_kernel(const float* x, long long coun
   if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
+// The three BinaryCrossentropy terms of one Pix2Pix step in ONE pass over the two logit maps (pix2pix.py:167-188,
+// base_gan.py:227-245): gan_loss = BCE(1, D(fake)); disc_loss = 0.5 * (BCE(1, D(real)) + BCE(0, D(fake))), with the
+// three logit gradients.  Block partial sums [blocks][3] -> patchgan_finalize_kernel (fixed order), which also forms
+// gen_total_loss = gan_loss + lambda * l1 from the L1 term already in the loss vector.
+template <typename T>
+__global__ __launch_bounds__(256) void patchgan_bce_kernel(const float* real, const float* fake, long long count,
+                                                           T* g_dfake, T* d_dreal, T* d_dfake, int pitch, float* partial) {
+  __shared__ float red[4][3];
+  float s[3] = {0.f, 0.f, 0.f};
+  const float inv = 1.0f / (float)count;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < count; i += (long long)gridDim.x * 256) {
+    const float r = real[i], f = fake[i];
+    const float er = expf(-fabsf(r)), ef = expf(-fabsf(f));
+    const float lr = log1pf(er), lf = log1pf(ef);
+    s[0] += fmaxf(f, 0.f) - f + lf;                 // BCE(1, fake)
+    s[1] += fmaxf(r, 0.f) - r + lr;                 // BCE(1, real)
+    s[2] += fmaxf(f, 0.f) + lf;                     // BCE(0, fake)
+    const float sr = r >= 0.f ? 1.f / (1.f + er) : er / (1.f + er);
+    const float sf = f >= 0.f ? 1.f / (1.f + ef) : ef / (1.f + ef);
+    if (g_dfake) st_f(g_dfake + i * pitch, (sf - 1.f) * inv);
+    if (d_dreal) st_f(d_dreal + i * pitch, 0.5f * (sr - 1.f) * inv);
+    if (d_dfake) st_f(d_dfake + i * pitch, 0.5f * sf * inv);
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float w = wave_sum(s[k]);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = w;
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) partial[blockIdx.x * 3 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+__global__ __launch_bounds__(64) void patchgan_finalize_kernel(const float* partial, int n, double inv_count, float lambda,
+                                                               const float* l1, float* gen_total, float* gan_loss, float* disc_loss) {
+  double s = 0;
+  const int k = threadIdx.x;                          // lanes 0..2: one BCE term each, summed in block order
+  if (k < 3)
+    for (int i = 0; i < n; ++i) s += partial[i * 3 + k];
+  const float v = (float)(s * inv_count);
+  const float g = __shfl(v, 0, 64), r = __shfl(v, 1, 64), f = __shfl(v, 2, 64);
+  if (k == 0) {
+    *gan_loss = g;
+    *disc_loss = 0.5f * r + 0.5f * f;
+    if (gen_total) *gen_total = g + lambda * (l1 ? *l1 : 0.f);
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void l1_kernel(const T* a, int apitch, const T* b, int bpitch, int C, long long pixels,
                                                  float gscale, T* da, int dapitch, float* partial) {
@@ -283,6 +329,27 @@ int gan_bce_logits(const float* x, int64_t count, float target, float loss_scale
   GAN_CHECK_LAUNCH();
   hipLaunchKernelGGL(l1_finalize_kernel, dim3(1), dim3(256), 0, st, (const float*)workspace, blocks, 1.0 / (double)count,
                      loss_scale, loss_accumulate, loss_out);
+  GAN_CHECK_LAUNCH();
+  return 0;
+}
+
+int gan_patchgan_losses(const float* real_logits, const float* fake_logits, int64_t count, int32_t dtype, void* g_dfake,
+                        void* d_dreal, void* d_dfake, int32_t pitch, float lambda, const float* l1, float* gen_total,
+                        float* gan_loss, float* disc_loss, float* workspace, gan_stream_t stream) {
+  if (!real_logits || !fake_logits || count <= 0 || !gan_loss || !disc_loss || !workspace) return GAN_E_ARG;
+  if (dtype != GAN_F32 && dtype != GAN_BF16) return GAN_E_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  int blocks = (int)((count + 255) / 256);
+  if (blocks > 256) blocks = 256;
+  if (dtype == GAN_F32)
+    hipLaunchKernelGGL(patchgan_bce_kernel<float>, dim3(blocks), dim3(256), 0, st, real_logits, fake_logits, (long long)count,
+                       (float*)g_dfake, (float*)d_dreal, (float*)d_dfake, pitch, workspace);
+  else
+    hipLaunchKernelGGL(patchgan_bce_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, real_logits, fake_logits, (long long)count,
+                       (bf16_t*)g_dfake, (bf16_t*)d_dreal, (bf16_t*)d_dfake, pitch, workspace);
+  GAN_CHECK_LAUNCH();
+  hipLaunchKernelGGL(patchgan_finalize_kernel, dim3(1), dim3(64), 0, st, (const float*)workspace, blocks, 1.0 / (double)count, lambda,
+                     l1, gen_total, gan_loss, disc_loss);
   GAN_CHECK_LAUNCH();
   return 0;
 }

@@ -141,13 +141,13 @@ class Pix2PixStep(_StepBase):
         d.forward()                                                   # pix2pix.py:202-203 (real ++ fake)
         real_ptr, cnt = d.logits_view(0)
         fake_ptr, _ = d.logits_view(1)
-        # generator loss (pix2pix.py:167-188): BCE(1, D(fake)) + lambda * mean|target - gen|
-        self._bce(fake_ptr, cnt, 1.0, 1, 1.0, False, 1.0, d.dlogits_b.t.data_ptr())
+        # generator loss (pix2pix.py:167-188): BCE(1, D(fake)) + lambda * mean|target - gen|; discriminator loss
+        # (base_gan.py:233-245, factor 0.5 at pix2pix.py:206) - the L1 term, then all three BCE terms in one pass
         self._l1(g.out_view(), d.xin.view(Cc, Cc, 0, B), 2, 1.0, False, self.lam, g.dgen.view(0, Cc))
-        self.losses[0:1] = self.losses[1:2] + self.lam * self.losses[2:3]
-        # discriminator loss (base_gan.py:233-245, factor 0.5 at pix2pix.py:206)
-        self._bce(real_ptr, cnt, 1.0, 3, 0.5, False, 0.5, d.dlogits_ptr(0))
-        self._bce(fake_ptr, cnt, 0.0, 3, 0.5, True, 0.5, d.dlogits_ptr(1))
+        lp = self.losses.data_ptr()
+        L.check(self.ctx.lib.gan_patchgan_losses(real_ptr, fake_ptr, cnt, self.ctx.dt, d.dlogits_b.t.data_ptr(), d.dlogits_ptr(0),
+                                                 d.dlogits_ptr(1), 8, self.lam, lp + 8, lp, lp + 4, lp + 12,
+                                                 self.bce_ws.data_ptr(), self.ctx.stream()), "patchgan_losses")
         if training:
             d.backward_input(1)                                       # dL_G/d gen through D(fake), pre-update D
             self._copy(d.dxin.view(Cc, Cc), g.dgen2.view(0, Cc))

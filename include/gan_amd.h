@@ -183,6 +183,14 @@ int gan_act_bwd(const GanActBwdDesc* d, gan_stream_t stream);
 int gan_bce_logits(const float* x, int64_t count, float target, float loss_scale, int32_t loss_accumulate,
                    float* loss_out, float grad_scale, int32_t dtype, void* dx, int32_t dx_pitch, float* workspace,
                    gan_stream_t stream);
+/* The three BCE terms of one Pix2Pix / PatchGAN step in one pass (generator_loss pix2pix.py:167-188 and
+ * discriminator_loss base_gan.py:227-245 with the 0.5 of pix2pix.py:206): gan_loss = BCE(1, fake),
+ * disc_loss = 0.5*(BCE(1, real) + BCE(0, fake)), gradients (optional, `dtype`, element stride `pitch`):
+ * g_dfake = d gan_loss / d fake, d_dreal / d_dfake = d disc_loss / d real, fake.  If gen_total != NULL it receives
+ * gan_loss + lambda * (*l1) (l1 = the already computed L1 term, pix2pix.py:184).  workspace >= 768 floats. */
+int gan_patchgan_losses(const float* real_logits, const float* fake_logits, int64_t count, int32_t dtype, void* g_dfake,
+                        void* d_dreal, void* d_dfake, int32_t pitch, float lambda, const float* l1, float* gen_total,
+                        float* gan_loss, float* disc_loss, float* workspace, gan_stream_t stream);
 /* tf.reduce_mean(tf.abs(a - b)) (pix2pix.py:181, cycle_gan.py:167,176). loss_out (+)= loss_scale*mean.
  * da (optional, dtype, own pitch) = grad_scale * sign(a-b)/count. workspace >= 4096 floats. */
 int gan_l1(int32_t dtype, const GanTensor* a, const GanTensor* b, float loss_scale, int32_t loss_accumulate,

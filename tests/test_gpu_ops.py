@@ -513,3 +513,37 @@ def test_fused_adam_prepare_equals_adam_then_prepare(ctx):
         assert ctx.lib.gan_weights_prepare(ref[0].data_ptr() + 4 * o, A, B, ctx.dt, nat2.data_ptr(), tr2.data_ptr(), ctx.stream()) == 0
         torch.cuda.synchronize()
         assert torch.equal(nat, nat2) and torch.equal(tr, tr2), (A, B)
+
+
+def test_patchgan_losses_equal_three_bce_calls(ctx):
+    """gan_patchgan_losses (one pass over D(real), D(fake)) against three gan_bce_logits calls and the oracle."""
+    from gan_amd.nets import Buf
+    rng = np.random.default_rng(21)
+    N = 3
+    real = (2.5 * rng.standard_normal((N, 30, 30, 1))).astype(np.float32)
+    fake = (2.5 * rng.standard_normal((N, 30, 30, 1)) - 0.5).astype(np.float32)
+    tr_, tf_ = torch.from_numpy(real).to(ctx.device), torch.from_numpy(fake).to(ctx.device)
+    cnt = real.size
+    losses = torch.zeros(4, dtype=torch.float32, device=ctx.device)       # [gen_total, gan, l1, disc]
+    losses[2] = 0.37
+    gb, rb, fb = (Buf(ctx, N, 30, 30, 8) for _ in range(3))
+    lp = losses.data_ptr()
+    assert ctx.lib.gan_patchgan_losses(tr_.data_ptr(), tf_.data_ptr(), cnt, ctx.dt, gb.t.data_ptr(), rb.t.data_ptr(), fb.t.data_ptr(), 8,
+                                       100.0, lp + 8, lp, lp + 4, lp + 12, ctx.ws_ptr, ctx.stream()) == 0
+    ref = torch.zeros(2, dtype=torch.float32, device=ctx.device)
+    g2, r2, f2 = (Buf(ctx, N, 30, 30, 8) for _ in range(3))
+    ws2 = ctx.ws_ptr + 65536
+    bce = ctx.lib.gan_bce_logits
+    assert bce(tf_.data_ptr(), cnt, 1.0, 1.0, 0, ref.data_ptr(), 1.0, ctx.dt, g2.t.data_ptr(), 8, ws2, ctx.stream()) == 0
+    assert bce(tr_.data_ptr(), cnt, 1.0, 0.5, 0, ref.data_ptr() + 4, 0.5, ctx.dt, r2.t.data_ptr(), 8, ws2, ctx.stream()) == 0
+    assert bce(tf_.data_ptr(), cnt, 0.0, 0.5, 1, ref.data_ptr() + 4, 0.5, ctx.dt, f2.t.data_ptr(), 8, ws2, ctx.stream()) == 0
+    torch.cuda.synchronize()
+    got = losses.cpu().numpy()
+    assert np.allclose(got[[1, 3]], ref.cpu().numpy(), rtol=1e-6)
+    assert abs(got[0] - (got[1] + 100.0 * 0.37)) < 1e-5
+    for a, b in ((gb, g2), (rb, r2), (fb, f2)):
+        assert torch.equal(a.t, b.t)
+    lg, _ = O.bce_logits(fake.astype(np.float64), 1.0)
+    lr_, _ = O.bce_logits(real.astype(np.float64), 1.0)
+    lf, _ = O.bce_logits(fake.astype(np.float64), 0.0)
+    assert abs(got[1] - lg) < 1e-6 * max(1, lg) and abs(got[3] - 0.5 * (lr_ + lf)) < 1e-6
