@@ -296,6 +296,26 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* src, T* dst, int
   if (i >= total) return;
   st_f(dst + (i / C) * pitch + (i % C), src[i]);
 }
+// up to 4 (source, destination view) pairs of the same shape in one launch (blockIdx.y = pair): the input pipeline of
+// a step packs the same two images into the generator's and the discriminator's typed input buffers
+struct PackMulti { const float* src[4]; void* dst[4]; int pitch[4]; };
+template <typename T>
+__global__ __launch_bounds__(256) void pack_multi_kernel(const PackMulti pm, int C, long long total) {
+  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int k = blockIdx.y;
+  st_f((T*)pm.dst[k] + (i / C) * pm.pitch[k] + (i % C), pm.src[k][i]);
+}
+struct DropMulti { uint8_t* mask[4]; long long count[4]; uint32_t sid[4]; };
+__global__ __launch_bounds__(256) void dropout_multi_kernel(const DropMulti dm, uint64_t seed, const int32_t* step) {
+  const int k = blockIdx.y;
+  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  long long w = i * 8;
+  if (w >= dm.count[k]) return;
+  uint64_t key = mix64(seed ^ ((uint64_t)(uint32_t)(*step) << 32) ^ dm.sid[k]);
+  uint64_t h = mix64(key ^ (uint64_t)i);
+  for (int e = 0; e < 8 && w + e < dm.count[k]; ++e) dm.mask[k][w + e] = (uint8_t)((h >> (e * 8 + 7)) & 1);
+}
 template <typename T>
 __global__ __launch_bounds__(256) void unpack_kernel(const T* src, float* dst, int C, int pitch, long long total) {
   long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -457,6 +477,41 @@ int gan_pack(int32_t dtype, const float* src, const GanTensor* dst, gan_stream_t
     hipLaunchKernelGGL(pack_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, src, (float*)dst->ptr, dst->c, dst->pitch, total);
   else
     hipLaunchKernelGGL(pack_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst->ptr, dst->c, dst->pitch, total);
+  GAN_CHECK_LAUNCH();
+  return 0;
+}
+
+int gan_pack_multi(int32_t dtype, int32_t n, const float* const* srcs, const GanTensor* dsts, gan_stream_t stream) {
+  if (!srcs || !dsts || n <= 0 || n > 4) return GAN_E_ARG;
+  if (dtype != GAN_F32 && dtype != GAN_BF16) return GAN_E_ARG;
+  PackMulti pm;
+  for (int k = 0; k < n; ++k) {
+    if (!srcs[k] || !dsts[k].ptr) return GAN_E_ARG;
+    if (dsts[k].n != dsts[0].n || dsts[k].h != dsts[0].h || dsts[k].w != dsts[0].w || dsts[k].c != dsts[0].c) return GAN_E_SHAPE;
+    pm.src[k] = srcs[k]; pm.dst[k] = dsts[k].ptr; pm.pitch[k] = dsts[k].pitch;
+  }
+  const long long total = (long long)dsts[0].n * dsts[0].h * dsts[0].w * dsts[0].c;
+  if (total <= 0) return GAN_E_SHAPE;
+  dim3 grid((unsigned)((total + 255) / 256), (unsigned)n);
+  if (dtype == GAN_F32) hipLaunchKernelGGL(pack_multi_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, pm, dsts[0].c, total);
+  else hipLaunchKernelGGL(pack_multi_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, pm, dsts[0].c, total);
+  GAN_CHECK_LAUNCH();
+  return 0;
+}
+
+int gan_dropout_mask_multi(int32_t n, uint8_t* const* masks, const int64_t* counts, uint64_t seed, const int32_t* step,
+                           const uint32_t* stream_ids, gan_stream_t stream) {
+  if (!masks || !counts || !stream_ids || !step || n <= 0 || n > 4) return GAN_E_ARG;
+  DropMulti dm;
+  long long maxw = 0;
+  for (int k = 0; k < n; ++k) {
+    if (!masks[k] || counts[k] <= 0) return GAN_E_ARG;
+    dm.mask[k] = masks[k]; dm.count[k] = counts[k]; dm.sid[k] = stream_ids[k];
+    const long long w = (counts[k] + 7) / 8;
+    if (w > maxw) maxw = w;
+  }
+  hipLaunchKernelGGL(dropout_multi_kernel, dim3((unsigned)((maxw + 255) / 256), (unsigned)n), dim3(256), 0, (hipStream_t)stream, dm,
+                     seed, step);
   GAN_CHECK_LAUNCH();
   return 0;
 }

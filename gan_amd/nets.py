@@ -399,10 +399,11 @@ class GenCall:
 
         self.masks = [torch.ones((B, hs[6 - j], hs[6 - j], 512), dtype=torch.uint8, device=dev) for j in range(3)] if dropout else None
         self.mask_ops = []
-        if dropout:
-            for j in range(3):
-                self.mask_ops.append((ctx.lib.gan_dropout_mask, (self.masks[j].data_ptr(), self.masks[j].numel(), seed,
-                                                                 P.step.data_ptr(), stream_id * 8 + j), "dropout_mask"))
+        if dropout:          # the three Dropout(0.5) masks of this call in one launch
+            self._mask_args = ((C.c_void_p * 3)(*[m.data_ptr() for m in self.masks]), (C.c_int64 * 3)(*[m.numel() for m in self.masks]),
+                               (C.c_uint32 * 3)(*[stream_id * 8 + j for j in range(3)]))
+            self.mask_ops.append((ctx.lib.gan_dropout_mask_multi, (3, self._mask_args[0], self._mask_args[1], seed, P.step.data_ptr(),
+                                                                   self._mask_args[2]), "dropout_mask_multi"))
         self.auto_masks = dropout
 
         def a_down(i):      # activation view of down i

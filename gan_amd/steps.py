@@ -33,6 +33,13 @@ class _StepBase:
     def _pack(self, src_f32, dst_view):
         L.check(self.ctx.lib.gan_pack(self.ctx.dt, src_f32.data_ptr(), C.byref(dst_view), self.ctx.stream()), "pack")
 
+    def _pack_multi(self, pairs):
+        """[(src_f32, dst_view), ...] (<= 4, one shape) in a single launch."""
+        n = len(pairs)
+        srcs = (C.c_void_p * n)(*[s_.data_ptr() for s_, _ in pairs])
+        dsts = (L.GanTensor * n)(*[d_ for _, d_ in pairs])
+        L.check(self.ctx.lib.gan_pack_multi(self.ctx.dt, n, srcs, dsts, self.ctx.stream()), "pack_multi")
+
     def _copy(self, src_view, dst_view):
         L.check(self.ctx.lib.gan_copy_view(self.ctx.dt, C.byref(src_view), C.byref(dst_view), self.ctx.stream()), "copy_view")
 
@@ -132,10 +139,8 @@ class Pix2PixStep(_StepBase):
             d.backward_params()
             return self.losses
         # inputs -> typed, channel-padded buffers.  D input = concat([inp, tar|gen]) (base_gan.py:139)
-        self._pack(inp, g.xin.view(0, Cc))
-        self._pack(inp, d.xin.view(0, Cc, 0, B))
-        self._pack(inp, d.xin.view(0, Cc, B, B))
-        self._pack(tar, d.xin.view(Cc, Cc, 0, B))
+        self._pack_multi([(inp, g.xin.view(0, Cc)), (inp, d.xin.view(0, Cc, 0, B)), (inp, d.xin.view(0, Cc, B, B)),
+                          (tar, d.xin.view(Cc, Cc, 0, B))])
         g.forward()                                                   # pix2pix.py:200
         self._copy(g.out_view(), d.xin.view(Cc, Cc, B, B))
         d.forward()                                                   # pix2pix.py:202-203 (real ++ fake)

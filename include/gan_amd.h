@@ -208,8 +208,13 @@ int gan_adam_tf(float* param, float* m, float* v, const float* grad, int64_t cou
 /* Bernoulli(0.5) keep-mask from a counter hash of (seed, *step, stream_id, index). */
 int gan_dropout_mask(uint8_t* mask, int64_t count, uint64_t seed, const int32_t* step, uint32_t stream_id,
                      gan_stream_t stream);
+/* the same for n <= 4 masks (the three Dropout layers of a generator call) in a single launch; host arrays */
+int gan_dropout_mask_multi(int32_t n, uint8_t* const* masks, const int64_t* counts, uint64_t seed, const int32_t* step,
+                           const uint32_t* stream_ids, gan_stream_t stream);
 /* dst(dtype, pitch view) <- src fp32 dense [n,h,w,c]  /  dst fp32 dense <- src(dtype, pitch view) */
 int gan_pack(int32_t dtype, const float* src, const GanTensor* dst, gan_stream_t stream);
+/* n <= 4 (source, destination) pairs of one shape in a single launch (host arrays, read at call time) */
+int gan_pack_multi(int32_t dtype, int32_t n, const float* const* srcs, const GanTensor* dsts, gan_stream_t stream);
 int gan_unpack(int32_t dtype, const GanTensor* src, float* dst, gan_stream_t stream);
 /* typed view -> typed view (same n,h,w,c; pitches / channel offsets may differ): places the generator
  * output into the discriminator's concat input (base_gan.py:139) and routes its gradient back. */

@@ -547,3 +547,35 @@ def test_patchgan_losses_equal_three_bce_calls(ctx):
     lr_, _ = O.bce_logits(real.astype(np.float64), 1.0)
     lf, _ = O.bce_logits(fake.astype(np.float64), 0.0)
     assert abs(got[1] - lg) < 1e-6 * max(1, lg) and abs(got[3] - 0.5 * (lr_ + lf)) < 1e-6
+
+
+def test_multi_launch_pack_and_dropout_equal_single_calls(ctx):
+    from gan_amd import _lib as L
+    from gan_amd.nets import Buf
+    rng = np.random.default_rng(4)
+    a = torch.from_numpy(rng.standard_normal((2, 16, 16, 1)).astype(np.float32)).to(ctx.device)
+    b = torch.from_numpy(rng.standard_normal((2, 16, 16, 1)).astype(np.float32)).to(ctx.device)
+    big, one = Buf(ctx, 4, 16, 16, 8), Buf(ctx, 2, 16, 16, 8)
+    big2, one2 = Buf(ctx, 4, 16, 16, 8), Buf(ctx, 2, 16, 16, 8)
+    pairs = [(a, one.view(0, 1)), (a, big.view(0, 1, 0, 2)), (a, big.view(0, 1, 2, 2)), (b, big.view(1, 1, 0, 2))]
+    srcs = (C.c_void_p * 4)(*[s.data_ptr() for s, _ in pairs])
+    dsts = (L.GanTensor * 4)(*[d for _, d in pairs])
+    assert ctx.lib.gan_pack_multi(ctx.dt, 4, srcs, dsts, ctx.stream()) == 0
+    for s, d in [(a, one2.view(0, 1)), (a, big2.view(0, 1, 0, 2)), (a, big2.view(0, 1, 2, 2)), (b, big2.view(1, 1, 0, 2))]:
+        assert ctx.lib.gan_pack(ctx.dt, s.data_ptr(), C.byref(d), ctx.stream()) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(big.t, big2.t) and torch.equal(one.t, one2.t)
+    # dropout masks: same counter hash, three masks of different sizes in one launch
+    step = torch.full((1,), 5, dtype=torch.int32, device=ctx.device)
+    sizes = [1000, 4096, 77]
+    m1 = [torch.zeros(n, dtype=torch.uint8, device=ctx.device) for n in sizes]
+    m2 = [torch.zeros(n, dtype=torch.uint8, device=ctx.device) for n in sizes]
+    ptrs = (C.c_void_p * 3)(*[m.data_ptr() for m in m1])
+    cnts = (C.c_int64 * 3)(*sizes)
+    sids = (C.c_uint32 * 3)(8, 9, 10)
+    assert ctx.lib.gan_dropout_mask_multi(3, ptrs, cnts, 1234, step.data_ptr(), sids, ctx.stream()) == 0
+    for m, sid in zip(m2, (8, 9, 10)):
+        assert ctx.lib.gan_dropout_mask(m.data_ptr(), m.numel(), 1234, step.data_ptr(), sid, ctx.stream()) == 0
+    torch.cuda.synchronize()
+    for x, y in zip(m1, m2):
+        assert torch.equal(x, y) and 0.3 < x.float().mean().item() < 0.7
