@@ -530,7 +530,19 @@ class GenCall:
         if key not in self._bwd_cache:
             self._bwd_cache[key] = self._build_bwd(*key)
         ops = self._bwd_cache[key]
-        if defer_wgrads:
+        if defer_wgrads == 'staged':
+            # the wgrad GEMMs (they only feed Adam) run on `self.wgrad_stream` in a few coarse stages: those of the
+            # layers before cut k start when the main dgrad/norm chain has passed cut k - per-op dependencies thrash
+            # (two LDS-bound GEMMs on the same CUs), one stage at the very end leaves the tail serial
+            main = self.ctx.lane_stream(0)
+            is_w = lambda o: len(o) > 4 and o[4]
+            idx = [i for i, o in enumerate(ops) if is_w(o)]
+            bounds = [0] + [idx[c] for c in self.wgrad_cuts if 0 < c < len(idx)] + [len(ops)]
+            for lo, hi in zip(bounds[:-1], bounds[1:]):
+                self.ctx.run([o for o in ops[lo:hi] if not is_w(o)])
+                self.wgrad_stream.wait_stream(main)
+                self.ctx.run_on([o for o in ops[lo:hi] if is_w(o)], self.wgrad_stream)
+        elif defer_wgrads:
             self.ctx.run([o for o in ops if not (len(o) > 4 and o[4])])
             self._deferred = [o for o in ops if len(o) > 4 and o[4]]
         else:

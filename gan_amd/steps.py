@@ -10,6 +10,7 @@ computes forward + losses only (pix2pix.py:208, :291-292).
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 
@@ -158,7 +159,12 @@ class Pix2PixStep(_StepBase):
             self._copy(d.dxin.view(Cc, Cc), g.dgen2.view(0, Cc))
             # two independent chains: D's parameter gradients (pix2pix.py:211) beside G's backward (:210)
             main, lane2 = self.ctx.lane_stream(0), self.ctx.lane_stream(2)
-            if phase == 1:                    # data-parallel: D's parameter pass is phase 2 (beside G's all-reduce)
+            if phase == 1 and self.ctx.ms_mode == 4:   # data-parallel: D's parameter pass is phase 2 (beside G's all-reduce)
+                lane3 = self.ctx.lane_stream(3)
+                g.wgrad_stream, g.wgrad_cuts = lane3, [8]
+                g.backward(use_dgen2=True, defer_wgrads='staged')
+                main.wait_stream(lane3)
+            elif phase == 1:
                 g.backward(use_dgen2=True)
             elif self.ctx.ms_mode == 2:
                 lane2.wait_stream(main)
@@ -183,13 +189,14 @@ class Pix2PixStep(_StepBase):
                 self.ctx.run_on(d.params_ops(), lane2)
                 g.backward(use_dgen2=True)
                 main.wait_stream(lane2)
-            elif self.ctx.ms_mode == 4:       # three chains: D params | G dgrad/norm chain | G wgrads
+            elif self.ctx.ms_mode == 4:       # three chains: D params | G dgrad/norm chain | G wgrads in two stages
                 lane3 = self.ctx.lane_stream(3)
                 lane2.wait_stream(main)
                 self.ctx.run_on(d.params_ops(), lane2)
-                g.backward(use_dgen2=True, defer_wgrads=True)
-                lane3.wait_stream(main)
-                g.run_deferred_wgrads(lane3)
+                # the decoder's wgrad GEMMs start on lane 3 once the main chain has passed the decoder, the encoder's
+                # at its end (+2.5 % over one stage at the end; per-op dependencies, mode 5, lose 9 %)
+                g.wgrad_stream, g.wgrad_cuts = lane3, [int(c) for c in os.environ.get('GAN_AMD_WCUT', '8').split(',')]
+                g.backward(use_dgen2=True, defer_wgrads='staged')
                 main.wait_stream(lane2)
                 main.wait_stream(lane3)
             else:
