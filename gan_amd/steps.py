@@ -25,10 +25,11 @@ class _StepBase:
                                 grad_scale, ctx.dt, dx_ptr, 8, self.bce_ws.data_ptr(), ctx.stream())
         L.check(rc, "bce_logits")
 
-    def _l1(self, a, b, loss_idx, loss_scale, acc, grad_scale, da):
+    def _l1(self, a, b, loss_idx, loss_scale, acc, grad_scale, da, stream=None):
         lib, ctx = self.ctx.lib, self.ctx
         rc = lib.gan_l1(ctx.dt, C.byref(a), C.byref(b), loss_scale, int(acc), self.losses.data_ptr() + 4 * loss_idx,
-                        grad_scale, C.byref(da) if da is not None else None, self.l1_ws.data_ptr(), ctx.stream())
+                        grad_scale, C.byref(da) if da is not None else None, self.l1_ws.data_ptr(),
+                        stream.cuda_stream if stream is not None else ctx.stream())
         L.check(rc, "l1")
 
     def _pack(self, src_f32, dst_view):
@@ -143,13 +144,19 @@ class Pix2PixStep(_StepBase):
         self._pack_multi([(inp, g.xin.view(0, Cc)), (inp, d.xin.view(0, Cc, 0, B)), (inp, d.xin.view(0, Cc, B, B)),
                           (tar, d.xin.view(Cc, Cc, 0, B))])
         g.forward()                                                   # pix2pix.py:200
+        # generator loss (pix2pix.py:167-188): BCE(1, D(fake)) + lambda * mean|target - gen|; discriminator loss
+        # (base_gan.py:233-245, factor 0.5 at pix2pix.py:206) - the L1 term (it only needs G's output: beside D's
+        # forward when lanes are on), then all three BCE terms in one pass
+        side = self.ctx.lane_stream(2) if self.ctx.ms_mode == 4 else None
+        if side is not None:
+            side.wait_stream(self.ctx.lane_stream(0))
+        self._l1(g.out_view(), d.xin.view(Cc, Cc, 0, B), 2, 1.0, False, self.lam, g.dgen.view(0, Cc), stream=side)
         self._copy(g.out_view(), d.xin.view(Cc, Cc, B, B))
         d.forward()                                                   # pix2pix.py:202-203 (real ++ fake)
+        if side is not None:
+            self.ctx.lane_stream(0).wait_stream(side)
         real_ptr, cnt = d.logits_view(0)
         fake_ptr, _ = d.logits_view(1)
-        # generator loss (pix2pix.py:167-188): BCE(1, D(fake)) + lambda * mean|target - gen|; discriminator loss
-        # (base_gan.py:233-245, factor 0.5 at pix2pix.py:206) - the L1 term, then all three BCE terms in one pass
-        self._l1(g.out_view(), d.xin.view(Cc, Cc, 0, B), 2, 1.0, False, self.lam, g.dgen.view(0, Cc))
         lp = self.losses.data_ptr()
         L.check(self.ctx.lib.gan_patchgan_losses(real_ptr, fake_ptr, cnt, self.ctx.dt, d.dlogits_b.t.data_ptr(), d.dlogits_ptr(0),
                                                  d.dlogits_ptr(1), 8, self.lam, lp + 8, lp, lp + 4, lp + 12,
