@@ -6,26 +6,21 @@
 // rows m = (image, gy, gx) on a "GEMM grid"; src(m,tap) = (gy*S + dy(tap), gx*S + dx(tap)) with zero
 // fill outside the source map; output pixel = (gy*OS + py, gx*OS + px).  A stride-2 transposed conv
 // (and the dgrad of a stride-2 conv) is four output-parity sub-GEMMs with 4 taps each (K = 4*Cin),
-// selected by blockIdx.z, so no zero-inserted input is ever materialised.
+// enumerated parity-fastest in blockIdx.x, so no zero-inserted input is ever materialised.
 //
-// Data path: the im2col gather goes global -> LDS directly (global_load_lds_dwordx4: per-lane SOURCE
-// address = the gather, lane-linear LDS destination), no VGPR staging and no ds_write.  An LDS tile row is
-// 128 bytes of K (64 bf16 / 32 fp32) = eight 16-byte slots, XOR-swizzled by (row & 7) through the source
-// address so the ds_read_b128 fragment reads are bank-conflict free.  Padding taps and out-of-range rows
-// read a zero page.  Two LDS stages: tile k+1 streams in while tile k is multiplied; one barrier per
-// 128-byte K step.  256 threads = 4 waves; block tile BM x BN; bf16: v_mfma_f32_16x16x32_bf16, fp32
-// (parity path): exact v_mfma_f32_16x16x4_f32.  The epilogue stages the tile in LDS and writes whole
-// 16-byte channel vectors (bias + activation fused).  Small problems split K across blockIdx.z into fp32
-// slabs + a reduce kernel.  Block ids are remapped so that each XCD (own L2) works on a contiguous range
-// of M tiles and all their N tiles.
+// Data path: the im2col gather goes global -> LDS directly (buffer_load_dwordx4 ... lds: per-lane SOURCE offset =
+// the gather, read from a per-block table in LDS; lane-linear LDS destination), no VGPR staging and no ds_write.
+// An LDS tile row is 128 (or 64) bytes of K, 16-byte slots XOR-swizzled through the source address so the
+// ds_read_b128 fragment reads are bank-conflict free.  Padding taps and out-of-range rows carry the offset
+// 0x80000000, which the buffer descriptor's range check turns into zeros.  2 or 3 LDS stages (counted vmcnt, raw
+// s_barrier, inline-asm fragment reads); 4 or 8 waves; block tile BM x BN chosen per layer (256x256 ... 16x128, see
+// plan_gemm); bf16: v_mfma_f32_16x16x32_bf16, fp32 (parity path): exact v_mfma_f32_16x16x4_f32, with the weights
+// as the MFMA "A" operand so that a lane's accumulators are 4 consecutive channels of one pixel.  The epilogue
+// stages the tile in LDS and writes whole 16-byte channel vectors (bias + activation fused, optional
+// normalisation-statistics partials).  Small problems split K across blockIdx.z into fp32 slabs + a reduce kernel.
+// Block ids are remapped so that each XCD (own L2) works on a contiguous range of M tiles and all their N tiles.
+// The <= 8-channel layers do not come here: thin.hip.  DESIGN.md section 4 has the measured LDS-bandwidth model.
 #include "common.h"
-#ifndef CFG_BKB_25664
-#define CFG_BKB_25664 64
-#endif
-#define CFG_WN_25664 2
-#ifndef CFG_BKB_256128
-#define CFG_BKB_256128 128
-#endif
 #include <type_traits>
 #include "conv_params.h"
 
@@ -443,9 +438,10 @@ __global__ __launch_bounds__(256) void splitk_reduce4_kernel(const GemmParams p,
 }
 
 // ------------------------------------------------------------------------------------------------
-// pipeline shape per tile: big (one block per CU) tiles use 64-byte K rows and 4-5 stages so ~100 KB of
-// LDS-DMA stays in flight per CU; small tiles (several blocks per CU) use 128-byte rows, 2 stages.
-static constexpr int cfg_bkb(int BM, int BN) { return (BM == 256 && BN == 64) ? CFG_BKB_25664 : (BM == 256 && BN == 128) ? CFG_BKB_256128 : 128; }
+// pipeline shape per tile (measured): 128-byte K rows and 2 stages for the 8-wave 256-row tiles (one block per CU),
+// 64-byte rows for 256x64 and 2 stages for 128x128 so that two blocks share a CU, 3 stages with counted vmcnt for the
+// 4-wave 128x64 / 64x128 tiles.
+static constexpr int cfg_bkb(int BM, int BN) { return (BM == 256 && BN == 64) ? 64 : 128; }   // 256x64: two blocks per CU
 static constexpr int cfg_ns(int BM, int BN) {
   return BM == 256 ? 2 : (BM == 128 && BN == 128) ? 2 : ((BM == 128 && BN >= 64) || (BM == 64 && BN == 128)) ? 3 : 2;
 }
@@ -599,7 +595,7 @@ static int launch_gemm(const GemmPlan& pl, hipStream_t st) {
     case 256256: rc = launch_cfg<T, 256, 256, 2, 4>(pl, st); break;
     case 256128: rc = launch_cfg<T, 256, 128, 4, 2>(pl, st); break;
     case 128128: rc = launch_cfg<T, 128, 128, 2, 2>(pl, st); break;
-    case 256064: rc = launch_cfg<T, 256, 64, 4, CFG_WN_25664>(pl, st); break;
+    case 256064: rc = launch_cfg<T, 256, 64, 4, 2>(pl, st); break;
     case 128064: rc = launch_cfg<T, 128, 64, 2, 2>(pl, st); break;
     case 128016: rc = launch_cfg<T, 128, 16, 4, 1>(pl, st); break;
     case 64128: rc = launch_cfg<T, 64, 128, 2, 2>(pl, st); break;
