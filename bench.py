@@ -127,12 +127,12 @@ def main():
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
 
     from gan_amd.ddp import GradSync
-    from gan_amd.nets import Ctx
+    from gan_amd.nets import Ctx, workspace_mb_for
     from gan_amd.steps import CycleGANStep, Pix2PixStep
     dev = f'cuda:{local}'
     torch.cuda.set_device(local)
-    ctx = Ctx(dev, args.dtype)
     B, S = args.batch, args.img_size
+    ctx = Ctx(dev, args.dtype, workspace_mb=workspace_mb_for(B, S))
     if args.model == 'pix2pix':
         step = Pix2PixStep(ctx, B, S, 1, lam=100.0, seed=123)
     else:

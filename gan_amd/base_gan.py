@@ -16,7 +16,7 @@ import torch
 from . import _lib as L
 from . import data as D
 from .checkpoint import DISC_LAYERS, GEN_LAYERS, tf_variable_key
-from .nets import Ctx, DiscriminatorNet, GeneratorNet
+from .nets import Ctx, DiscriminatorNet, GeneratorNet, workspace_mb_for
 
 
 def _to_dev(x, ctx):
@@ -132,7 +132,9 @@ class AdamConfig:
 class GAN(ABC):
     def __init__(self, config):
         self.config = config
-        self.ctx = Ctx(config.get('device', 'cuda:0'), config.get('dtype', 'bf16'))
+        self.ctx = Ctx(config.get('device', 'cuda:0'), config.get('dtype', 'bf16'),
+                       workspace_mb=workspace_mb_for(int(config.get('batch_size', 1)), int(config.get('img_size', 256)),
+                                                     int(config.get('channels', 1))))
         self.loss_obj = self.loss_object()
 
     # ---- image helpers (base_gan.py:26-61) -------------------------------------------------------

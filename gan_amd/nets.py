@@ -32,6 +32,13 @@ def pad8(c):
     return (c + 7) // 8 * 8
 
 
+def workspace_mb_for(batch, size, channels=1, calls=2):
+    """Lane workspace (MiB) that covers the largest scratch user of a step at this shape: the thin-N kernels'
+    Z[pixel][c][tap] fp32 buffer of the discriminator's input gradient (2*batch... images, 2*channels outputs)."""
+    need = calls * batch * (size // 2) ** 2 * max(1, 2 * channels) * 64 + (16 << 20)
+    return max(256, (need >> 20) + 1)
+
+
 class Ctx:
     """Device, dtype, library handle and the shared split-K / reduction workspace."""
 
