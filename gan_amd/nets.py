@@ -58,7 +58,7 @@ class Ctx:
         self.ws_lanes = [torch.empty(workspace_mb << 20, dtype=torch.uint8, device=self.device) for _ in range(4)]
         self.ws = self.ws_lanes[0]
         self.ws_ptr, self.ws_bytes = self.ws.data_ptr(), self.ws.numel()
-        self.side = [torch.cuda.Stream(device=self.device) for _ in range(3)]
+        self.side = [torch.cuda.Stream(device=self.device) for _ in range(4)]     # lanes 1..4 (4: early optimiser step)
         # 0: everything on one stream; 1: one fork/join per step (deferred generator wgrads beside the
         # discriminator's parameter pass); 2: per-op wgrad side stream + second chain
         import os
@@ -152,17 +152,45 @@ class ParamSet:
                 self.nat[name] = torch.zeros((16, A, pad8(B)), dtype=ctx.tdtype, device=dev)
                 self.tr[name] = torch.zeros((16, B, pad8(A)), dtype=ctx.tdtype, device=dev)
         # one launch refreshes every NK copy of the network (device table of GanPrepEntry)
+        self._prep_table, self._prep_args = self._kernel_table(list(self.nat))
+        self._prep_ops = [(ctx.lib.gan_weights_prepare_multi, self._prep_args, "weights_prepare_multi")]
+        self._segments = None
+
+    def _kernel_table(self, names):
+        """Device table of GanPrepEntry for the kernels `names` -> (table tensor, (ptr, n, tiles, dtype))."""
         ents, tiles = [], 0
-        for name in self.nat:
+        for name in names:
             o, shape = self.entries[name]
             A, B = shape[2], shape[3]
             tb = (pad8(B) + 63) // 64
             ents.append(L.GanPrepEntry(self.master.data_ptr() + 4 * o, self.nat[name].data_ptr(), self.tr[name].data_ptr(), A, B, tiles, tb))
             tiles += 16 * ((pad8(A) + 63) // 64) * tb
         arr = (L.GanPrepEntry * len(ents))(*ents)
-        self._prep_table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
-        self._prep_ops = [(ctx.lib.gan_weights_prepare_multi, (self._prep_table.data_ptr(), len(ents), tiles, ctx.dt),
-                           "weights_prepare_multi")]
+        table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.ctx.device)
+        return table, (table.data_ptr(), len(ents), tiles, self.ctx.dt)
+
+    def split_kernels_at(self, name):
+        """Two update segments of the kernel tensors: those before `name` / from `name` on (own tables), so the later
+        segment can be updated as soon as ITS gradients are complete."""
+        names = list(self.nat)
+        k = names.index(name)
+        self._segments = [self._kernel_table(names[:k]), self._kernel_table(names[k:])]
+
+    def adam_begin_ops(self, lr, b1, b2):
+        return [(self.ctx.lib.gan_adam_begin, (self.step.data_ptr(), self.lr_t.data_ptr(), lr, b1, b2), "adam_begin")]
+
+    def adam_segment_ops(self, seg, b1, b2, eps=1e-7, grad_scale=1.0, vectors=False):
+        """Fused Adam + NK refresh of kernel segment `seg` (split_kernels_at), optionally followed by the vectors'
+        plain Adam.  gan_adam_begin must already have run this step."""
+        lib = self.ctx.lib
+        ptrs = (self.master.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), self.grad.data_ptr())
+        ops = [(lib.gan_adam_prepare_multi, self._segments[seg][1] + ptrs + (self.lr_t.data_ptr(), b1, b2, eps, grad_scale),
+                "adam_prepare_multi")]
+        nvec = self.total - self.vec_start
+        if vectors and nvec > 0:
+            ops.append((lib.gan_adam_tf, tuple(p_ + 4 * self.vec_start for p_ in ptrs) + (nvec, self.lr_t.data_ptr(), b1, b2, eps, grad_scale),
+                        "adam_tf"))
+        return ops
 
     def ptr(self, name, which='master'):
         return getattr(self, which).data_ptr() + 4 * self.entries[name][0]
@@ -196,7 +224,7 @@ class ParamSet:
         """Keras Adam (base_gan.py:247-252): the kernels in one launch fused with the refresh of their NK copies, the
         vectors (norm parameters, biases) in a second, small one."""
         lib = self.ctx.lib
-        table_ptr, n_ents, tiles, dt = self._prep_ops[0][1]
+        table_ptr, n_ents, tiles, dt = self._prep_args
         ptrs = (self.master.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), self.grad.data_ptr())
         ops = [(lib.gan_adam_begin, (self.step.data_ptr(), self.lr_t.data_ptr(), lr, b1, b2), "adam_begin"),
                (lib.gan_adam_prepare_multi, (table_ptr, n_ents, tiles, dt) + ptrs + (self.lr_t.data_ptr(), b1, b2, eps, grad_scale),
@@ -545,10 +573,12 @@ class GenCall:
             is_w = lambda o: len(o) > 4 and o[4]
             idx = [i for i, o in enumerate(ops) if is_w(o)]
             bounds = [0] + [idx[c] for c in self.wgrad_cuts if 0 < c < len(idx)] + [len(ops)]
-            for lo, hi in zip(bounds[:-1], bounds[1:]):
+            for k, (lo, hi) in enumerate(zip(bounds[:-1], bounds[1:])):
                 self.ctx.run([o for o in ops[lo:hi] if not is_w(o)])
                 self.wgrad_stream.wait_stream(main)
                 self.ctx.run_on([o for o in ops[lo:hi] if is_w(o)], self.wgrad_stream)
+                if k == 0 and getattr(self, 'stage_hook', None) is not None:
+                    self.stage_hook()          # e.g. the optimiser step of the layers whose gradients are now complete
         elif defer_wgrads:
             self.ctx.run([o for o in ops if not (len(o) > 4 and o[4])])
             self._deferred = [o for o in ops if len(o) > 4 and o[4]]

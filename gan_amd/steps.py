@@ -46,7 +46,9 @@ class _StepBase:
         L.check(self.ctx.lib.gan_copy_view(self.ctx.dt, C.byref(src_view), C.byref(dst_view), self.ctx.stream()), "copy_view")
 
     def _run(self, a, b, training=True):
+        self._updating = training          # a full step: parts of the update may be scheduled inside the backward pass
         self._forward_backward(a, b, training)
+        self._updating = False
         if training:
             if self.sync is not None:
                 self.sync()                       # data-parallel gradient exchange (RCCL)
@@ -55,8 +57,13 @@ class _StepBase:
 
     def _update(self):
         gs = self.sync.grad_scale if self.sync is not None else 1.0
+        early = getattr(self, '_early_adam', None)
         for net in self.nets():
-            net.params.adam(self.lr, self.b1, self.b2, grad_scale=gs)
+            if net is early:       # its decoder kernels were updated beside the tail of the backward pass
+                self.ctx.run(net.params.adam_segment_ops(0, self.b1, self.b2, grad_scale=gs, vectors=True))
+            else:
+                net.params.adam(self.lr, self.b1, self.b2, grad_scale=gs)
+        self._early_adam = None
 
     # ---- hipGraph capture of a whole step --------------------------------------------------------
     def capture(self, training=True):
@@ -124,6 +131,7 @@ class Pix2PixStep(_StepBase):
         self.l1_ws = torch.zeros(4096, dtype=torch.float32, device=ctx.device)
         self.bce_ws = torch.zeros(1024, dtype=torch.float32, device=ctx.device)
         self.sync = None             # GradSync for data-parallel runs
+        self._early_adam = None
 
     def nets(self):
         return (self.G, self.D)
@@ -203,9 +211,25 @@ class Pix2PixStep(_StepBase):
                 # the decoder's wgrad GEMMs start on lane 3 once the main chain has passed the decoder, the encoder's
                 # at its end (+2.5 % over one stage at the end; per-op dependencies, mode 5, lose 9 %)
                 g.wgrad_stream, g.wgrad_cuts = lane3, [int(c) for c in os.environ.get('GAN_AMD_WCUT', '8').split(',')]
+                g.stage_hook = None
+                if getattr(self, '_updating', False) and self.sync is None and os.environ.get('GAN_AMD_EARLY_ADAM', '1') == '1':
+                    # the decoder's kernel gradients are complete once its wgrads (stage 1 on lane 3) are done: their
+                    # Adam + NK refresh (HBM-bound) runs on lane 4 beside the encoder's dgrad chain and wgrad GEMMs
+                    P, lane4 = self.G.params, self.ctx.lane_stream(4)
+                    if P._segments is None:
+                        P.split_kernels_at('up0.kernel')
+
+                    def hook():
+                        lane4.wait_stream(lane3)
+                        self.ctx.run_on(P.adam_begin_ops(self.lr, self.b1, self.b2) + P.adam_segment_ops(1, self.b1, self.b2), lane4)
+                    g.stage_hook = hook
+                    self._early_adam = self.G
                 g.backward(use_dgen2=True, defer_wgrads='staged')
+                g.stage_hook = None
                 main.wait_stream(lane2)
                 main.wait_stream(lane3)
+                if self._early_adam is not None:
+                    main.wait_stream(self.ctx.lane_stream(4))
             else:
                 g.backward(use_dgen2=True)
                 d.backward_params()
