@@ -220,9 +220,9 @@ class ParamSet:
         """(Re)build the typed NK weight copies from the fp32 master."""
         self.ctx.run(self._prep_ops)
 
-    def adam(self, lr, b1, b2, eps=1e-7, grad_scale=1.0):
+    def adam(self, lr, b1, b2, eps=1e-7, grad_scale=1.0, stream=None):
         """Keras Adam (base_gan.py:247-252): the kernels in one launch fused with the refresh of their NK copies, the
-        vectors (norm parameters, biases) in a second, small one."""
+        vectors (norm parameters, biases) in a second, small one.  `stream`: that lane instead of the current stream."""
         lib = self.ctx.lib
         table_ptr, n_ents, tiles, dt = self._prep_args
         ptrs = (self.master.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), self.grad.data_ptr())
@@ -233,7 +233,10 @@ class ParamSet:
         if nvec > 0:
             ops.append((lib.gan_adam_tf, tuple(p_ + 4 * self.vec_start for p_ in ptrs) + (nvec, self.lr_t.data_ptr(), b1, b2, eps, grad_scale),
                         "adam_tf"))
-        self.ctx.run(ops)
+        if stream is not None:
+            self.ctx.run_on(ops, stream)
+        else:
+            self.ctx.run(ops)
 
 
 def _norm_spec(spec, name, c, norm):

@@ -57,13 +57,15 @@ class _StepBase:
 
     def _update(self):
         gs = self.sync.grad_scale if self.sync is not None else 1.0
-        early = getattr(self, '_early_adam', None)
+        early, done = getattr(self, '_early_adam', None), getattr(self, '_adam_done', ())
         for net in self.nets():
+            if net in done:        # updated at the end of its own backward chain
+                continue
             if net is early:       # its decoder kernels were updated beside the tail of the backward pass
                 self.ctx.run(net.params.adam_segment_ops(0, self.b1, self.b2, grad_scale=gs, vectors=True))
             else:
                 net.params.adam(self.lr, self.b1, self.b2, grad_scale=gs)
-        self._early_adam = None
+        self._early_adam, self._adam_done = None, ()
 
     # ---- hipGraph capture of a whole step --------------------------------------------------------
     def capture(self, training=True):
@@ -208,6 +210,10 @@ class Pix2PixStep(_StepBase):
                 lane3 = self.ctx.lane_stream(3)
                 lane2.wait_stream(main)
                 self.ctx.run_on(d.params_ops(), lane2)
+                if getattr(self, '_updating', False) and self.sync is None:
+                    # nothing else reads D's weights in this step: its (small) update runs at the end of its own chain
+                    self.D.params.adam(self.lr, self.b1, self.b2, stream=lane2)
+                    self._adam_done = (self.D,)
                 # the decoder's wgrad GEMMs start on lane 3 once the main chain has passed the decoder, the encoder's
                 # at its end (+2.5 % over one stage at the end; per-op dependencies, mode 5, lose 9 %)
                 g.wgrad_stream, g.wgrad_cuts = lane3, [int(c) for c in os.environ.get('GAN_AMD_WCUT', '8').split(',')]
