@@ -169,12 +169,12 @@ class ParamSet:
         table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.ctx.device)
         return table, (table.data_ptr(), len(ents), tiles, self.ctx.dt)
 
-    def split_kernels_at(self, name):
-        """Two update segments of the kernel tensors: those before `name` / from `name` on (own tables), so the later
-        segment can be updated as soon as ITS gradients are complete."""
+    def split_kernels_at(self, *cut_names):
+        """Update segments of the kernel tensors, cut before each of `cut_names` (own tables), so that a segment can be
+        updated as soon as ITS gradients are complete."""
         names = list(self.nat)
-        k = names.index(name)
-        self._segments = [self._kernel_table(names[:k]), self._kernel_table(names[k:])]
+        ks = [0] + [names.index(n) for n in cut_names] + [len(names)]
+        self._segments = [self._kernel_table(names[a:b]) for a, b in zip(ks[:-1], ks[1:])]
 
     def adam_begin_ops(self, lr, b1, b2):
         return [(self.ctx.lib.gan_adam_begin, (self.step.data_ptr(), self.lr_t.data_ptr(), lr, b1, b2), "adam_begin")]
@@ -580,8 +580,8 @@ class GenCall:
                 self.ctx.run([o for o in ops[lo:hi] if not is_w(o)])
                 self.wgrad_stream.wait_stream(main)
                 self.ctx.run_on([o for o in ops[lo:hi] if is_w(o)], self.wgrad_stream)
-                if k == 0 and getattr(self, 'stage_hook', None) is not None:
-                    self.stage_hook()          # e.g. the optimiser step of the layers whose gradients are now complete
+                if getattr(self, 'stage_hook', None) is not None:
+                    self.stage_hook(k)         # e.g. the optimiser step of the layers whose gradients are now complete
         elif defer_wgrads:
             self.ctx.run([o for o in ops if not (len(o) > 4 and o[4])])
             self._deferred = [o for o in ops if len(o) > 4 and o[4]]

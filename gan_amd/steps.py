@@ -61,8 +61,12 @@ class _StepBase:
         for net in self.nets():
             if net in done:        # updated at the end of its own backward chain
                 continue
-            if net is early:       # its decoder kernels were updated beside the tail of the backward pass
-                self.ctx.run(net.params.adam_segment_ops(0, self.b1, self.b2, grad_scale=gs, vectors=True))
+            if net is early:       # some kernel segments were updated beside the backward pass: the rest + the vectors
+                rest = [k for k in range(len(net.params._segments)) if k not in self._early_segs]
+                for j, k in enumerate(rest):
+                    self.ctx.run(net.params.adam_segment_ops(k, self.b1, self.b2, grad_scale=gs, vectors=(j == len(rest) - 1)))
+                if not rest:
+                    self.ctx.run(net.params.adam_segment_ops(0, self.b1, self.b2, grad_scale=gs, vectors=True)[1:])
             else:
                 net.params.adam(self.lr, self.b1, self.b2, grad_scale=gs)
         self._early_adam, self._adam_done = None, ()
@@ -216,18 +220,27 @@ class Pix2PixStep(_StepBase):
                     self._adam_done = (self.D,)
                 # the decoder's wgrad GEMMs start on lane 3 once the main chain has passed the decoder, the encoder's
                 # at its end (+2.5 % over one stage at the end; per-op dependencies, mode 5, lose 9 %)
-                g.wgrad_stream, g.wgrad_cuts = lane3, [int(c) for c in os.environ.get('GAN_AMD_WCUT', '8').split(',')]
+                g.wgrad_stream, g.wgrad_cuts = lane3, [int(c) for c in os.environ.get('GAN_AMD_WCUT', '8,12').split(',')]
                 g.stage_hook = None
                 if getattr(self, '_updating', False) and self.sync is None and os.environ.get('GAN_AMD_EARLY_ADAM', '1') == '1':
-                    # the decoder's kernel gradients are complete once its wgrads (stage 1 on lane 3) are done: their
-                    # Adam + NK refresh (HBM-bound) runs on lane 4 beside the encoder's dgrad chain and wgrad GEMMs
+                    # a segment's kernel gradients are complete once its wgrads (a stage on lane 3) are done: its Adam +
+                    # NK refresh (HBM-bound) runs on lane 4 beside the rest of the backward pass.  Stages: decoder
+                    # (last, up6..up0) | down7..down4 | down3..down0 (the tail, updated after the join with the vectors)
                     P, lane4 = self.G.params, self.ctx.lane_stream(4)
-                    if P._segments is None:
-                        P.split_kernels_at('up0.kernel')
+                    g.wgrad_cuts = [8, 12]          # the segments below are cut at exactly these wgrads
+                    if P._segments is None or len(P._segments) != 3:
+                        P.split_kernels_at('down4.kernel', 'up0.kernel')
+                    nst = len(g.wgrad_cuts)
 
-                    def hook():
+                    self._early_segs = set()
+
+                    def hook(k):
+                        if k >= nst or k > 1:          # the last stage's segment is updated after the join
+                            return
                         lane4.wait_stream(lane3)
-                        self.ctx.run_on(P.adam_begin_ops(self.lr, self.b1, self.b2) + P.adam_segment_ops(1, self.b1, self.b2), lane4)
+                        ops = P.adam_begin_ops(self.lr, self.b1, self.b2) if k == 0 else []
+                        self.ctx.run_on(ops + P.adam_segment_ops(2 - k, self.b1, self.b2), lane4)
+                        self._early_segs.add(2 - k)
                     g.stage_hook = hook
                     self._early_adam = self.G
                 g.backward(use_dgen2=True, defer_wgrads='staged')
