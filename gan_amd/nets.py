@@ -455,6 +455,8 @@ class GenCall:
         x = self.xin.view()
         for i in range(8):
             name = f'down{i}'
+            if i == 3:
+                self.fwd_inner_start = len(fwd)      # from here on (M <= 4096 rows) the layers leave most of the chip idle
             w = P.tr[name + '.kernel']
             if i == 0:      # conv -> LeakyReLU fused in the GEMM epilogue (apply_norm=False, base_gan.py:180)
                 fwd.append(bd.conv('conv_fwd', x, a_down(0), w.data_ptr(), G_DOWN[0], 2, None, 'lrelu', k_real=C_))
@@ -554,10 +556,17 @@ class GenCall:
         dst = self.xin.view(0, self.C)
         L.check(self.ctx.lib.gan_copy_view(self.ctx.dt, C.byref(src_view), C.byref(dst), self.ctx.stream()), "copy_view")
 
-    def forward(self):
+    def forward(self, inner_hook=None):
+        """inner_hook: called when the op list reaches the inner layers (down3): a place to start independent work on
+        another lane that then runs beside the launch-latency-bound part of the generator."""
         if self.auto_masks:
             self.ctx.run(self.mask_ops)
-        self.ctx.run(self.fwd_ops)
+        if inner_hook is None:
+            self.ctx.run(self.fwd_ops)
+        else:
+            self.ctx.run(self.fwd_ops[:self.fwd_inner_start])
+            inner_hook()
+            self.ctx.run(self.fwd_ops[self.fwd_inner_start:])
 
     def out_view(self):
         return self.out.view(0, self.C)
@@ -670,6 +679,29 @@ class DiscCall:
 
     def forward(self):
         self.ctx.run(self.fwd_ops)
+
+    def forward_part_ops(self, call, lane=0):
+        """Forward of ONE invocation (batch slice `call`) as its own op list: the same results as the batched forward
+        (statistics are per invocation anyway), usable on another lane - D(real) does not depend on the generator."""
+        key = ('F', call, lane)
+        if key not in self._cache:
+            bd, P, net, B = (self._bd2 if lane == 2 else self._bd), self.net.params, self.net, self.B
+            n0, gper = call * B, self.gper
+            sv = lambda buf: buf.view(0, None, n0, B)
+            ops = [bd.conv('conv_fwd', sv(self.xin), sv(self.a0), P.tr['down0.kernel'].data_ptr(), 64, 2, None, 'lrelu', k_real=net.cin)]
+            prev = self.a0
+            for name, co, stride in self.LAYERS[1:4]:
+                ops.append(bd.conv('conv_fwd', sv(prev), sv(self.y[name]), P.tr[name + '.kernel'].data_ptr(), co, stride,
+                                   stats_groups=gper))
+                mean, rstd = self.stats[name]
+                lo, hi = call * gper * co, (call + 1) * gper * co
+                ops += bd.norm_fwd(name, sv(self.y[name]), sv(self.a[name]), gper, mean[lo:hi], rstd[lo:hi], 'lrelu', None,
+                                   fused_chunks=bd.last_stats_chunks, fused_ptr=bd.last_stats_ptr)
+                prev = self.a[name]
+            ops.append(bd.conv('conv_fwd', sv(prev), sv(self.logits), P.tr['last.kernel'].data_ptr(), 1, 1,
+                               P.ptr('last.bias'), None, 1))
+            self._cache[key] = ops
+        return self._cache[key]
 
     def logits_view(self, call):
         """fp32 logits of invocation `call`: (ptr, count)."""

@@ -157,16 +157,33 @@ class Pix2PixStep(_StepBase):
         # inputs -> typed, channel-padded buffers.  D input = concat([inp, tar|gen]) (base_gan.py:139)
         self._pack_multi([(inp, g.xin.view(0, Cc)), (inp, d.xin.view(0, Cc, 0, B)), (inp, d.xin.view(0, Cc, B, B)),
                           (tar, d.xin.view(Cc, Cc, 0, B))])
-        g.forward()                                                   # pix2pix.py:200
+        dreal = self.ctx.ms_mode == 4 and os.environ.get('GAN_AMD_DREAL', '1') == '1'
+        if dreal:
+            # D(real) does not depend on the generator: it starts on lane 2 when G reaches its inner layers (down3 on:
+            # launch-bound layers that leave the chip idle; measured best start point, +0.8 %) and D(fake) follows G on the main chain.  Same
+            # BatchNormalization call order (real, then fake) as pix2pix.py:202-203.
+            main_, lane2_ = self.ctx.lane_stream(0), self.ctx.lane_stream(2)
+
+            def start_dreal():
+                lane2_.wait_stream(main_)
+                self.ctx.run_on(d.forward_part_ops(0, lane=2), lane2_)
+            g.forward(inner_hook=start_dreal)                         # pix2pix.py:200
+        else:
+            g.forward()                                               # pix2pix.py:200
         # generator loss (pix2pix.py:167-188): BCE(1, D(fake)) + lambda * mean|target - gen|; discriminator loss
         # (base_gan.py:233-245, factor 0.5 at pix2pix.py:206) - the L1 term (it only needs G's output: beside D's
         # forward when lanes are on), then all three BCE terms in one pass
         side = self.ctx.lane_stream(2) if self.ctx.ms_mode == 4 else None
+        if dreal:
+            self.ctx.lane_stream(0).wait_stream(side)                 # D(real) done (its BatchNorm updates come first)
         if side is not None:
             side.wait_stream(self.ctx.lane_stream(0))
         self._l1(g.out_view(), d.xin.view(Cc, Cc, 0, B), 2, 1.0, False, self.lam, g.dgen.view(0, Cc), stream=side)
         self._copy(g.out_view(), d.xin.view(Cc, Cc, B, B))
-        d.forward()                                                   # pix2pix.py:202-203 (real ++ fake)
+        if dreal:
+            self.ctx.run(d.forward_part_ops(1))                       # pix2pix.py:203
+        else:
+            d.forward()                                               # pix2pix.py:202-203 (real ++ fake)
         if side is not None:
             self.ctx.lane_stream(0).wait_stream(side)
         real_ptr, cnt = d.logits_view(0)
