@@ -204,14 +204,29 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_gemm_kernel(const
     for (int s = 0; s < KSTEPS; ++s) {
       const unsigned sw = s ? sw1 : sw0;
 #pragma unroll
+#ifdef GAN_ABLATE_FRAGS   // timing experiment only (wrong results): GAN_ABLATE_FRAGS of the MT / NT fragment reads, re-used
+      for (int i = 0; i < MT; ++i)
+        if (i < GAN_ABLATE_FRAGS) asm volatile("ds_read_b128 %0, %1" : "=v"(af[s][i]) : "v"(sbase + a_off + i * 16 * BKB + sw));
+        else af[s][i] = af[s][0];
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+        if (j < GAN_ABLATE_FRAGS) asm volatile("ds_read_b128 %0, %1" : "=v"(bfr[s][j]) : "v"(sbase + b_off + j * 16 * BKB + sw));
+        else bfr[s][j] = bfr[s][0];
+    }
+#else
       for (int i = 0; i < MT; ++i) asm volatile("ds_read_b128 %0, %1" : "=v"(af[s][i]) : "v"(sbase + a_off + i * 16 * BKB + sw));
 #pragma unroll
       for (int j = 0; j < NT; ++j) asm volatile("ds_read_b128 %0, %1" : "=v"(bfr[s][j]) : "v"(sbase + b_off + j * 16 * BKB + sw));
     }
+#endif
 #pragma unroll
     for (int s = 0; s < KSTEPS; ++s) {
+#ifdef GAN_ABLATE_FRAGS
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
       if (s + 1 < KSTEPS) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(MT + NT) : "memory");
       else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
