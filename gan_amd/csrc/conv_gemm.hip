@@ -260,7 +260,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_gemm_kernel(const
     else if (NS >= 4 && pending == 2) wait_vmcnt<2 * PT>();
     else if (NS >= 3 && pending == 1) wait_vmcnt<PT>();
     else wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
+    if (!(p.debug & 64)) __builtin_amdgcn_s_barrier();      // (64: timing experiment without the per-step barrier; only with 2)
     // (spreading the piece issues between the MFMAs instead of this burst measured 5 % slower)
     if (i + NS - 1 < nk && !(p.debug & 2)) issue(kc_begin + i + NS - 1, st_i);
     if (!(p.debug & 1)) compute(st_c, false, st_i);
