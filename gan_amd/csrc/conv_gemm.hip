@@ -24,7 +24,13 @@
 #include <type_traits>
 #include "conv_params.h"
 
-__device__ uint4 g_zero_page[8];   // 128 B of zeros: source of padding taps / out-of-range rows
+#ifdef GAN_DIAG   // diagnostic build only (tools/diag_build.sh): in-kernel wall-clock stamps per block, 100 MHz ticks
+static unsigned long long* g_diag = nullptr;
+extern "C" void gan_diag_set(void* ptr) { g_diag = (unsigned long long*)ptr; }
+#define DIAG_STAMP(i) do { if (p.diag && tid == 0) p.diag[(size_t)(blockIdx.x + gridDim.x * blockIdx.z) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define DIAG_STAMP(i) do {} while (0)
+#endif
 
 template <typename T> struct Mma;
 template <> struct Mma<bf16_t> {
@@ -63,6 +69,137 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned char* lds_wave
 }
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// Epilogue shared by the GEMM kernels.  The MFMAs ran with the weights as the "A" operand, so the accumulators hold
+// the transposed tile: acc[i][j][e] = Y[pixel row i*16 + (lane & 15)][channel j*16 + (lane >> 4)*4 + e] - four
+// consecutive channels of one pixel per lane, which pack into one 8-byte (bf16) / 16-byte (fp32) write.  SMEMB bytes of
+// LDS at `smem` are free for staging (the caller has passed a block barrier after its last LDS read).
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int SMEMB>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[BM / WAVES_M / 16][BN / WAVES_N / 16],
+                                              unsigned char* smem, int bm0, int bn0, int par, int P, int split) {
+  constexpr int VEC = VecOf<T>::N;
+  constexpr int NW = WAVES_M * WAVES_N, NTHREADS = 64 * NW;
+  constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N, MT = WTM / 16, NT = WTN / 16;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int r = lane & 15, q = lane >> 4;
+  const int py = par >> 1, px = par & 1;
+  if (p.splits > 1) {
+    float* slab = p.slab + (size_t)(par * p.splits + split) * p.M * p.NslabPitch;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int m = bm0 + wm * WTM + i * 16 + r;
+      if (m < p.M) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          *(f32x4*)(slab + (size_t)m * p.NslabPitch + bn0 + wn * WTN + j * 16 + q * 4) = acc[i][j];
+      }
+    }
+  } else if (p.vec_store) {
+    // stage the tile (bias + activation applied) as T in LDS, then coalesced 16-byte row stores.  The whole
+    // stage/table area is free now, so as many 16-row groups per wave-row as fit are staged per pass (one
+    // pass for bf16 tiles): IPP = largest divisor of MT whose rows fit.
+    constexpr int CS = BN * (int)sizeof(T) + (sizeof(T) == 2 ? 32 : 16);
+    constexpr int VPR = BN / VEC;
+    constexpr int MAXG = SMEMB / (CS * WAVES_M * 16);          // 16-row groups per wave-row that fit
+    constexpr int IPP = MAXG >= MT ? MT : (MAXG >= MT / 2 && MT % 2 == 0 ? MT / 2 : (MAXG >= MT / 4 && MT % 4 == 0 ? MT / 4 : 1));
+    static_assert(MAXG >= 1, "staging tile does not fit");
+    unsigned char* Cs = smem;
+    float bv[NT][4];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int n = bn0 + wn * WTN + j * 16 + q * 4 + e;
+        bv[j][e] = (p.bias && n < p.Cout) ? p.bias[n] : 0.f;
+      }
+    // fused normalisation statistics: per-column (sum, sum of squares) of the STORED values of this tile
+    // a thread sums one 16-byte column group (VEC channels) over a slice of the staged rows
+    constexpr int CG = BN / VEC, SL = NTHREADS / CG;          // column groups; row slices (NTHREADS >= BN)
+    const int scg = tid % CG, sslice = tid / CG;
+    float ssum[VEC], ssq[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) ssum[e] = ssq[e] = 0.f;
+#pragma unroll
+    for (int ip = 0; ip < MT / IPP; ++ip) {
+      if (ip) __syncthreads();
+      // activation resolved once per pass, not per element (the run-time select chain over 64 accumulators per
+      // lane was ~3 us of the epilogue)
+      auto stage = [&](auto actc) {
+        constexpr int ACT = decltype(actc)::value;
+#pragma unroll
+        for (int ii = 0; ii < IPP; ++ii)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = act_c<ACT>(acc[ip * IPP + ii][j][e] + bv[j][e], p.slope);
+            T* dst = (T*)(Cs + ((wm * IPP + ii) * 16 + r) * CS) + wn * WTN + j * 16 + q * 4;
+            if constexpr (sizeof(T) == 2) *(uint2*)dst = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+            else *(f32x4*)dst = f32x4{v[0], v[1], v[2], v[3]};
+          }
+      };
+      if (p.act == GAN_ACT_NONE) stage(std::integral_constant<int, GAN_ACT_NONE>{});
+      else if (p.act == GAN_ACT_LRELU) stage(std::integral_constant<int, GAN_ACT_LRELU>{});
+      else if (p.act == GAN_ACT_RELU) stage(std::integral_constant<int, GAN_ACT_RELU>{});
+      else stage(std::integral_constant<int, GAN_ACT_TANH>{});
+      __syncthreads();
+      for (int idx = tid; idx < WAVES_M * IPP * 16 * VPR; idx += NTHREADS) {
+        const int sr = idx / VPR, v = idx % VPR;
+        const int g16 = sr >> 4;
+        const int m = bm0 + (g16 / IPP) * WTM + (ip * IPP + g16 % IPP) * 16 + (sr & 15), n = bn0 + v * VEC;
+        if (m < p.M && n < p.Cout)
+          *(uint4*)((T*)p.y + out_pixel_offset(p, m, py, px) + n) = *(const uint4*)(Cs + sr * CS + v * 16);
+      }
+      if (p.stats) {
+        for (int sr = sslice; sr < WAVES_M * IPP * 16; sr += SL) {
+          const int g16 = sr >> 4;
+          const int m = bm0 + (g16 / IPP) * WTM + (ip * IPP + g16 % IPP) * 16 + (sr & 15);
+          if (m < p.M) {
+            float v[VEC];
+            unpack16<T>(*(const uint4*)(Cs + sr * CS + scg * 16), v);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) { ssum[e] += v[e]; ssq[e] += v[e] * v[e]; }
+          }
+        }
+      }
+    }
+    if (p.stats) {
+      __syncthreads();
+      float* red = (float*)smem;                               // [SL][BN][2]
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        red[(sslice * BN + scg * VEC + e) * 2] = ssum[e]; red[(sslice * BN + scg * VEC + e) * 2 + 1] = ssq[e];
+      }
+      __syncthreads();
+      if (tid < BN && bn0 + tid < p.Cout) {
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int k = 0; k < SL; ++k) { a += red[(k * BN + tid) * 2]; b += red[(k * BN + tid) * 2 + 1]; }
+        // chunk index: (tile within its group) * P + parity; groups are whole numbers of M tiles
+        const int tm = bm0 / BM, grp = tm / p.stats_tpg, chunk = (tm % p.stats_tpg) * P + par;
+        float* dst = p.stats + (((size_t)grp * p.stats_tpg * P + chunk) * p.stats_C + bn0 + tid) * 2;
+        dst[0] = a; dst[1] = b;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int m = bm0 + wm * WTM + i * 16 + r;
+      if (m < p.M) {
+        const size_t po = out_pixel_offset(p, m, py, px);
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int n = bn0 + wn * WTN + j * 16 + q * 4 + e;
+            if (n < p.Cout) store_out<T>(p, po, n, acc[i][j][e]);
+          }
+      }
+    }
+  }
+}
 
 // BKB: bytes of K per LDS row / pipeline step (128 or 64); NS: LDS stages (NS-1 tiles in flight)
 template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int BKB, int NS>
@@ -113,7 +250,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_gemm_kernel(const
   // 0x80000000 for zero padding / rows past M.  Loads go through buffer descriptors, whose range check turns
   // such offsets into zeros, so the K loop spends one LDS read + one add per 1-KiB piece on addressing.
   int* tbl = (int*)(smem + NS * STAGE);       // [T][BM]
-  for (int e = tid; e < ((p.debug & 8) ? 0 : p.T * BM); e += NTHREADS) {
+  for (int e = tid; e < p.T * BM; e += NTHREADS) {
     const int row = e % BM, tap = e / BM;
     const int m = bm0 + row;
     int off = (int)0x80000000;
@@ -204,29 +341,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_gemm_kernel(const
     for (int s = 0; s < KSTEPS; ++s) {
       const unsigned sw = s ? sw1 : sw0;
 #pragma unroll
-#ifdef GAN_ABLATE_FRAGS   // timing experiment only (wrong results): GAN_ABLATE_FRAGS of the MT / NT fragment reads, re-used
-      for (int i = 0; i < MT; ++i)
-        if (i < GAN_ABLATE_FRAGS) asm volatile("ds_read_b128 %0, %1" : "=v"(af[s][i]) : "v"(sbase + a_off + i * 16 * BKB + sw));
-        else af[s][i] = af[s][0];
-#pragma unroll
-      for (int j = 0; j < NT; ++j)
-        if (j < GAN_ABLATE_FRAGS) asm volatile("ds_read_b128 %0, %1" : "=v"(bfr[s][j]) : "v"(sbase + b_off + j * 16 * BKB + sw));
-        else bfr[s][j] = bfr[s][0];
-    }
-#else
       for (int i = 0; i < MT; ++i) asm volatile("ds_read_b128 %0, %1" : "=v"(af[s][i]) : "v"(sbase + a_off + i * 16 * BKB + sw));
 #pragma unroll
       for (int j = 0; j < NT; ++j) asm volatile("ds_read_b128 %0, %1" : "=v"(bfr[s][j]) : "v"(sbase + b_off + j * 16 * BKB + sw));
     }
-#endif
 #pragma unroll
     for (int s = 0; s < KSTEPS; ++s) {
-#ifdef GAN_ABLATE_FRAGS
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#else
       if (s + 1 < KSTEPS) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(MT + NT) : "memory");
       else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
@@ -260,123 +382,240 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_gemm_kernel(const
     else if (NS >= 4 && pending == 2) wait_vmcnt<2 * PT>();
     else if (NS >= 3 && pending == 1) wait_vmcnt<PT>();
     else wait_vmcnt<0>();
-    if (!(p.debug & 64)) __builtin_amdgcn_s_barrier();      // (64: timing experiment without the per-step barrier; only with 2)
+    __builtin_amdgcn_s_barrier();
     // (spreading the piece issues between the MFMAs instead of this burst measured 5 % slower)
-    if (i + NS - 1 < nk && !(p.debug & 2)) issue(kc_begin + i + NS - 1, st_i);
-    if (!(p.debug & 1)) compute(st_c, false, st_i);
+    if (i + NS - 1 < nk) issue(kc_begin + i + NS - 1, st_i);
+    compute(st_c, false, st_i);
     st_c = st_c + 1 == NS ? 0 : st_c + 1;
     st_i = st_i + 1 == NS ? 0 : st_i + 1;
   }
   __syncthreads();
 
-  // epilogue.  The MFMAs ran with the weights as the "A" operand, so the accumulators hold the transposed tile:
-  // acc[i][j][e] = Y[pixel row i*16 + (lane & 15)][channel j*16 + (lane >> 4)*4 + e] - four consecutive channels of
-  // one pixel per lane, which pack into one 8-byte (bf16) / 16-byte (fp32) write.
-  if (p.debug & 4) return;   // timing experiment: no epilogue
-  if (p.splits > 1) {
-    float* slab = p.slab + (size_t)(par * p.splits + split) * p.M * p.NslabPitch;
+  gemm_epilogue<T, BM, BN, WAVES_M, WAVES_N, NS * STAGE + 16 * BM * 4>(p, acc, smem, bm0, bn0, par, P, split);
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------
+// "Ping-pong" kernel for the 256-row tiles (256x256 and 256x128; 8 waves as 2 (M) x 4 (N), one block per CU).
+//
+// A K tile (128 bytes of K per row) is multiplied in PH phases of 16 MFMA steps per wave (a 64-row x 32-column piece of
+// the wave's accumulator tile).  Each phase is a LOAD segment (fragment ds_reads for this phase + PP LDS-DMA pieces of a
+// tile DP phases ahead + a counted vmcnt) and a MATH segment (the MFMAs), with a block barrier after each.  Waves 4..7
+// (the second wave on every SIMD) run one barrier behind waves 0..3, so on every SIMD one wave is in its MATH segment
+// while its partner is in its LOAD segment: the matrix pipe is fed without any wave having to overlap its own loads
+// with its own math.  LDS-DMA pieces stay in flight across barriers (counted vmcnt, never 0 inside the loop).
+//
+// Ordering rules (g = phase number; group 0 = waves 0..3, group 1 = waves 4..7; group 0 runs LOAD(g) in barrier interval
+// 2g and MATH(g) in 2g+1, group 1 in 2g+1 and 2g+2):
+//   RAW: a piece first read in phase r must be covered by the vmcnt at the end of LOAD(r-1) of EVERY wave: after issuing
+//        the pieces of phase r-1+DP at most VMW pieces may be outstanding.
+//   WAR: a piece slot is re-filled NB K tiles later; its LDS-DMA is issued in LOAD(g') with g' >= (last phase whose
+//        LOAD segment reads the old contents) + 2, because those reads are only known complete at the lgkmcnt(0) that
+//        opens the reader's MATH segment.  The B fragments of the first column half are kept in registers for the
+//        tile's last phase (256x256) so that no phase re-reads a half that is about to be re-staged.
+// Piece slots of a K tile per wave, in staging order, and the phase that first reads them:
+//   256x256 (PH 4, PP 2, DP 5, VMW 6, NB 2): A0 A0 | B0 B0 | B1 B1 | A1 A1   first read in phase 0 0 0 0 1 1 2 2
+//   256x128 (PH 2, PP 3, DP 4, VMW 8, NB 3): A0 A0 B | B A1 A1               first read in phase 0 0 0 0 1 1
+// (Issuing the pieces between the MFMAs of the MATH segment instead measured 25 % slower.)
+// (A0/A1: the first/second 64 rows of each wave-row's 128 rows; B0/B1: the first/second 32 columns of each wave's 64.)
+// K tiles past the end of the block's K range are staged as out-of-range pieces (zeros, no memory traffic), which keeps
+// the vmcnt arithmetic uniform to the last phase.
+//
+// The im2col gather needs no table: a lane serves the same 4 tile rows for every K tile, so it keeps, per row, the byte
+// offset of the row's window origin and a 16-bit mask of the taps that fall inside the source map; a piece's source
+// offset is origin + (wave-uniform tap/channel offset) or 0x80000000 (range-checked to zeros).
+template <int IMM> __device__ __forceinline__ void lds_read128(uint4& d, unsigned addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(IMM));
+}
+template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (N > 0) { static_for<N - 1>(f); f(std::integral_constant<int, N - 1>{}); }
+}
+
+template <typename T, int BN>
+__global__ __launch_bounds__(512) void conv_gemm_pp_kernel(const GemmParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int BM = 256, WAVES_M = 2, WAVES_N = 4, BKB = 128;
+  constexpr int WTN = BN / 4, MT = 8, NT = WTN / 16;        // wave tile 128 x (64 | 32)
+  constexpr int PH = BN == 256 ? 4 : 2;
+  constexpr int NB = BN == 256 ? 2 : 3;
+  constexpr int PP = BN == 256 ? 2 : 3;
+  constexpr int DP = BN == 256 ? 5 : 4;
+  constexpr int VMW = BN == 256 ? 6 : 8;
+  constexpr int QS = PP * PH;                               // piece slots per wave per K tile
+  constexpr int STAGE = (BM + BN) * BKB;
+  constexpr int ES = sizeof(T);
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x;
+  DIAG_STAMP(0);
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int r = lane & 15, q = lane >> 4;
+
+  // tile order: as conv_gemm_kernel (XCD-contiguous, parity fastest)
+  const int P = p.parity ? 4 : 1;
+  int bid = blockIdx.x;
+  const int nb = p.tilesM * p.tilesN * P;
+  if ((nb & 7) == 0) bid = (bid & 7) * (nb >> 3) + (bid >> 3);
+  const int par = bid % P;
+  bid /= P;
+  const int bm0 = (bid / p.tilesN) * BM, bn0 = (bid % p.tilesN) * BN;
+  const int split = blockIdx.z;
+  const int py = par >> 1, px = par & 1;
+  int dy0 = p.dy0, dx0 = p.dx0, wy0 = p.wy0, wx0 = p.wx0;
+  if (p.parity) { dy0 = py; dx0 = px; wy0 = 1 - py; wx0 = 1 - px; }
+  const int twmask = (1 << p.TWlog2) - 1, TW = 1 << p.TWlog2;
+
+  // ---- per-lane gather state ---------------------------------------------------------------------------
+  const int lrow = lane >> 3, slot = lane & 7;
+  const int chunkB = ((slot ^ lrow) << 4);                  // swizzled 16-byte K chunk this lane fetches for its LDS slot
+  int a_org[2][2];                                          // [half][k]: byte offset of the row's window origin (+ chunk)
+  unsigned a_msk[2][2];                                     // taps inside the source map
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      const int m = bm0 + wm * WTM + i * 16 + r;
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int m = bm0 + (k * 16 + 8 * h + wave) * 8 + lrow;
+      unsigned msk = 0;
+      int org = 0;
       if (m < p.M) {
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-          *(f32x4*)(slab + (size_t)m * p.NslabPitch + bn0 + wn * WTN + j * 16 + q * 4) = acc[i][j];
+        const unsigned t = fdiv((unsigned)m, p.divWg);
+        const int gx = m - (int)t * p.Wg;
+        const unsigned img = fdiv(t, p.divHg);
+        const int gy = (int)t - (int)img * p.Hg;
+        const int sy0 = gy * p.S + dy0, sx0 = gx * p.S + dx0;
+        unsigned vx = 0;
+        for (int tx = 0; tx < TW; ++tx) vx |= ((unsigned)(sx0 + tx * p.dstep) < (unsigned)p.Ws ? 1u : 0u) << tx;
+        for (int ty = 0; ty < TW; ++ty)
+          if ((unsigned)(sy0 + ty * p.dstep) < (unsigned)p.Hs) msk |= vx << (ty << p.TWlog2);
+        org = (int)((((long long)((int)img * p.Hs + sy0) * p.Ws + sx0) * (long long)p.xpitch) * ES) + chunkB;
       }
+      a_org[h][k] = org; a_msk[h][k] = msk;
     }
-  } else if (p.vec_store) {
-    // stage the tile (bias + activation applied) as T in LDS, then coalesced 16-byte row stores.  The whole
-    // stage/table area is free now, so as many 16-row groups per wave-row as fit are staged per pass (one
-    // pass for bf16 tiles): IPP = largest divisor of MT whose rows fit.
-    constexpr int CS = BN * (int)sizeof(T) + (sizeof(T) == 2 ? 32 : 16);
-    constexpr int VPR = BN / VEC;
-    constexpr int SMEMB = NS * STAGE + 16 * BM * 4;
-    constexpr int MAXG = SMEMB / (CS * WAVES_M * 16);          // 16-row groups per wave-row that fit
-    constexpr int IPP = MAXG >= MT ? MT : (MAXG >= MT / 2 && MT % 2 == 0 ? MT / 2 : (MAXG >= MT / 4 && MT % 4 == 0 ? MT / 4 : 1));
-    static_assert(MAXG >= 1, "staging tile does not fit");
-    unsigned char* Cs = smem;
-    float bv[NT][4];
+  constexpr int BK_ = BN == 256 ? 4 : 2;                    // B pieces per wave per K tile
+  int b_org[BK_];
 #pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int n = bn0 + wn * WTN + j * 16 + q * 4 + e;
-        bv[j][e] = (p.bias && n < p.Cout) ? p.bias[n] : 0.f;
-      }
-    // fused normalisation statistics: per-column (sum, sum of squares) of the STORED values of this tile
-    constexpr int SL = NTHREADS / BN;                         // row slices per column (NTHREADS >= BN)
-    const int scol = tid % BN, sslice = tid / BN;
-    float ssum = 0.f, ssq = 0.f;
-#pragma unroll
-    for (int ip = 0; ip < MT / IPP; ++ip) {
-      if (ip) __syncthreads();
-      // activation resolved once per pass, not per element (the run-time select chain over 64 accumulators per
-      // lane was ~3 us of the epilogue)
-      auto stage = [&](auto actc) {
-        constexpr int ACT = decltype(actc)::value;
-#pragma unroll
-        for (int ii = 0; ii < IPP; ++ii)
-#pragma unroll
-          for (int j = 0; j < NT; ++j) {
-            float v[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = act_c<ACT>(acc[ip * IPP + ii][j][e] + bv[j][e], p.slope);
-            T* dst = (T*)(Cs + ((wm * IPP + ii) * 16 + r) * CS) + wn * WTN + j * 16 + q * 4;
-            if constexpr (sizeof(T) == 2) *(uint2*)dst = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
-            else *(f32x4*)dst = f32x4{v[0], v[1], v[2], v[3]};
-          }
-      };
-      if (p.act == GAN_ACT_NONE) stage(std::integral_constant<int, GAN_ACT_NONE>{});
-      else if (p.act == GAN_ACT_LRELU) stage(std::integral_constant<int, GAN_ACT_LRELU>{});
-      else if (p.act == GAN_ACT_RELU) stage(std::integral_constant<int, GAN_ACT_RELU>{});
-      else stage(std::integral_constant<int, GAN_ACT_TANH>{});
-      __syncthreads();
-      for (int idx = tid; idx < WAVES_M * IPP * 16 * VPR; idx += NTHREADS) {
-        const int sr = idx / VPR, v = idx % VPR;
-        const int g16 = sr >> 4;
-        const int m = bm0 + (g16 / IPP) * WTM + (ip * IPP + g16 % IPP) * 16 + (sr & 15), n = bn0 + v * VEC;
-        if (m < p.M && n < p.Cout)
-          *(uint4*)((T*)p.y + out_pixel_offset(p, m, py, px) + n) = *(const uint4*)(Cs + sr * CS + v * 16);
-      }
-      if (p.stats && SL >= 1 && sslice < SL) {
-        for (int sr = sslice; sr < WAVES_M * IPP * 16; sr += SL) {
-          const int g16 = sr >> 4;
-          const int m = bm0 + (g16 / IPP) * WTM + (ip * IPP + g16 % IPP) * 16 + (sr & 15);
-          if (m < p.M) { const float v = ld_f((const T*)(Cs + sr * CS) + scol); ssum += v; ssq += v * v; }
-        }
-      }
-    }
-    if (p.stats) {
-      __syncthreads();
-      float* red = (float*)smem;                               // [SL][BN][2]
-      if (sslice < SL) { red[(sslice * BN + scol) * 2] = ssum; red[(sslice * BN + scol) * 2 + 1] = ssq; }
-      __syncthreads();
-      if (tid < BN && bn0 + tid < p.Cout) {
-        float a = 0.f, b = 0.f;
-#pragma unroll
-        for (int k = 0; k < SL; ++k) { a += red[(k * BN + tid) * 2]; b += red[(k * BN + tid) * 2 + 1]; }
-        // chunk index: (tile within its group) * P + parity; groups are whole numbers of M tiles
-        const int tm = bm0 / BM, grp = tm / p.stats_tpg, chunk = (tm % p.stats_tpg) * P + par;
-        float* dst = p.stats + (((size_t)grp * p.stats_tpg * P + chunk) * p.stats_C + bn0 + tid) * 2;
-        dst[0] = a; dst[1] = b;
-      }
-    }
-  } else {
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      const int m = bm0 + wm * WTM + i * 16 + r;
-      if (m < p.M) {
-        const size_t po = out_pixel_offset(p, m, py, px);
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int n = bn0 + wn * WTN + j * 16 + q * 4 + e;
-            if (n < p.Cout) store_out<T>(p, po, n, acc[i][j][e]);
-          }
-      }
-    }
+  for (int i = 0; i < BK_; ++i) {
+    // 256: i = h*2 + k -> piece (wave>>2)*8 + 16k + 4h + (wave&3);  128: i = k -> piece wave + 8k
+    const int pb = BN == 256 ? ((wave >> 2) * 8 + 16 * (i & 1) + 4 * (i >> 1) + (wave & 3)) : (wave + 8 * i);
+    const int n = bn0 + pb * 8 + lrow;
+    b_org[i] = n < p.Wrows ? (int)((size_t)n * p.Cin * ES) + chunkB : (int)0x80000000;
   }
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.xbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.wbytes, 0x00020000);
+  const int wtapbytes = p.Wrows * p.Cin * ES;
+  const int pixbytes = p.xpitch * ES;
+
+  const int kc_begin = (int)((long long)p.kchunks * split / p.splits);
+  const int kc_end = (int)((long long)p.kchunks * (split + 1) / p.splits);
+  const int nk = kc_end - kc_begin;
+
+  // issue piece slots [I0, I0 + CNT) of K tile ts (ts >= nk: out-of-range pieces)
+  auto issue_slots = [&](auto I0c, auto CNTc, int ts) {
+    constexpr int I0 = decltype(I0c)::value, CNT = decltype(CNTc)::value;
+    const int kc = kc_begin + ts;
+    const bool live = ts < nk;
+    const int tap = kc & (p.T - 1);
+    const int coff = (kc >> p.log2T) * BKB;                // K order: channel chunk major, tap minor
+    const int ty = tap >> p.TWlog2, tx = tap & twmask;
+    const unsigned s_bit = live ? (1u << tap) : 0u;
+    const int s_aoff = (ty * p.dstep * p.Ws + tx * p.dstep) * pixbytes + coff;
+    const int s_boff = live ? ((wy0 + ty * p.wstep) * 4 + (wx0 + tx * p.wstep)) * wtapbytes + coff : (int)0x80000000;
+    unsigned char* st = smem + (ts % NB) * STAGE;
+    static_for<CNT>([&](auto Ic) {
+      constexpr int i = I0 + decltype(Ic)::value;
+      // slot -> (operand, half, k)
+      constexpr bool isA = BN == 256 ? (i < 2 || i >= 6) : (i < 2 || i >= 4);
+      if constexpr (isA) {
+        constexpr int h = i < 2 ? 0 : 1, k = i & 1;
+        const int pa = k * 16 + 8 * h + wave;
+        const int off = (a_msk[h][k] & s_bit) ? a_org[h][k] + s_aoff : (int)0x80000000;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(st + pa * 1024), 16, off, 0, 0, 0);
+      } else {
+        constexpr int bi = BN == 256 ? (i - 2) : (i - 2);  // 256: 0..3 = (h, k) as h*2+k;  128: 0..1 = k
+        constexpr int h = BN == 256 ? (bi >> 1) : 0, k = bi & 1;
+        const int pb = BN == 256 ? ((wave >> 2) * 8 + 16 * k + 4 * h + (wave & 3)) : (wave + 8 * k);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(st + BM * BKB + pb * 1024), 16,
+                                                 b_org[BN == 256 ? h * 2 + k : k] + s_boff, 0, 0, 0);
+      }
+    });
+  };
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // fragment addresses: tile row R, 16-byte K slot c at R*128 + ((c ^ (R & 7)) << 4); k-step s uses slots 4s + q
+  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  const unsigned swz0 = (unsigned)((q ^ (r & 7)) << 4), swz1 = (unsigned)(((4 + q) ^ (r & 7)) << 4);
+  const unsigned a_row = lds_base + (wr * 128 + r) * BKB, b_row = lds_base + BM * BKB + (wc * WTN + r) * BKB;
+
+  DIAG_STAMP(1);
+  // prologue: the first DP phases' worth of pieces
+  static_for<(PP * DP + QS - 1) / QS>([&](auto Tc) {
+    constexpr int t = decltype(Tc)::value;
+    constexpr int cnt = (PP * DP - t * QS) < QS ? (PP * DP - t * QS) : QS;
+    issue_slots(std::integral_constant<int, 0>{}, std::integral_constant<int, cnt>{}, t);
+  });
+  wait_vmcnt<VMW>();
+  __builtin_amdgcn_s_barrier();
+  DIAG_STAMP(2);
+  if (wr == 1) __builtin_amdgcn_s_barrier();              // waves 4..7 run one barrier behind
+
+  uint4 af[2][4], bf0[2][2], bf1[2][2];
+  for (int t = 0; t < nk; ++t) {
+    const unsigned so = (unsigned)((t % NB) * STAGE);
+    const unsigned aA0 = a_row + so + swz0, aA1 = a_row + so + swz1, bB0 = b_row + so + swz0, bB1 = b_row + so + swz1;
+    static_for<PH>([&](auto Pc) {
+      constexpr int ph = decltype(Pc)::value;
+      // ---- LOAD segment ----
+      constexpr int mh = BN == 256 ? ((ph == 0 || ph == 1) ? 0 : 1) : ph;     // row half multiplied in this phase
+      constexpr int nh = BN == 256 ? ((ph == 1 || ph == 2) ? 1 : 0) : 0;      // column half (256x256 only)
+      constexpr bool readA = BN == 256 ? (ph == 0 || ph == 2) : true;
+      constexpr bool readB = BN == 256 ? (ph == 0 || ph == 1) : (ph == 0);
+      if constexpr (readB) {
+        static_for<2>([&](auto Jc) {
+          constexpr int j = decltype(Jc)::value;
+          constexpr int imm = (nh * 2 + j) * 16 * BKB;
+          if constexpr (nh == 0) { lds_read128<imm>(bf0[0][j], bB0); lds_read128<imm>(bf0[1][j], bB1); }
+          else { lds_read128<imm>(bf1[0][j], bB0); lds_read128<imm>(bf1[1][j], bB1); }
+        });
+      }
+      if constexpr (readA) {
+        static_for<4>([&](auto Ic) {
+          constexpr int i = decltype(Ic)::value;
+          constexpr int imm = (mh * 4 + i) * 16 * BKB;
+          lds_read128<imm>(af[0][i], aA0); lds_read128<imm>(af[1][i], aA1);
+        });
+      }
+      constexpr int x0 = PP * (ph + DP);                   // slots of this phase, relative to K tile t
+      issue_slots(std::integral_constant<int, x0 % QS>{}, std::integral_constant<int, PP>{}, t + x0 / QS);
+      wait_vmcnt<VMW>();
+      __builtin_amdgcn_s_barrier();
+      // ---- MATH segment ----
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            Mma<T>::run(acc[mh * 4 + i][nh * 2 + j], nh == 0 ? bf0[s2][j] : bf1[s2][j], af[s2][i]);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_s_barrier();
+    });
+  }
+  if (wr == 0) __builtin_amdgcn_s_barrier();
+  wait_vmcnt<0>();
+  __syncthreads();
+  DIAG_STAMP(3);
+  gemm_epilogue<T, BM, BN, WAVES_M, WAVES_N, NB * STAGE>(p, acc, smem, bm0, bn0, par, P, split);
+  DIAG_STAMP(4);
 #endif
 }
 
@@ -471,6 +710,7 @@ static int tune(const char* name, int dflt) {   // GAN_AMD_<name> overrides a pl
 struct GemmPlan {
   GemmParams p;
   int BM, BN, P, stats_chunks;
+  bool pp;                 // 256-row tile on the ping-pong kernel
   dim3 grid;
   size_t slab_bytes;
 };
@@ -495,7 +735,6 @@ static int plan_gemm(const GanConvDesc* d, int op, GemmPlan* pl) {
   }
   p.Nimg = x.n; p.Hs = x.h; p.Ws = x.w; p.xpitch = x.pitch; p.Cin = x.c; p.log2_cvecs = l2;
   p.Wrows = d->w_rows; p.Ho = y.h; p.Wo = y.w; p.ypitch = y.pitch; p.Cout = y.c;
-  { static int dbg = -1; if (dbg < 0) { const char* e = getenv("GAN_AMD_GEMM_DEBUG"); dbg = e ? atoi(e) : 0; } p.debug = dbg; }
   p.act = d->act; p.slope = d->slope; p.out_f32 = d->y_f32 || d->dtype == GAN_F32;
   p.vec_store = (!d->y_f32 || d->dtype == GAN_F32) && y.c % vec == 0 && y.pitch % vec == 0 && ((uintptr_t)y.ptr % 16) == 0;
   p.parity = 0; p.OS = 1; p.wy0 = p.wx0 = 0; p.wstep = 1; p.TWlog2 = 2; p.T = 16; p.log2T = 4;
@@ -579,6 +818,11 @@ static int plan_gemm(const GanConvDesc* d, int op, GemmPlan* pl) {
   }
   p.NslabPitch = tilesN * BN;
   p.tilesM = (int)tilesM; p.tilesN = tilesN;
+#ifdef GAN_DIAG
+  p.diag = g_diag;
+#endif
+  static const int use_pp = tune("PP", 1);
+  pl->pp = use_pp && BM == 256 && (BN == 256 || BN == 128) && ((long long)x.c * (d->dtype == GAN_F32 ? 4 : 2)) % 128 == 0;
   pl->BM = BM; pl->BN = BN;
   pl->grid = dim3((unsigned)(tilesM * tilesN * P), 1, (unsigned)splits);
   pl->slab_bytes = splits > 1 ? (size_t)P * splits * (size_t)M * p.NslabPitch * sizeof(float) : 0;
@@ -602,11 +846,28 @@ static int launch_cfg(const GemmPlan& pl, hipStream_t st) {
   return 0;
 }
 
+template <typename T, int BN>
+static int launch_pp(const GemmPlan& pl, hipStream_t st) {
+  static bool attr_set = false;
+  constexpr size_t smem = (size_t)(BN == 256 ? 2 : 3) * (256 + BN) * 128;
+  auto kern = conv_gemm_pp_kernel<T, BN>;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, pl.grid, dim3(512), smem, st, pl.p);
+  GAN_CHECK_LAUNCH();
+  return 0;
+}
+
 template <typename T>
 static int launch_gemm(const GemmPlan& pl, hipStream_t st) {
   int rc;
-  const int key = pl.BM * 1000 + pl.BN;
+  const int key = pl.pp ? pl.BN : pl.BM * 1000 + pl.BN;
   switch (key) {
+    case 256: rc = launch_pp<T, 256>(pl, st); break;
+    case 128: rc = launch_pp<T, 128>(pl, st); break;
     case 256256: rc = launch_cfg<T, 256, 256, 2, 4>(pl, st); break;
     case 256128: rc = launch_cfg<T, 256, 128, 4, 2>(pl, st); break;
     case 128128: rc = launch_cfg<T, 128, 128, 2, 2>(pl, st); break;

@@ -17,7 +17,10 @@ struct GemmParams {
   unsigned xbytes, wbytes;   // extents for the buffer descriptors (out-of-range offsets read zeros)
   float* stats; int stats_tpg, stats_C;   // fused per-channel (sum, sum^2) partials: tiles per group, channel count
   FastDiv divWg, divHg;      // GEMM-grid width / height (row -> (image, gy, gx) decode)
-  int debug;                 // timing experiments only (GAN_AMD_GEMM_DEBUG): 1 = skip MFMA phase, 2 = skip loads
+#ifdef GAN_DIAG
+  unsigned long long* diag;  // diagnostic build: per-block stamps
+#endif
+
 };
 
 // thin.hip: streaming kernels for the layers with <= 8 channels on one side (HBM-bound, no LDS tiling).
