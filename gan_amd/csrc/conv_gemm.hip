@@ -27,9 +27,18 @@
 #ifdef GAN_DIAG   // diagnostic build only (tools/diag_build.sh): in-kernel wall-clock stamps per block, 100 MHz ticks
 static unsigned long long* g_diag = nullptr;
 extern "C" void gan_diag_set(void* ptr) { g_diag = (unsigned long long*)ptr; }
-#define DIAG_STAMP(i) do { if (p.diag && tid == 0) p.diag[(size_t)(blockIdx.x + gridDim.x * blockIdx.z) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define DIAG_STAMP(i) do { if (p.diag && tid == 0) p.diag[(size_t)(blockIdx.x + gridDim.x * blockIdx.z) * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+// per-segment cycle sums of the ping-pong loop (wave 0 of the block): SEG_T0 at a segment's start, SEG_ADD(k) at its end
+#define SEG_DECL unsigned long long seg_t = 0, seg_sum[6] = {0, 0, 0, 0, 0, 0}
+#define SEG_T0 do { if (p.diag) { __builtin_amdgcn_sched_barrier(0); seg_t = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#define SEG_ADD(k) do { if (p.diag) { __builtin_amdgcn_sched_barrier(0); const unsigned long long n_ = __builtin_amdgcn_s_memtime(); seg_sum[k] += n_ - seg_t; seg_t = n_; __builtin_amdgcn_sched_barrier(0); } } while (0)
+#define SEG_STORE do { if (p.diag && tid == 0) for (int k_ = 0; k_ < 6; ++k_) p.diag[(size_t)(blockIdx.x + gridDim.x * blockIdx.z) * 16 + 8 + k_] = seg_sum[k_]; } while (0)
 #else
 #define DIAG_STAMP(i) do {} while (0)
+#define SEG_DECL
+#define SEG_T0 do {} while (0)
+#define SEG_ADD(k) do {} while (0)
+#define SEG_STORE do {} while (0)
 #endif
 
 template <typename T> struct Mma;
@@ -566,6 +575,8 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(const GemmParams p) {
   if (wr == 1) __builtin_amdgcn_s_barrier();              // waves 4..7 run one barrier behind
 
   uint4 af[2][4], bf0[2][2], bf1[2][2];
+  SEG_DECL;
+  SEG_T0;
   for (int t = 0; t < nk; ++t) {
     const unsigned so = (unsigned)((t % NB) * STAGE);
     const unsigned aA0 = a_row + so + swz0, aA1 = a_row + so + swz1, bB0 = b_row + so + swz0, bB1 = b_row + so + swz1;
@@ -576,6 +587,9 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(const GemmParams p) {
       constexpr int nh = BN == 256 ? ((ph == 1 || ph == 2) ? 1 : 0) : 0;      // column half (256x256 only)
       constexpr bool readA = BN == 256 ? (ph == 0 || ph == 2) : true;
       constexpr bool readB = BN == 256 ? (ph == 0 || ph == 1) : (ph == 0);
+      constexpr int x0 = PP * (ph + DP);                   // slots of this phase, relative to K tile t
+      issue_slots(std::integral_constant<int, x0 % QS>{}, std::integral_constant<int, PP>{}, t + x0 / QS);
+      SEG_ADD(5);                                          // LDS-DMA issue
       if constexpr (readB) {
         static_for<2>([&](auto Jc) {
           constexpr int j = decltype(Jc)::value;
@@ -591,10 +605,11 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(const GemmParams p) {
           lds_read128<imm>(af[0][i], aA0); lds_read128<imm>(af[1][i], aA1);
         });
       }
-      constexpr int x0 = PP * (ph + DP);                   // slots of this phase, relative to K tile t
-      issue_slots(std::integral_constant<int, x0 % QS>{}, std::integral_constant<int, PP>{}, t + x0 / QS);
+      SEG_ADD(0);                                          // issue + fragment read issue
       wait_vmcnt<VMW>();
+      SEG_ADD(1);                                          // waiting for older pieces
       __builtin_amdgcn_s_barrier();
+      SEG_ADD(2);                                          // waiting for the partner group's MATH segment
       // ---- MATH segment ----
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
@@ -607,9 +622,12 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(const GemmParams p) {
           for (int j = 0; j < 2; ++j)
             Mma<T>::run(acc[mh * 4 + i][nh * 2 + j], nh == 0 ? bf0[s2][j] : bf1[s2][j], af[s2][i]);
       __builtin_amdgcn_s_setprio(0);
+      SEG_ADD(3);                                          // fragment wait + MFMAs
       __builtin_amdgcn_s_barrier();
+      SEG_ADD(4);                                          // waiting for the partner group's LOAD segment
     });
   }
+  SEG_STORE;
   if (wr == 0) __builtin_amdgcn_s_barrier();
   wait_vmcnt<0>();
   __syncthreads();

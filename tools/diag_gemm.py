@@ -27,7 +27,7 @@ d = L.GanConvDesc(ctx.dt, s, x.view(), y.view(), w.data_ptr(), co, None, 0, 0.3,
                   ctx.ws_lanes[1].data_ptr() if stats else None, stats)
 fn = [lib.gan_conv2d_fwd, lib.gan_conv2d_dgrad, lib.gan_convT2d_fwd, lib.gan_convT2d_dgrad][opi]
 info = (C.c_int32 * 5)(); lib.gan_conv_plan_info(C.byref(d), opi, info)
-diag = torch.zeros(1 << 16, 8, dtype=torch.int64, device='cuda')
+diag = torch.zeros(1 << 16, 16, dtype=torch.int64, device='cuda')
 for _ in range(3):
     assert fn(C.byref(d), ctx.stream()) == 0
 torch.cuda.synchronize()
@@ -41,10 +41,17 @@ for cold in (0, 1):
     torch.cuda.synchronize()
     lib.gan_diag_set(None)
     t = diag.cpu().numpy()
-    t = t[t[:, 0] != 0][:, :5].astype(np.float64) * 0.01    # us
+    t = t[t[:, 0] != 0]
+    segc = t[:, 8:14].astype(np.float64).mean(axis=0)
+    nph = int(os.environ.get('NPH', '0'))
+    t = t[:, :5].astype(np.float64) * 0.01    # us
     t0 = t[:, 0].min()
     seg = np.diff(t, axis=1)
     print(f"{op} N{N} H{H} {ci}->{co} s{s} tile {info[0]}x{info[1]} splits {info[2]} blocks {len(t)} {'cold' if cold else 'warm'}: event {e0.elapsed_time(e1)*1e3:.1f} us, "
           f"kernel span {t[:, 4].max() - t0:.1f} us")
     print(f"   block start spread {t[:, 0].max() - t0:.2f} us; mean per block: setup {seg[:, 0].mean():.2f}  first-fill {seg[:, 1].mean():.2f}  "
           f"loop {seg[:, 2].mean():.2f}  epilogue {seg[:, 3].mean():.2f} (max {seg[:, 3].max():.2f})  total {(t[:, 4] - t[:, 0]).mean():.2f} us")
+    tot = segc.sum()
+    if tot > 0:
+        print("   loop cycles of wave 0 (shader clock): " + "  ".join(f"{n} {v / tot * 100:.0f}%" for n, v in zip(
+            ["frag reads", "vmcnt wait", "barrier(partner math)", "lgkm+MFMA", "barrier(partner load)", "DMA issue"], segc)) + f"  total {tot:.0f}")
