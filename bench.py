@@ -2,7 +2,8 @@
 """Headline benchmark: Pix2Pix `train_step` images/sec at 256x256 (BASELINE.json), bf16, batch 16 per GPU.
 
   python bench.py --gpus N --steps K --warmup W
-  (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+  (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...; started WITHOUT a
+   launcher, `--gpus N` spawns that command itself, one rank per GPU, before the parent touches a GPU)
 
 A "step" is one full Pix2Pix.train_step(training=True): generator forward, discriminator forward on
 real++fake, BCE/L1 losses, both backward passes (dgrad + wgrad), TF-form Adam on every weight, and (N>1)
@@ -13,6 +14,8 @@ live with HIP events, and the CPU oracle timed on this box's host cores.
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -93,8 +96,28 @@ def cpu_baseline(budget_s=20.0):
         cores = max([p.get('num_threads', 1) for p in threadpool_info()] or [1])
     except Exception:
         cores = os.cpu_count() or 1
-    return {"value": round(n / dt, 4), "unit": "images/sec", "cores": int(cores), "kind": "port",
-            "sample": f"{n} train_steps of the numpy oracle (fp32), Pix2Pix 256x256 batch 1, {dt:.1f} s"}
+    out = {"value": round(n / dt, 4), "unit": "images/sec", "cores": int(cores), "kind": "port",
+           "sample": f"{n} train_steps of the numpy oracle (fp32), Pix2Pix 256x256 batch 1, {dt:.1f} s"}
+    # second stand-in SURVEY.md 8(d) names: the same graph as eager PyTorch-CPU autograd (oracle/torch_ref.py), fp32
+    try:
+        from oracle import torch_ref as TR
+        Gt, Dt = TR.params(Gp, torch.float32), TR.params(Dp, torch.float32)
+        ti, tt = TR.t(inp, torch.float32), TR.t(tar, torch.float32)
+        mt = [TR.t(m, torch.float32) for m in masks]
+        state = {}
+        TR.pix2pix_train_step_eager(Gt, Dt, state, ti, tt, 100.0, mt)
+        n2, t0 = 0, time.perf_counter()
+        while True:
+            TR.pix2pix_train_step_eager(Gt, Dt, state, ti, tt, 100.0, mt)
+            n2 += 1
+            dt2 = time.perf_counter() - t0
+            if dt2 > budget_s / 2 or n2 >= 50:
+                break
+        out["torch_cpu_eager"] = {"value": round(n2 / dt2, 4), "unit": "images/sec", "cores": int(torch.get_num_threads()),
+                                  "sample": f"{n2} eager PyTorch-CPU train_steps (fp32 autograd + TF-form Adam), batch 1, {dt2:.1f} s"}
+    except Exception as e:      # the baseline is a report, not a gate
+        out["torch_cpu_eager"] = {"error": repr(e)}
+    return out
 
 
 def main():
@@ -109,7 +132,21 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--fp32-allreduce', action='store_true', help='exchange gradients as fp32 instead of bf16')
+    ap.add_argument('--repeats', type=int, default=5, help='the K-step timed region is run this many times; the median is reported')
     args = ap.parse_args()
+
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # no launcher: start one rank per GPU ourselves (before this process initialises a GPU) and relay the result
+        ndev = torch.cuda.device_count()              # does not create a GPU context
+        if ndev < args.gpus and os.environ.get('GAN_AMD_ALLOW_SHARED_GPU') != '1':
+            print(f"bench.py: --gpus {args.gpus} but only {ndev} GPU(s) visible", file=sys.stderr)
+            sys.exit(3)
+        with socket.socket() as sk:
+            sk.bind(('127.0.0.1', 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+               '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.run(cmd).returncode)
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -123,8 +160,10 @@ def main():
             dist.init_process_group('nccl', device_id=torch.device(f'cuda:{local}'))
         else:
             dist.init_process_group(backend)
-    if args.gpus != world and rank == 0 and world > 1:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+    if args.gpus != world:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but {world} rank(s) joined", file=sys.stderr)
+        sys.exit(4)
 
     from gan_amd.ddp import GradSync
     from gan_amd.nets import Ctx, workspace_mb_for
@@ -150,22 +189,26 @@ def main():
         run = lambda: replay(*inputs)
     for _ in range(args.warmup):
         run()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        run()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    times = []
+    for _ in range(max(1, args.repeats)):          # each repeat: EXACTLY --steps steps between barrier + synchronize
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            run()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        times.append(dt)
+    dt = sorted(times)[len(times) // 2]             # median over the repeats (max over ranks inside each)
     losses = step.losses.cpu().numpy()
     if not np.all(np.isfinite(losses)):
         raise RuntimeError(f"non-finite losses {losses}")
@@ -177,7 +220,8 @@ def main():
         out = {"metric": f"Pix2Pix train_step images/sec at {S}x{S}" if args.model == 'pix2pix' else f"CycleGAN train_step pairs/sec at {S}x{S}",
                "value": round(value, 2), "unit": unit, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": args.dtype, "data": "synthetic",
+               "dtype": args.dtype, "data": "synthetic", "repeats": len(times),
+               "ms_per_step_all_repeats": [round(t_ / args.steps * 1e3, 4) for t_ in times],
                "config": {"workload": f"{'Pix2Pix' if args.model == 'pix2pix' else 'CycleGAN'} {S}x{S} {args.dtype} "
                                       f"batch={B}/GPU train_step (G fwd, D fwd real+fake, losses, dgrad+wgrad, Adam"
                                       f"{', RCCL grad all-reduce' if world > 1 else ''})",
@@ -191,15 +235,19 @@ def main():
         tot_ms = sum(v[0] for v in prof.values())
         kname, (kms, kfl, kn) = max(prof.items(), key=lambda kv: kv[1][0])
         ach = kfl / (kms * 1e-3) / 1e12
-        traffic = None          # HBM bytes per launch from the committed PMC passes (profiles/), if present
-        try:
-            pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')))
-            if B == 16 and S == 256 and args.model == 'pix2pix' and kname in pmc:
-                traffic = pmc[kname]["hbm_bytes_per_launch"]
-        except Exception:
-            pass
+        # HBM bytes per launch come from a separate rocprofv3 --pmc pass of this same command (counters cannot be
+        # collected inside this process); the committed summary is quoted and named, never re-measured here
+        traffic, traffic_src = None, None
+        for name in ('r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
+            try:
+                pmc = json.load(open(os.path.join(ROOT, 'profiles', name)))
+                if B == 16 and S == 256 and args.model == 'pix2pix' and kname in pmc:
+                    traffic, traffic_src = pmc[kname]["hbm_bytes_per_launch"], f"profiles/{name} (separate rocprofv3 --pmc pass, not this run)"
+                    break
+            except Exception:
+                pass
         out["roofline"] = {"bound": "mfma", "kernel": kname, "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS,
-                           "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                           "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                            "flops_per_launch": round(kfl / kn),
                            "launches_per_step": kn, "avg_launch_us": round(kms / kn * 1e3, 2),
                            "gemm_share_of_eager_gemm_time": round(kms / tot_ms, 3)}

@@ -100,6 +100,8 @@ SYMBOLS = {
     "gan_unpack": (C.c_int, [C.c_int32, C.POINTER(GanTensor), C.c_void_p, C.c_void_p]),
     "gan_copy_view": (C.c_int, [C.c_int32, C.POINTER(GanTensor), C.POINTER(GanTensor), C.c_void_p]),
     "gan_bias_grad": (C.c_int, [C.c_int32, C.POINTER(GanTensor), C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "gan_grad_pack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "gan_grad_unpack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p]),
     "gan_version": (C.c_char_p, []),
 }
 

@@ -330,6 +330,22 @@ __global__ __launch_bounds__(256) void copy_view_kernel(const T* src, int spitch
   dst[(i / C) * dpitch + (i % C)] = src[(i / C) * spitch + (i % C)];
 }
 
+// gradient wire format of the data-parallel exchange (gan_amd/ddp.py): fp32 <-> bf16, 8 elements per thread
+__global__ __launch_bounds__(256) void grad_pack_kernel(const float4* __restrict__ src, uint4* __restrict__ dst, long long n8) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
+    const float4 a = src[2 * i], b = src[2 * i + 1];
+    dst[i] = make_uint4(pack_bf2(a.x, a.y), pack_bf2(a.z, a.w), pack_bf2(b.x, b.y), pack_bf2(b.z, b.w));
+  }
+}
+__global__ __launch_bounds__(256) void grad_unpack_kernel(const uint4* __restrict__ src, float4* __restrict__ dst, long long n8, float scale) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
+    float v[8];
+    unpack16<bf16_t>(src[i], v);
+    dst[2 * i] = make_float4(v[0] * scale, v[1] * scale, v[2] * scale, v[3] * scale);
+    dst[2 * i + 1] = make_float4(v[4] * scale, v[5] * scale, v[6] * scale, v[7] * scale);
+  }
+}
+
 extern "C" {
 
 int gan_bce_logits(const float* x, int64_t count, float target, float loss_scale, int32_t loss_accumulate,
@@ -543,5 +559,21 @@ int gan_copy_view(int32_t dtype, const GanTensor* src, const GanTensor* dst, gan
   return 0;
 }
 
-const char* gan_version(void) { return "gan_amd 0.1 (gfx950)"; }
+int gan_grad_pack(const float* src, void* dst_bf16, int64_t count, gan_stream_t stream) {
+  if (!src || !dst_bf16 || count <= 0 || count % 8 || (((uintptr_t)src | (uintptr_t)dst_bf16) & 15)) return GAN_E_ARG;
+  const long long n8 = count / 8;
+  const unsigned grid = (unsigned)((n8 + 255) / 256 < 4096 ? (n8 + 255) / 256 : 4096);
+  hipLaunchKernelGGL(grad_pack_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float4*)src, (uint4*)dst_bf16, n8);
+  GAN_CHECK_LAUNCH();
+  return 0;
+}
+int gan_grad_unpack(const void* src_bf16, float* dst, int64_t count, float scale, gan_stream_t stream) {
+  if (!src_bf16 || !dst || count <= 0 || count % 8 || (((uintptr_t)src_bf16 | (uintptr_t)dst) & 15)) return GAN_E_ARG;
+  const long long n8 = count / 8;
+  const unsigned grid = (unsigned)((n8 + 255) / 256 < 4096 ? (n8 + 255) / 256 : 4096);
+  hipLaunchKernelGGL(grad_unpack_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint4*)src_bf16, (float4*)dst, n8, scale);
+  GAN_CHECK_LAUNCH();
+  return 0;
+}
+const char* gan_version(void) { return "gan_amd 0.2 (gfx950)"; }
 }

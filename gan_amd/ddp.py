@@ -1,16 +1,18 @@
-"""Data-parallel gradient exchange: one process per GPU, gradients of every network live in ONE flat fp32
-buffer per network (ParamSet.grad), so the exchange is a handful of large collectives — sized for xGMI's
-point-to-point links rather than many small per-tensor all-reduces.  The reference has no multi-GPU code
-(base_gan.py:18-19 only prints the GPU count); semantics are defined here: per-replica
-BatchNorm statistics, gradient = mean over ranks of the per-rank mean-loss gradients.
+"""Data-parallel gradient exchange: one process per GPU; the gradients of every network live in ONE flat fp32
+buffer per network (ParamSet.grad: conv kernels first, in layer order, then the norm/bias vectors), so a BUCKET is
+a contiguous range of that buffer.  The reference has no multi-GPU code (base_gan.py:18-19 only prints the GPU
+count); semantics are defined here: per-replica BatchNorm statistics, gradient = mean over ranks
+of the per-rank mean-loss gradients.
 
-The exchange is asynchronous: `start(i)` enqueues the all-reduce of buffer i on the communicator's stream
-(after the work already queued on the current stream) and returns; `finish()` makes the current stream wait
-for all of them.  The step driver starts the generator's (large) exchange as soon as its backward is done and
-runs the discriminator's parameter-gradient pass meanwhile.  Optional bf16 wire format halves the bytes
-(57 M fp32 gradients = 229 MB per Pix2Pix step).
+Exchange = one RCCL all-reduce per bucket (a few large collectives sized for xGMI's point-to-point links, not one per
+tensor), started as soon as the bucket's last wgrad GEMM has been enqueued and overlapped with the rest of the
+backward pass; Adam runs per bucket as it lands (gan_amd/steps.py).  Wire format: bf16 (57 M fp32 gradients =
+229 MB per Pix2Pix step, 114 MB on the wire) written by our own cast kernel (gan_grad_pack, captured in the step's
+graphs) and read back by gan_grad_unpack, which also applies the 1/world of the mean; fp32 exchanges in place.
 
-Backend "nccl" is RCCL on ROCm; "gloo" is used by the CPU tests (world_size 2).
+`start(i, lo, hi)` enqueues the all-reduce of elements [lo, hi) of buffer i on the communicator's stream (after the
+work already queued on the current stream) and returns a handle; `wait(h)` makes the CURRENT stream wait for it
+(the host never blocks).  Backend "nccl" is RCCL on ROCm; "gloo" is used by the CPU tests (world_size 2).
 """
 from __future__ import annotations
 
@@ -19,48 +21,80 @@ import torch.distributed as dist
 
 
 class GradSync:
-    def __init__(self, grad_buffers, group=None, compress_bf16=False, max_chunk_elems=64 << 20):
-        """grad_buffers: list of flat fp32 tensors (ParamSet.grad of each network)."""
+    def __init__(self, grad_buffers, group=None, compress_bf16=False, lib=None):
+        """grad_buffers: list of flat fp32 tensors (ParamSet.grad of each network).  lib: the loaded C-ABI library
+        (needed for the bf16 wire format on the GPU; CPU/gloo tests pass None and get a torch cast)."""
         self.bufs = list(grad_buffers)
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.compress = compress_bf16
-        self.max_chunk = max_chunk_elems
-        self._stage = [torch.empty_like(b, dtype=torch.bfloat16) for b in self.bufs] if compress_bf16 else None
+        self.compress = bool(compress_bf16)
+        self.lib = lib
+        self.wire = [torch.zeros_like(b, dtype=torch.bfloat16) for b in self.bufs] if self.compress else None
         self._pending = []
 
     @property
     def grad_scale(self):
-        """Adam consumes SUM-reduced gradients scaled by 1/world (mean over ranks)."""
-        return 1.0 / self.world
+        """What Adam must multiply the exchanged gradients by: fp32 exchanges are SUMs (1/world applied by Adam's
+        grad_scale); bf16 exchanges come back through unpack(), which already applied it."""
+        return 1.0 if self.compress else 1.0 / self.world
 
-    def start(self, i):
-        """Begin the all-reduce of buffer i (non-blocking for the host and for the current stream)."""
-        if self.world == 1:
+    # ---- wire-format kernels (enqueue-only; capturable) ----------------------------------------------
+    def _stream(self):
+        return torch.cuda.current_stream(self.bufs[0].device).cuda_stream if self.bufs[0].is_cuda else None
+
+    def pack(self, i, lo=0, hi=None):
+        """grad[i][lo:hi] (fp32) -> wire[i][lo:hi] (bf16).  No-op for fp32 exchanges."""
+        if not self.compress:
             return
-        b = self.bufs[i]
-        t = b
-        if self.compress:
-            t = self._stage[i]
-            t.copy_(b)
-        works = []
-        n = t.numel()
-        for o in range(0, n, self.max_chunk):
-            works.append(dist.all_reduce(t[o:min(n, o + self.max_chunk)], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
-        self._pending.append((i, works))
+        hi = self.bufs[i].numel() if hi is None else hi
+        if self.lib is not None and self.bufs[i].is_cuda:
+            rc = self.lib.gan_grad_pack(self.bufs[i].data_ptr() + 4 * lo, self.wire[i].data_ptr() + 2 * lo, hi - lo, self._stream())
+            if rc:
+                raise RuntimeError(f"gan_grad_pack failed rc={rc}")
+        else:
+            self.wire[i][lo:hi].copy_(self.bufs[i][lo:hi])
+
+    def unpack(self, i, lo=0, hi=None):
+        """wire[i][lo:hi] (bf16, summed over ranks) * 1/world -> grad[i][lo:hi] (fp32).  No-op for fp32 exchanges."""
+        if not self.compress:
+            return
+        hi = self.bufs[i].numel() if hi is None else hi
+        if self.lib is not None and self.bufs[i].is_cuda:
+            rc = self.lib.gan_grad_unpack(self.wire[i].data_ptr() + 2 * lo, self.bufs[i].data_ptr() + 4 * lo, hi - lo,
+                                          1.0 / self.world, self._stream())
+            if rc:
+                raise RuntimeError(f"gan_grad_unpack failed rc={rc}")
+        else:
+            self.bufs[i][lo:hi].copy_(self.wire[i][lo:hi].float() / self.world)
+
+    # ---- collectives -----------------------------------------------------------------------------------
+    def start(self, i, lo=0, hi=None):
+        """Begin the all-reduce (SUM) of elements [lo, hi) of buffer i in its wire format; returns a handle."""
+        if self.world == 1:
+            return None
+        t = self.wire[i] if self.compress else self.bufs[i]
+        hi = t.numel() if hi is None else hi
+        return dist.all_reduce(t[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def wait(self, handle):
+        """The current stream waits for the collective (asynchronous for the host with RCCL)."""
+        if handle is not None:
+            handle.wait()
+
+    # ---- whole-buffer convenience (eager path; CycleGAN's per-network exchange) --------------------------
+    def start_all(self, i):
+        self.pack(i)
+        self._pending.append((i, self.start(i)))
 
     def finish(self):
-        """Current stream waits for every started exchange; decompress if needed."""
-        for i, works in self._pending:
-            for w in works:
-                w.wait()
-            if self.compress:
-                self.bufs[i].copy_(self._stage[i])
+        for i, h in self._pending:
+            self.wait(h)
+            self.unpack(i)
         self._pending = []
 
     def __call__(self):
         for i in range(len(self.bufs)):
-            self.start(i)
+            self.start_all(i)
         self.finish()
 
 

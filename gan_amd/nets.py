@@ -597,6 +597,19 @@ class GenCall:
         else:
             self.ctx.run(ops)
 
+    def bwd_stages(self, cuts, use_dgen2=False, need_dx=False, accumulate=False):
+        """The backward op list cut into coarse stages at the wgrad indices `cuts` (the same cuts as the 'staged'
+        mode): [(main-chain ops, wgrad ops)] per stage.  The wgrad GEMMs of a stage only feed Adam, so a caller may
+        run them beside the NEXT stage's main chain (gan_amd/steps.py data-parallel schedule)."""
+        key = (use_dgen2, need_dx, accumulate)
+        if key not in self._bwd_cache:
+            self._bwd_cache[key] = self._build_bwd(*key)
+        ops = self._bwd_cache[key]
+        is_w = lambda o: len(o) > 4 and o[4]
+        idx = [i for i, o in enumerate(ops) if is_w(o)]
+        bounds = [0] + [idx[c] for c in cuts if 0 < c < len(idx)] + [len(ops)]
+        return [([o for o in ops[lo:hi] if not is_w(o)], [o for o in ops[lo:hi] if is_w(o)]) for lo, hi in zip(bounds[:-1], bounds[1:])]
+
     def run_deferred_wgrads(self, stream):
         """Kernel-gradient GEMMs postponed by backward(defer_wgrads=True): they only feed Adam."""
         self.ctx.run_on(self._deferred, stream)

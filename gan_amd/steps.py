@@ -84,6 +84,8 @@ class _StepBase:
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         split = training and self.sync is not None and self.sync.world > 1
+        if split and hasattr(self, '_capture_bucketed') and self.ctx.ms_mode == 4 and os.environ.get('GAN_AMD_DDP_BUCKETS', '1') == '1':
+            return self._capture_bucketed()
         g1 = torch.cuda.CUDAGraph()
         g2 = g3 = None
         if not split:
@@ -111,10 +113,10 @@ class _StepBase:
             g1.replay()
             if g2 is not None:
                 for i in early:
-                    self.sync.start(i)
+                    self.sync.start_all(i)
                 g2.replay()
                 for i in late:
-                    self.sync.start(i)
+                    self.sync.start_all(i)
                 self.sync.finish()
                 g3.replay()
             return self.losses
@@ -195,6 +197,8 @@ class Pix2PixStep(_StepBase):
         if training:
             d.backward_input(1)                                       # dL_G/d gen through D(fake), pre-update D
             self._copy(d.dxin.view(Cc, Cc), g.dgen2.view(0, Cc))
+            if phase == 3:                                            # bucketed data-parallel schedule: the caller stages G's backward
+                return self.losses
             # two independent chains: D's parameter gradients (pix2pix.py:211) beside G's backward (:210)
             main, lane2 = self.ctx.lane_stream(0), self.ctx.lane_stream(2)
             if phase == 1 and self.ctx.ms_mode == 4:   # data-parallel: D's parameter pass is phase 2 (beside G's all-reduce)
@@ -270,6 +274,114 @@ class Pix2PixStep(_StepBase):
                 g.backward(use_dgen2=True)
                 d.backward_params()
         return self.losses                                            # Adam: _update() (pix2pix.py:213-216)
+
+    # ---- data-parallel schedule: bucketed exchange overlapped with the backward pass ---------------------------
+    def _capture_bucketed(self):
+        """Five compute graphs with a gradient bucket leaving after each of the last three, and one Adam graph per
+        bucket on a side stream as soon as that bucket's all-reduce has landed (the reference is
+        single-device).  Stage k's wgrad GEMMs run beside stage k+1's dgrad/norm chain exactly as in the one-GPU
+        schedule:
+
+          G1  forward, losses, D's input-gradient pass, G backward stage 0 chain (decoder)
+          G2  stage 1 chain (down7..4)  ||  stage 0 wgrads              -> bucket 0 = decoder kernels
+          G3  stage 2 chain (down3..0)  ||  stage 1 wgrads              -> bucket 1 = down7..4 kernels
+          G4  stage 2 wgrads            ||  D's parameter-gradient pass -> bucket 2 = down3..0 kernels + G's vectors,
+                                                                           bucket 3 = D (whole network)
+        Weights are only rewritten by an Adam graph after every kernel that reads them in this step has been
+        enqueued: a segment's NK copies feed the dgrads of its own stage, which precede its bucket."""
+        ctx, g, d, sync = self.ctx, self.g, self.d, self.sync
+        P, PD = self.G.params, self.D.params
+        P.split_kernels_at('down4.kernel', 'up0.kernel')            # segments 0: down0..3 | 1: down4..7 | 2: up0..last
+        o4, ou = P.entries['down4.kernel'][0], P.entries['up0.kernel'][0]
+        self.buckets = [(0, ou, P.vec_start), (0, o4, ou), (0, 0, o4), (0, P.vec_start, P.total), (1, 0, PD.total)]
+        stages = g.bwd_stages([8, 12], use_dgen2=True)
+        assert len(stages) == 3
+        main = torch.cuda.current_stream(ctx.device)
+        lane2, lane3, lane4 = ctx.lane_stream(2), ctx.lane_stream(3), ctx.lane_stream(4)
+        self._static_in = [torch.zeros_like(t) for t in self._example_inputs()]
+        torch.cuda.synchronize()
+        s = torch.cuda.Stream(device=ctx.device)
+        s.wait_stream(main)
+        with torch.cuda.stream(s):           # warm-up outside capture (lazy inits, func attributes)
+            self._forward_backward(*self._static_in, True, phase=1)
+            self._forward_backward(*self._static_in, True, phase=2)
+            for b in range(len(self.buckets)):
+                sync.pack(*self.buckets[b]); sync.unpack(*self.buckets[b])
+        main.wait_stream(s)
+        torch.cuda.synchronize()
+
+        def graph(fn):
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr):
+                fn()
+            return gr
+
+        def fork_join(side_ops, side_stream, main_fn):
+            cur = torch.cuda.current_stream(ctx.device)
+            side_stream.wait_stream(cur)
+            ctx.run_on(side_ops, side_stream)
+            main_fn()
+            cur.wait_stream(side_stream)
+
+        def g1():
+            self._forward_backward(*self._static_in, True, phase=3)          # everything up to G's backward
+            ctx.run(stages[0][0])
+
+        def g2():
+            fork_join(stages[0][1], lane3, lambda: ctx.run(stages[1][0]))
+            sync.pack(*self.buckets[0])
+
+        def g3():
+            fork_join(stages[1][1], lane3, lambda: ctx.run(stages[2][0]))
+            sync.pack(*self.buckets[1])
+
+        def g4():
+            fork_join(stages[2][1], lane3, lambda: ctx.run(d.params_ops()))
+            for b in (2, 3, 4):
+                sync.pack(*self.buckets[b])
+
+        gs = sync.grad_scale
+
+        def a0():
+            sync.unpack(*self.buckets[0])
+            ctx.run(P.adam_begin_ops(self.lr, self.b1, self.b2) + P.adam_segment_ops(2, self.b1, self.b2, grad_scale=gs))
+
+        def a1():
+            sync.unpack(*self.buckets[1])
+            ctx.run(P.adam_segment_ops(1, self.b1, self.b2, grad_scale=gs))
+
+        def a2():
+            sync.unpack(*self.buckets[2]); sync.unpack(*self.buckets[3])
+            ctx.run(P.adam_segment_ops(0, self.b1, self.b2, grad_scale=gs, vectors=True))
+
+        def a3():
+            sync.unpack(*self.buckets[4])
+            PD.adam(self.lr, self.b1, self.b2, grad_scale=gs)
+
+        G = [graph(f) for f in (g1, g2, g3, g4)]
+        A = [graph(f) for f in (a0, a1, a2, a3)]
+        self._graphs = tuple(G + A)
+        # after G_k: which buckets leave, and which Adam graph follows each of them
+        plan = {1: [(0, 0)], 2: [(1, 1)], 3: [(2, None), (3, 2), (4, 3)]}
+
+        def replay(*inputs):
+            for dst, src in zip(self._static_in, inputs):
+                if src is not dst:
+                    dst.copy_(src, non_blocking=True)
+            cur = torch.cuda.current_stream(ctx.device)
+            for k, gr in enumerate(G):
+                gr.replay()
+                started = [(sync.start(*self.buckets[b]), ai) for b, ai in plan.get(k, ())]
+                if started:
+                    lane4.wait_stream(cur)                 # (the Adam graphs also read what the compute graphs wrote)
+                    with torch.cuda.stream(lane4):
+                        for h, ai in started:
+                            sync.wait(h)                   # lane 4 waits for the collective; the host does not
+                            if ai is not None:
+                                A[ai].replay()
+            cur.wait_stream(lane4)
+            return self.losses
+        return replay
 
     def train_step(self, input_image, target, training=True):
         """(gen_total_loss, gen_gan_loss, gen_l1_loss, disc_loss) as a 4-element device tensor view."""

@@ -223,6 +223,11 @@ int gan_copy_view(int32_t dtype, const GanTensor* src, const GanTensor* dst, gan
  * workspace >= gan_norm_workspace_bytes(1, dy.c, n*h*w). */
 int gan_bias_grad(int32_t dtype, const GanTensor* dy, float* dbias, int32_t accumulate, void* workspace,
                   size_t workspace_bytes, gan_stream_t stream);
+/* Wire format of the data-parallel gradient exchange (no counterpart in the reference, which is single-device:
+ * base_gan.py:18-19 only prints the GPU count; semantics in SURVEY.md section 8e): fp32 gradients -> bf16 wire buffer
+ * before the RCCL all-reduce, and back (times `scale` = 1/world) before Adam.  count % 8 == 0, 16-byte aligned. */
+int gan_grad_pack(const float* src, void* dst_bf16, int64_t count, gan_stream_t stream);
+int gan_grad_unpack(const void* src_bf16, float* dst, int64_t count, float scale, gan_stream_t stream);
 const char* gan_version(void);
 
 #ifdef __cplusplus

@@ -1,6 +1,7 @@
 """Independent PyTorch-CPU autograd implementation of the same graph as
 oracle/gan_oracle.py (a second opinion, NOT the reference).
-Used only by tests to cross-check the oracle's explicit backward passes."""
+TEST INFRASTRUCTURE: used by tests/ to cross-check the oracle's explicit backward passes and by bench.py's
+cpu_baseline leg as the "PyTorch-CPU eager" stand-in SURVEY.md 8(d) names; never imported by gan_amd/."""
 import numpy as np
 import torch
 import torch.nn.functional as F
@@ -139,3 +140,29 @@ def cyclegan_losses_and_grads(Ggn, Gfn, Dxn, Dyn, rx, ry, lam, masks, dt=torch.f
     losses = tuple(v.item() for v in (gen_g, gen_f, cyc, tot_g, tot_f, dxl, dyl))
     pk = lambda P, g: {k: v.numpy() for k, v in zip(P.keys(), g)}
     return losses, pk(Gg, g1), pk(Gf, g2), pk(Dx, g3), pk(Dy, g4)
+
+
+def pix2pix_train_step_eager(G, D, optstate, inp, tar, lam, masks, lr=2e-4, b1=0.5, b2=0.999, eps=1e-7):
+    """One eager PyTorch-CPU Pix2Pix train_step (pix2pix.py:190-218) on torch parameter dicts, TF-form Adam included
+    (timing stand-in for the TF CPU path; fp32)."""
+    gen = generator(G, inp, 'batchnorm', masks)
+    d_real = discriminator(D, inp, tar, 'batchnorm')
+    d_fake = discriminator(D, inp, gen, 'batchnorm')
+    gan = bce(d_fake, 1.0)
+    l1 = (tar - gen).abs().mean()
+    gen_total = gan + lam * l1
+    disc = (bce(d_real, 1.0) + bce(d_fake, 0.0)) * 0.5
+    gG = torch.autograd.grad(gen_total, list(G.values()), retain_graph=True)
+    gD = torch.autograd.grad(disc, list(D.values()))
+    optstate['t'] = optstate.get('t', 0) + 1
+    tstep = optstate['t']
+    lr_t = lr * (1 - b2 ** tstep) ** 0.5 / (1 - b1 ** tstep)
+    with torch.no_grad():
+        for P, grads, tag in ((G, gG, 'G'), (D, gD, 'D')):
+            for (k, p), g in zip(P.items(), grads):
+                m = optstate.setdefault((tag, k, 'm'), torch.zeros_like(p))
+                v = optstate.setdefault((tag, k, 'v'), torch.zeros_like(p))
+                m += (g - m) * (1 - b1)
+                v += (g * g - v) * (1 - b2)
+                p -= lr_t * m / (v.sqrt() + eps)
+    return gen_total.item(), gan.item(), l1.item(), disc.item()

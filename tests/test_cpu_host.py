@@ -132,9 +132,18 @@ def _ddp_worker(rank, world, port, q):
     mine = [t.clone() for t in per_rank[rank]]
     for compress in (False, True):
         bufs = [t.clone() for t in mine]
-        sync = GradSync(bufs, compress_bf16=compress, max_chunk_elems=300)
-        sync()
-        expect = [sum(per_rank[r][i] for r in range(world)) * sync.grad_scale for i in range(2)]
+        sync = GradSync(bufs, compress_bf16=compress)
+        if compress:            # bucketed use: two ranges of buffer 0, buffer 1 whole (what the step graphs do)
+            handles = []
+            for i, lo, hi in ((0, 0, 640), (0, 640, 1000), (1, 0, 77)):
+                sync.pack(i, lo, hi)
+                handles.append((sync.start(i, lo, hi), i, lo, hi))
+            for h, i, lo, hi in handles:
+                sync.wait(h)
+                sync.unpack(i, lo, hi)
+        else:
+            sync()
+        expect = [sum(per_rank[r][i] for r in range(world)) / world for i in range(2)]     # mean over ranks
         got = [b * sync.grad_scale for b in bufs]
         tol = 2e-2 if compress else 1e-6
         ok = all(torch.allclose(a, b, rtol=tol, atol=tol) for a, b in zip(got, expect))
@@ -157,3 +166,18 @@ def test_gradsync_world2_gloo():
     assert all(ok for _, _, ok, _ in res), res
     shards = {r: s for r, _, _, s in res}
     assert shards[0] == (0, 32) and shards[1] == (32, 32)
+
+
+def test_bench_gpus_without_enough_devices_fails_loudly():
+    """`python bench.py --gpus N` with no launcher spawns the ranks itself; with fewer than N GPUs visible it must exit
+    non-zero instead of silently benchmarking one GPU."""
+    import subprocess
+    import sys
+    import torch
+    n = torch.cuda.device_count() + 2
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', str(n), '--steps', '1', '--warmup', '0'],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0 and 'GPU(s) visible' in r.stderr, (r.returncode, r.stderr[-300:])
+    assert '"metric"' not in r.stdout

@@ -1,11 +1,11 @@
 """Pins the CPU oracle (oracle/gan_oracle.py): analytic known-answer values, parameter-count
 KATs (SURVEY.md 8c items 4,5), finite differences, and an independent PyTorch-CPU autograd
-implementation of the same graph (tests/torch_ref.py)."""
+implementation of the same graph (oracle/torch_ref.py)."""
 import numpy as np
 import pytest
 
 from oracle import gan_oracle as O
-from tests import torch_ref as TR
+from oracle import torch_ref as TR
 
 RNG = np.random.default_rng(0)
 
