@@ -127,7 +127,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--batch', type=int, default=16, help='per-GPU batch')
     ap.add_argument('--img-size', type=int, default=256)
-    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f16', 'f32'])
     ap.add_argument('--model', default='pix2pix', choices=['pix2pix', 'cyclegan'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true')
@@ -177,7 +177,7 @@ def main():
     else:
         step = CycleGANStep(ctx, B, S, 1, lam=10.0, seed=123)
     if world > 1:
-        step.sync = GradSync([n.params.grad for n in step.nets()], compress_bf16=(args.dtype == 'bf16' and not args.fp32_allreduce))
+        step.sync = GradSync([n.params.grad for n in step.nets()], compress_bf16=(args.dtype != "f32" and not args.fp32_allreduce), lib=ctx.lib)
     # synthetic inputs on the normalize() lattice u/127.5-1 (base_gan.py:56-61), different per rank
     g = torch.Generator(device='cpu').manual_seed(123 + rank)
     mk = lambda: (torch.randint(0, 256, (B, S, S, 1), generator=g).float() / 127.5 - 1.0).to(dev)

@@ -169,7 +169,7 @@ class GAN(ABC):
             out = torch.zeros(1, dtype=torch.float32, device=ctx.device)
             ws = torch.empty(1024, dtype=torch.float32, device=ctx.device)
             L.check(ctx.lib.gan_bce_logits(x.data_ptr(), x.numel(), t, 1.0, 0, out.data_ptr(), 0.0, ctx.dt, None, 8,
-                                           ws.data_ptr(), ctx.stream()), "bce_logits")
+                                           ws.data_ptr(), None, ctx.stream()), "bce_logits")
             return out[0]
         return bce
 

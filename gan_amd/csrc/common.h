@@ -5,6 +5,8 @@
 #include "../../include/gan_amd.h"
 
 typedef __bf16 bf16_t;
+typedef _Float16 f16_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
@@ -18,12 +20,15 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 __device__ __forceinline__ float bf2f(bf16_t v) { return (float)v; }
 __device__ __forceinline__ float ld_f(const float* p) { return *p; }
 __device__ __forceinline__ float ld_f(const bf16_t* p) { return (float)*p; }
+__device__ __forceinline__ float ld_f(const f16_t* p) { return (float)*p; }
 __device__ __forceinline__ void st_f(float* p, float v) { *p = v; }
 __device__ __forceinline__ void st_f(bf16_t* p, float v) { *p = (bf16_t)v; }
+__device__ __forceinline__ void st_f(f16_t* p, float v) { *p = (f16_t)v; }
 
 template <typename T> struct VecOf;  // elements per 16-byte vector
 template <> struct VecOf<float> { static constexpr int N = 4; };
 template <> struct VecOf<bf16_t> { static constexpr int N = 8; };
+template <> struct VecOf<f16_t> { static constexpr int N = 8; };
 
 // unpack a 16-byte vector of T into floats
 template <typename T> __device__ __forceinline__ void unpack16(const uint4& v, float* out);
@@ -37,17 +42,44 @@ template <> __device__ __forceinline__ void unpack16<bf16_t>(const uint4& v, flo
   out[4] = __uint_as_float(v.z << 16); out[5] = __uint_as_float(v.z & 0xffff0000u);
   out[6] = __uint_as_float(v.w << 16); out[7] = __uint_as_float(v.w & 0xffff0000u);
 }
+__device__ __forceinline__ float h2f(uint32_t bits16) { const uint16_t u = (uint16_t)bits16; return (float)*(const f16_t*)&u; }
+template <> __device__ __forceinline__ void unpack16<f16_t>(const uint4& v, float* out) {
+  out[0] = h2f(v.x); out[1] = h2f(v.x >> 16); out[2] = h2f(v.y); out[3] = h2f(v.y >> 16);
+  out[4] = h2f(v.z); out[5] = h2f(v.z >> 16); out[6] = h2f(v.w); out[7] = h2f(v.w >> 16);
+}
+__device__ __forceinline__ uint32_t pack_h2(float lo, float hi) {
+  f16_t a = (f16_t)lo, b = (f16_t)hi;
+  return (uint32_t)(*(uint16_t*)&a) | ((uint32_t)(*(uint16_t*)&b) << 16);
+}
 __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
   bf16_t a = (bf16_t)lo, b = (bf16_t)hi;
   return (uint32_t)(*(uint16_t*)&a) | ((uint32_t)(*(uint16_t*)&b) << 16);
 }
+// two floats -> one 32-bit word of the 16-bit storage type T
+template <typename T> __device__ __forceinline__ uint32_t pack2(float lo, float hi);
+template <> __device__ __forceinline__ uint32_t pack2<bf16_t>(float lo, float hi) { return pack_bf2(lo, hi); }
+template <> __device__ __forceinline__ uint32_t pack2<f16_t>(float lo, float hi) { return pack_h2(lo, hi); }
+template <> __device__ __forceinline__ uint32_t pack2<float>(float lo, float hi) { return 0; }   // (never used: fp32 stores floats)
 template <typename T> __device__ __forceinline__ uint4 pack16(const float* in);
 template <> __device__ __forceinline__ uint4 pack16<float>(const float* in) {
   return make_uint4(__float_as_uint(in[0]), __float_as_uint(in[1]), __float_as_uint(in[2]), __float_as_uint(in[3]));
 }
+template <> __device__ __forceinline__ uint4 pack16<f16_t>(const float* in) {
+  return make_uint4(pack_h2(in[0], in[1]), pack_h2(in[2], in[3]), pack_h2(in[4], in[5]), pack_h2(in[6], in[7]));
+}
 template <> __device__ __forceinline__ uint4 pack16<bf16_t>(const float* in) {
   return make_uint4(pack_bf2(in[0], in[1]), pack_bf2(in[2], in[3]), pack_bf2(in[4], in[5]), pack_bf2(in[6], in[7]));
 }
+
+// 16x16x32 MFMA on 16-bit operands held as 4 dwords (8 elements) per lane, fp32 accumulate
+template <typename T> __device__ __forceinline__ f32x4 mma16(const uint4& a, const uint4& b, f32x4 c);
+template <> __device__ __forceinline__ f32x4 mma16<bf16_t>(const uint4& a, const uint4& b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&a, *(const bf16x8*)&b, c, 0, 0, 0);
+}
+template <> __device__ __forceinline__ f32x4 mma16<f16_t>(const uint4& a, const uint4& b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(*(const f16x8*)&a, *(const f16x8*)&b, c, 0, 0, 0);
+}
+static inline bool gan_dtype_ok(int dtype) { return dtype == GAN_F32 || dtype == GAN_BF16 || dtype == GAN_F16; }
 
 __device__ __forceinline__ float apply_act(float v, int act, float slope) {
   if (act == GAN_ACT_LRELU) return v > 0.f ? v : v * slope;

@@ -47,6 +47,9 @@ template <> struct Mma<bf16_t> {
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&a, *(const bf16x8*)&b, acc, 0, 0, 0);
   }
 };
+template <> struct Mma<f16_t> {
+  static __device__ __forceinline__ void run(f32x4& acc, const uint4& a, const uint4& b) { acc = mma16<f16_t>(a, b, acc); }
+};
 template <> struct Mma<float> {
   static __device__ __forceinline__ void run(f32x4& acc, const uint4& a, const uint4& b) {
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), acc, 0, 0, 0);
@@ -145,7 +148,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = act_c<ACT>(acc[ip * IPP + ii][j][e] + bv[j][e], p.slope);
             T* dst = (T*)(Cs + ((wm * IPP + ii) * 16 + r) * CS) + wn * WTN + j * 16 + q * 4;
-            if constexpr (sizeof(T) == 2) *(uint2*)dst = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+            if constexpr (sizeof(T) == 2) *(uint2*)dst = make_uint2(pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]));
             else *(f32x4*)dst = f32x4{v[0], v[1], v[2], v[3]};
           }
       };
@@ -679,7 +682,7 @@ __global__ __launch_bounds__(256) void splitk_reduce4_kernel(const GemmParams p,
   for (int e = 0; e < 4; ++e) v[e] = apply_act(s[e] + (p.bias ? p.bias[n + e] : 0.f), p.act, p.slope);
   const size_t o = out_pixel_offset(p, m, par >> 1, par & 1) + n;
   if (p.out_f32) *(f32x4*)((float*)p.y + o) = f32x4{v[0], v[1], v[2], v[3]};
-  else *(uint2*)((T*)p.y + o) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+  else *(uint2*)((T*)p.y + o) = make_uint2(pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]));
   if (p.stats) {
     // fused normalisation statistics of a split-K layer: a block covers RB = 256 / c4 whole rows of one parity and
     // one statistics group (the planner guarantees it); per-channel (sum, sum^2) of the STORED values over those
@@ -735,7 +738,7 @@ struct GemmPlan {
 
 static int plan_gemm(const GanConvDesc* d, int op, GemmPlan* pl) {
   if (!d || !d->x.ptr || !d->y.ptr || !d->w) return GAN_E_ARG;
-  if (d->dtype != GAN_F32 && d->dtype != GAN_BF16) return GAN_E_ARG;
+  if (!gan_dtype_ok(d->dtype)) return GAN_E_ARG;
   const int vec = d->dtype == GAN_F32 ? 4 : 8;
   const GanTensor &x = d->x, &y = d->y;
   if (x.c <= 0 || x.c % 8 || x.pitch % 8 || x.pitch < x.c || y.pitch < y.c || y.c <= 0) return GAN_E_SHAPE;
@@ -920,7 +923,7 @@ static int run_gemm(const GanConvDesc* d, int op, gan_stream_t stream) {
   hipStream_t st = (hipStream_t)stream;
   if (const int fam = thin_family(d, op, pl.p)) return thin_launch(fam, d, pl.p, st);   // <= 8-channel streaming layers
   if (pl.slab_bytes > d->workspace_bytes || (pl.slab_bytes && !d->workspace)) return GAN_E_WORKSPACE;
-  return d->dtype == GAN_F32 ? launch_gemm<float>(pl, st) : launch_gemm<bf16_t>(pl, st);
+  return d->dtype == GAN_F32 ? launch_gemm<float>(pl, st) : d->dtype == GAN_F16 ? launch_gemm<f16_t>(pl, st) : launch_gemm<bf16_t>(pl, st);
 }
 
 static void plan_only_desc(GanConvDesc* t) {   // planning only looks at shapes and alignment

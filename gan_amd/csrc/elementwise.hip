@@ -2,13 +2,15 @@
 // with fused gradients, TF-form Adam, weight layout preparation, dropout-mask generation and
 // fp32<->typed packing.  Reductions are two-stage and deterministic, never atomics.
 #include "common.h"
+#include <type_traits>
 
 // ------------------------------------------------------------------------------------------------
 // losses
 // ------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void bce_kernel(const float* x, long long count, float target, float grad_scale, T* dx,
-                                                  int dx_pitch, float* partial) {
+                                                  int dx_pitch, float* partial, const float* ls) {
+  if (ls) grad_scale *= ls[0];          // dynamic loss scale (fp16 path): gradients only, the reported loss is unscaled
   // one logit per thread and step (a single 1024-thread block spent 16 us in libm on one CU); block sums go to
   // `partial`, l1_finalize_kernel adds them in a fixed order
   __shared__ float red[4];
@@ -35,10 +37,11 @@ __global__ __launch_bounds__(256) void bce_kernel(const float* x, long long coun
 // gen_total_loss = gan_loss + lambda * l1 from the L1 term already in the loss vector.
 template <typename T>
 __global__ __launch_bounds__(256) void patchgan_bce_kernel(const float* real, const float* fake, long long count,
-                                                           T* g_dfake, T* d_dreal, T* d_dfake, int pitch, float* partial) {
+                                                           T* g_dfake, T* d_dreal, T* d_dfake, int pitch, float* partial,
+                                                           const float* ls) {
   __shared__ float red[4][3];
   float s[3] = {0.f, 0.f, 0.f};
-  const float inv = 1.0f / (float)count;
+  const float inv = (ls ? ls[0] : 1.0f) / (float)count;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < count; i += (long long)gridDim.x * 256) {
     const float r = real[i], f = fake[i];
     const float er = expf(-fabsf(r)), ef = expf(-fabsf(f));
@@ -77,9 +80,10 @@ __global__ __launch_bounds__(64) void patchgan_finalize_kernel(const float* part
 
 template <typename T>
 __global__ __launch_bounds__(256) void l1_kernel(const T* a, int apitch, const T* b, int bpitch, int C, long long pixels,
-                                                 float gscale, T* da, int dapitch, float* partial) {
+                                                 float gscale, T* da, int dapitch, float* partial, const float* ls) {
   __shared__ float red[4];
   float s = 0.f;
+  if (ls) gscale *= ls[0];
   const long long total = pixels * C;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
     long long px = i / C;
@@ -113,7 +117,25 @@ __global__ __launch_bounds__(256) void l1_finalize_kernel(const float* partial, 
 // ------------------------------------------------------------------------------------------------
 // Adam (TF form), weight prep, dropout, pack
 // ------------------------------------------------------------------------------------------------
-__global__ void adam_begin_kernel(int32_t* step, float* lr_t, float lr, float b1, float b2) {
+// Dynamic loss scale state (fp16 path), 4 floats on the device: [0] scale, [1] 1/scale, [2] consecutive finite steps,
+// [3] != 0: this step's gradients hold an inf/nan -> every Adam kernel (and the step counter) skips the step.
+__global__ __launch_bounds__(256) void grads_check_kernel(const uint4* __restrict__ g, long long nvec, float* ls) {
+  bool bad = false;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long long)gridDim.x * 256) {
+    const uint4 v = g[i];
+    bad |= ((v.x & 0x7f800000u) == 0x7f800000u) | ((v.y & 0x7f800000u) == 0x7f800000u) | ((v.z & 0x7f800000u) == 0x7f800000u) |
+           ((v.w & 0x7f800000u) == 0x7f800000u);
+  }
+  if (__any(bad) && (threadIdx.x & 63) == 0) ls[3] = 1.0f;       // every writer stores the same value
+}
+__global__ void loss_scale_update_kernel(float* ls, int growth_interval, float max_scale) {
+  float scale = ls[0], good = ls[2];
+  if (ls[3] != 0.f) { scale = fmaxf(scale * 0.5f, 1.0f); good = 0.f; }
+  else if (++good >= (float)growth_interval) { scale = fminf(scale * 2.0f, max_scale); good = 0.f; }
+  ls[0] = scale; ls[1] = 1.0f / scale; ls[2] = good; ls[3] = 0.f;
+}
+__global__ void adam_begin_kernel(int32_t* step, float* lr_t, float lr, float b1, float b2, const float* ls) {
+  if (ls && ls[3] != 0.f) return;        // skipped step: iterations and lr_t stay
   int t = *step + 1;
   *step = t;
   double v = (double)lr * sqrt(1.0 - pow((double)b2, (double)t)) / (1.0 - pow((double)b1, (double)t));
@@ -121,8 +143,9 @@ __global__ void adam_begin_kernel(int32_t* step, float* lr_t, float lr, float b1
 }
 __global__ __launch_bounds__(256) void adam_kernel(float4* __restrict__ p, float4* __restrict__ m, float4* __restrict__ v,
                                                    const float4* __restrict__ g, long long nvec, const float* lr_t,
-                                                   float omb1, float omb2, float eps, float gscale) {
+                                                   float omb1, float omb2, float eps, float gscale, const float* ls) {
   const float lr = *lr_t;
+  if (ls) { if (ls[3] != 0.f) return; gscale *= ls[1]; }
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long long)gridDim.x * 256) {
     float4 pp = p[i], mm = m[i], vv = v[i], gg = g[i];
 #define ADAM1(f)                                     \
@@ -205,8 +228,9 @@ __global__ __launch_bounds__(256) void wprep_multi_kernel(const PrepEntry* ents,
 struct AdamBases { float* master; float* m; float* v; const float* grad; };
 template <typename T>
 __global__ __launch_bounds__(256) void adam_prep_multi_kernel(const PrepEntry* ents, int n, AdamBases ab, const float* lr_t,
-                                                              float omb1, float omb2, float eps, float gscale) {
+                                                              float omb1, float omb2, float eps, float gscale, const float* ls) {
   __shared__ float tile[64][65];
+  if (ls) { if (ls[3] != 0.f) return; gscale *= ls[1]; }      // skipped step (weights and their NK copies stay) / unscale
   int e = 0;
   while (e + 1 < n && (int)blockIdx.x >= ents[e + 1].tile_start) ++e;
   const PrepEntry en = ents[e];
@@ -251,7 +275,7 @@ __global__ __launch_bounds__(256) void adam_prep_multi_kernel(const PrepEntry* e
       }
       if (nat) {
         T* dst = nat + ((size_t)tap * A + a) * B8 + b;           // B8 % 8 == 0, b % 4 == 0: 8-byte (bf16) / 16-byte aligned
-        if constexpr (sizeof(T) == 2) *(uint2*)dst = make_uint2(pack_bf2(w[0], w[1]), pack_bf2(w[2], w[3]));
+        if constexpr (sizeof(T) == 2) *(uint2*)dst = make_uint2(pack2<T>(w[0], w[1]), pack2<T>(w[2], w[3]));
         else *(float4*)dst = make_float4(w[0], w[1], w[2], w[3]);
       }
     }
@@ -267,7 +291,7 @@ __global__ __launch_bounds__(256) void adam_prep_multi_kernel(const PrepEntry* e
         T* dst = tr + ((size_t)tap * B + b) * A8 + a;
         const float w0 = tile[tx * 4][ty + 16 * i], w1 = tile[tx * 4 + 1][ty + 16 * i];
         const float w2 = tile[tx * 4 + 2][ty + 16 * i], w3 = tile[tx * 4 + 3][ty + 16 * i];
-        if constexpr (sizeof(T) == 2) *(uint2*)dst = make_uint2(pack_bf2(w0, w1), pack_bf2(w2, w3));
+        if constexpr (sizeof(T) == 2) *(uint2*)dst = make_uint2(pack2<T>(w0, w1), pack2<T>(w2, w3));
         else *(float4*)dst = make_float4(w0, w1, w2, w3);
       }
     }
@@ -330,6 +354,15 @@ __global__ __launch_bounds__(256) void copy_view_kernel(const T* src, int spitch
   dst[(i / C) * dpitch + (i % C)] = src[(i / C) * spitch + (i % C)];
 }
 
+// run f with a null pointer of the storage type as its tag
+template <typename F> static inline int with_dtype(int dtype, F&& f) {
+  if (dtype == GAN_F32) return f((float*)nullptr);
+  if (dtype == GAN_F16) return f((f16_t*)nullptr);
+  if (dtype == GAN_BF16) return f((bf16_t*)nullptr);
+  return GAN_E_ARG;
+}
+#define GAN_TAG_T(tag) typename std::remove_pointer<decltype(tag)>::type
+
 // gradient wire format of the data-parallel exchange (gan_amd/ddp.py): fp32 <-> bf16, 8 elements per thread
 __global__ __launch_bounds__(256) void grad_pack_kernel(const float4* __restrict__ src, uint4* __restrict__ dst, long long n8) {
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
@@ -350,19 +383,19 @@ extern "C" {
 
 int gan_bce_logits(const float* x, int64_t count, float target, float loss_scale, int32_t loss_accumulate,
                    float* loss_out, float grad_scale, int32_t dtype, void* dx, int32_t dx_pitch, float* workspace,
-                   gan_stream_t stream) {
+                   const float* scale_state, gan_stream_t stream) {
   if (!x || !loss_out || !workspace || count <= 0) return GAN_E_ARG;
-  if (dtype != GAN_F32 && dtype != GAN_BF16) return GAN_E_ARG;
   hipStream_t st = (hipStream_t)stream;
   int blocks = (int)((count + 255) / 256);
   if (blocks > 1024) blocks = 1024;
-  if (dtype == GAN_F32)
-    hipLaunchKernelGGL(bce_kernel<float>, dim3(blocks), dim3(256), 0, st, x, (long long)count, target, grad_scale, (float*)dx,
-                       dx_pitch, workspace);
-  else
-    hipLaunchKernelGGL(bce_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, x, (long long)count, target, grad_scale,
-                       (bf16_t*)dx, dx_pitch, workspace);
-  GAN_CHECK_LAUNCH();
+  int rc = with_dtype(dtype, [&](auto* tag) {
+    typedef GAN_TAG_T(tag) T;
+    hipLaunchKernelGGL(bce_kernel<T>, dim3(blocks), dim3(256), 0, st, x, (long long)count, target, grad_scale, (T*)dx, dx_pitch,
+                       workspace, scale_state);
+    GAN_CHECK_LAUNCH();
+    return 0;
+  });
+  if (rc) return rc;
   hipLaunchKernelGGL(l1_finalize_kernel, dim3(1), dim3(256), 0, st, (const float*)workspace, blocks, 1.0 / (double)count,
                      loss_scale, loss_accumulate, loss_out);
   GAN_CHECK_LAUNCH();
@@ -371,19 +404,19 @@ int gan_bce_logits(const float* x, int64_t count, float target, float loss_scale
 
 int gan_patchgan_losses(const float* real_logits, const float* fake_logits, int64_t count, int32_t dtype, void* g_dfake,
                         void* d_dreal, void* d_dfake, int32_t pitch, float lambda, const float* l1, float* gen_total,
-                        float* gan_loss, float* disc_loss, float* workspace, gan_stream_t stream) {
+                        float* gan_loss, float* disc_loss, float* workspace, const float* scale_state, gan_stream_t stream) {
   if (!real_logits || !fake_logits || count <= 0 || !gan_loss || !disc_loss || !workspace) return GAN_E_ARG;
-  if (dtype != GAN_F32 && dtype != GAN_BF16) return GAN_E_ARG;
   hipStream_t st = (hipStream_t)stream;
   int blocks = (int)((count + 255) / 256);
   if (blocks > 256) blocks = 256;
-  if (dtype == GAN_F32)
-    hipLaunchKernelGGL(patchgan_bce_kernel<float>, dim3(blocks), dim3(256), 0, st, real_logits, fake_logits, (long long)count,
-                       (float*)g_dfake, (float*)d_dreal, (float*)d_dfake, pitch, workspace);
-  else
-    hipLaunchKernelGGL(patchgan_bce_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, real_logits, fake_logits, (long long)count,
-                       (bf16_t*)g_dfake, (bf16_t*)d_dreal, (bf16_t*)d_dfake, pitch, workspace);
-  GAN_CHECK_LAUNCH();
+  int rc = with_dtype(dtype, [&](auto* tag) {
+    typedef GAN_TAG_T(tag) T;
+    hipLaunchKernelGGL(patchgan_bce_kernel<T>, dim3(blocks), dim3(256), 0, st, real_logits, fake_logits, (long long)count,
+                       (T*)g_dfake, (T*)d_dreal, (T*)d_dfake, pitch, workspace, scale_state);
+    GAN_CHECK_LAUNCH();
+    return 0;
+  });
+  if (rc) return rc;
   hipLaunchKernelGGL(patchgan_finalize_kernel, dim3(1), dim3(64), 0, st, (const float*)workspace, blocks, 1.0 / (double)count, lambda,
                      l1, gen_total, gan_loss, disc_loss);
   GAN_CHECK_LAUNCH();
@@ -391,7 +424,8 @@ int gan_patchgan_losses(const float* real_logits, const float* fake_logits, int6
 }
 
 int gan_l1(int32_t dtype, const GanTensor* a, const GanTensor* b, float loss_scale, int32_t loss_accumulate,
-           float* loss_out, float grad_scale, const GanTensor* da, float* workspace, gan_stream_t stream) {
+           float* loss_out, float grad_scale, const GanTensor* da, float* workspace, const float* scale_state,
+           gan_stream_t stream) {
   if (!a || !b || !a->ptr || !b->ptr || !loss_out || !workspace) return GAN_E_ARG;
   if (a->n != b->n || a->h != b->h || a->w != b->w || a->c != b->c) return GAN_E_SHAPE;
   long long pixels = (long long)a->n * a->h * a->w;
@@ -400,35 +434,52 @@ int gan_l1(int32_t dtype, const GanTensor* a, const GanTensor* b, float loss_sca
   if (blocks > 2048) blocks = 2048;
   float gs = grad_scale / (float)total;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == GAN_F32)
-    hipLaunchKernelGGL(l1_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)a->ptr, a->pitch, (const float*)b->ptr,
-                       b->pitch, a->c, pixels, gs, da ? (float*)da->ptr : nullptr, da ? da->pitch : 0, workspace);
-  else
-    hipLaunchKernelGGL(l1_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)a->ptr, a->pitch,
-                       (const bf16_t*)b->ptr, b->pitch, a->c, pixels, gs, da ? (bf16_t*)da->ptr : nullptr,
-                       da ? da->pitch : 0, workspace);
-  GAN_CHECK_LAUNCH();
+  int rc = with_dtype(dtype, [&](auto* tag) {
+    typedef GAN_TAG_T(tag) T;
+    hipLaunchKernelGGL(l1_kernel<T>, dim3(blocks), dim3(256), 0, st, (const T*)a->ptr, a->pitch, (const T*)b->ptr, b->pitch, a->c,
+                       pixels, gs, da ? (T*)da->ptr : nullptr, da ? da->pitch : 0, workspace, scale_state);
+    GAN_CHECK_LAUNCH();
+    return 0;
+  });
+  if (rc) return rc;
   hipLaunchKernelGGL(l1_finalize_kernel, dim3(1), dim3(256), 0, st, (const float*)workspace, blocks, 1.0 / (double)total,
                      loss_scale, loss_accumulate, loss_out);
   GAN_CHECK_LAUNCH();
   return 0;
 }
 
-int gan_adam_begin(int32_t* step, float* lr_t, float lr, float beta1, float beta2, gan_stream_t stream) {
+int gan_adam_begin(int32_t* step, float* lr_t, float lr, float beta1, float beta2, const float* scale_state, gan_stream_t stream) {
   if (!step || !lr_t) return GAN_E_ARG;
-  hipLaunchKernelGGL(adam_begin_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step, lr_t, lr, beta1, beta2);
+  hipLaunchKernelGGL(adam_begin_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step, lr_t, lr, beta1, beta2, scale_state);
   GAN_CHECK_LAUNCH();
   return 0;
 }
 
 int gan_adam_tf(float* param, float* m, float* v, const float* grad, int64_t count, const float* lr_t, float beta1,
-                float beta2, float eps, float grad_scale, gan_stream_t stream) {
+                float beta2, float eps, float grad_scale, const float* scale_state, gan_stream_t stream) {
   if (!param || !m || !v || !grad || !lr_t || count <= 0 || count % 4) return GAN_E_ARG;
   long long nvec = count / 4;
   long long blocks = (nvec + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (float4*)param, (float4*)m,
-                     (float4*)v, (const float4*)grad, nvec, lr_t, 1.f - beta1, 1.f - beta2, eps, grad_scale);
+                     (float4*)v, (const float4*)grad, nvec, lr_t, 1.f - beta1, 1.f - beta2, eps, grad_scale, scale_state);
+  GAN_CHECK_LAUNCH();
+  return 0;
+}
+
+int gan_grads_check(const float* grad, int64_t count, float* scale_state, gan_stream_t stream) {
+  if (!grad || !scale_state || count <= 0 || count % 4 || ((uintptr_t)grad & 15)) return GAN_E_ARG;
+  const long long nvec = count / 4;
+  long long blocks = (nvec + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(grads_check_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const uint4*)grad, nvec, scale_state);
+  GAN_CHECK_LAUNCH();
+  return 0;
+}
+
+int gan_loss_scale_update(float* scale_state, int32_t growth_interval, float max_scale, gan_stream_t stream) {
+  if (!scale_state || growth_interval <= 0 || !(max_scale >= 1.f)) return GAN_E_ARG;
+  hipLaunchKernelGGL(loss_scale_update_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, scale_state, growth_interval, max_scale);
   GAN_CHECK_LAUNCH();
   return 0;
 }
@@ -439,41 +490,39 @@ int gan_weights_prepare(const float* master, int32_t A, int32_t B, int32_t dtype
   const int B8 = (B + 7) & ~7, A8 = (A + 7) & ~7;
   dim3 grid((unsigned)((B8 + 63) / 64), (unsigned)((A8 + 63) / 64), 16);
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == GAN_F32)
-    hipLaunchKernelGGL(wprep_kernel<float>, grid, dim3(256), 0, st, master, A, B, (float*)nk_native, (float*)nk_transposed);
-  else
-    hipLaunchKernelGGL(wprep_kernel<bf16_t>, grid, dim3(256), 0, st, master, A, B, (bf16_t*)nk_native, (bf16_t*)nk_transposed);
-  GAN_CHECK_LAUNCH();
-  return 0;
+  return with_dtype(dtype, [&](auto* tag) {
+    typedef GAN_TAG_T(tag) T;
+    hipLaunchKernelGGL(wprep_kernel<T>, grid, dim3(256), 0, st, master, A, B, (T*)nk_native, (T*)nk_transposed);
+    GAN_CHECK_LAUNCH();
+    return 0;
+  });
 }
 
 int gan_weights_prepare_multi(const void* entries_dev, int32_t n, int32_t total_tiles, int32_t dtype, gan_stream_t stream) {
   if (!entries_dev || n <= 0 || total_tiles <= 0) return GAN_E_ARG;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == GAN_F32)
-    hipLaunchKernelGGL(wprep_multi_kernel<float>, dim3((unsigned)total_tiles), dim3(256), 0, st, (const PrepEntry*)entries_dev, n);
-  else
-    hipLaunchKernelGGL(wprep_multi_kernel<bf16_t>, dim3((unsigned)total_tiles), dim3(256), 0, st, (const PrepEntry*)entries_dev, n);
-  GAN_CHECK_LAUNCH();
-  return 0;
+  return with_dtype(dtype, [&](auto* tag) {
+    typedef GAN_TAG_T(tag) T;
+    hipLaunchKernelGGL(wprep_multi_kernel<T>, dim3((unsigned)total_tiles), dim3(256), 0, st, (const PrepEntry*)entries_dev, n);
+    GAN_CHECK_LAUNCH();
+    return 0;
+  });
 }
 
 int gan_adam_prepare_multi(const void* entries_dev, int32_t n, int32_t total_tiles, int32_t dtype, float* master, float* m,
                            float* v, const float* grad, const float* lr_t, float beta1, float beta2, float eps,
-                           float grad_scale, gan_stream_t stream) {
+                           float grad_scale, const float* scale_state, gan_stream_t stream) {
   if (!entries_dev || n <= 0 || total_tiles <= 0 || !master || !m || !v || !grad || !lr_t) return GAN_E_ARG;
-  if (dtype != GAN_F32 && dtype != GAN_BF16) return GAN_E_ARG;
   if (((uintptr_t)master | (uintptr_t)m | (uintptr_t)v | (uintptr_t)grad) & 15) return GAN_E_ARG;
   const AdamBases ab = {master, m, v, grad};
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == GAN_F32)
-    hipLaunchKernelGGL(adam_prep_multi_kernel<float>, dim3((unsigned)total_tiles), dim3(256), 0, st, (const PrepEntry*)entries_dev,
-                       n, ab, lr_t, 1.f - beta1, 1.f - beta2, eps, grad_scale);
-  else
-    hipLaunchKernelGGL(adam_prep_multi_kernel<bf16_t>, dim3((unsigned)total_tiles), dim3(256), 0, st,
-                       (const PrepEntry*)entries_dev, n, ab, lr_t, 1.f - beta1, 1.f - beta2, eps, grad_scale);
-  GAN_CHECK_LAUNCH();
-  return 0;
+  return with_dtype(dtype, [&](auto* tag) {
+    typedef GAN_TAG_T(tag) T;
+    hipLaunchKernelGGL(adam_prep_multi_kernel<T>, dim3((unsigned)total_tiles), dim3(256), 0, st, (const PrepEntry*)entries_dev, n, ab,
+                       lr_t, 1.f - beta1, 1.f - beta2, eps, grad_scale, scale_state);
+    GAN_CHECK_LAUNCH();
+    return 0;
+  });
 }
 
 int gan_dropout_mask(uint8_t* mask, int64_t count, uint64_t seed, const int32_t* step, uint32_t stream_id, gan_stream_t stream) {
@@ -489,17 +538,17 @@ int gan_pack(int32_t dtype, const float* src, const GanTensor* dst, gan_stream_t
   if (!src || !dst || !dst->ptr) return GAN_E_ARG;
   long long total = (long long)dst->n * dst->h * dst->w * dst->c;
   dim3 grid((unsigned)((total + 255) / 256));
-  if (dtype == GAN_F32)
-    hipLaunchKernelGGL(pack_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, src, (float*)dst->ptr, dst->c, dst->pitch, total);
-  else
-    hipLaunchKernelGGL(pack_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst->ptr, dst->c, dst->pitch, total);
-  GAN_CHECK_LAUNCH();
-  return 0;
+  return with_dtype(dtype, [&](auto* tag) {
+    typedef GAN_TAG_T(tag) T;
+    hipLaunchKernelGGL(pack_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, src, (T*)dst->ptr, dst->c, dst->pitch, total);
+    GAN_CHECK_LAUNCH();
+    return 0;
+  });
 }
 
 int gan_pack_multi(int32_t dtype, int32_t n, const float* const* srcs, const GanTensor* dsts, gan_stream_t stream) {
   if (!srcs || !dsts || n <= 0 || n > 4) return GAN_E_ARG;
-  if (dtype != GAN_F32 && dtype != GAN_BF16) return GAN_E_ARG;
+  if (!gan_dtype_ok(dtype)) return GAN_E_ARG;
   PackMulti pm;
   for (int k = 0; k < n; ++k) {
     if (!srcs[k] || !dsts[k].ptr) return GAN_E_ARG;
@@ -509,10 +558,12 @@ int gan_pack_multi(int32_t dtype, int32_t n, const float* const* srcs, const Gan
   const long long total = (long long)dsts[0].n * dsts[0].h * dsts[0].w * dsts[0].c;
   if (total <= 0) return GAN_E_SHAPE;
   dim3 grid((unsigned)((total + 255) / 256), (unsigned)n);
-  if (dtype == GAN_F32) hipLaunchKernelGGL(pack_multi_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, pm, dsts[0].c, total);
-  else hipLaunchKernelGGL(pack_multi_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, pm, dsts[0].c, total);
-  GAN_CHECK_LAUNCH();
-  return 0;
+  return with_dtype(dtype, [&](auto* tag) {
+    typedef GAN_TAG_T(tag) T;
+    hipLaunchKernelGGL(pack_multi_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, pm, dsts[0].c, total);
+    GAN_CHECK_LAUNCH();
+    return 0;
+  });
 }
 
 int gan_dropout_mask_multi(int32_t n, uint8_t* const* masks, const int64_t* counts, uint64_t seed, const int32_t* step,
@@ -536,12 +587,12 @@ int gan_unpack(int32_t dtype, const GanTensor* src, float* dst, gan_stream_t str
   if (!src || !dst || !src->ptr) return GAN_E_ARG;
   long long total = (long long)src->n * src->h * src->w * src->c;
   dim3 grid((unsigned)((total + 255) / 256));
-  if (dtype == GAN_F32)
-    hipLaunchKernelGGL(unpack_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)src->ptr, dst, src->c, src->pitch, total);
-  else
-    hipLaunchKernelGGL(unpack_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src->ptr, dst, src->c, src->pitch, total);
-  GAN_CHECK_LAUNCH();
-  return 0;
+  return with_dtype(dtype, [&](auto* tag) {
+    typedef GAN_TAG_T(tag) T;
+    hipLaunchKernelGGL(unpack_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)src->ptr, dst, src->c, src->pitch, total);
+    GAN_CHECK_LAUNCH();
+    return 0;
+  });
 }
 
 int gan_copy_view(int32_t dtype, const GanTensor* src, const GanTensor* dst, gan_stream_t stream) {
@@ -549,14 +600,13 @@ int gan_copy_view(int32_t dtype, const GanTensor* src, const GanTensor* dst, gan
   if (src->n != dst->n || src->h != dst->h || src->w != dst->w || src->c != dst->c) return GAN_E_SHAPE;
   long long total = (long long)src->n * src->h * src->w * src->c;
   dim3 grid((unsigned)((total + 255) / 256));
-  if (dtype == GAN_F32)
-    hipLaunchKernelGGL(copy_view_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)src->ptr, src->pitch,
-                       (float*)dst->ptr, dst->pitch, src->c, total);
-  else
-    hipLaunchKernelGGL(copy_view_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src->ptr, src->pitch,
-                       (bf16_t*)dst->ptr, dst->pitch, src->c, total);
-  GAN_CHECK_LAUNCH();
-  return 0;
+  return with_dtype(dtype, [&](auto* tag) {
+    typedef GAN_TAG_T(tag) T;
+    hipLaunchKernelGGL(copy_view_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)src->ptr, src->pitch, (T*)dst->ptr,
+                       dst->pitch, src->c, total);
+    GAN_CHECK_LAUNCH();
+    return 0;
+  });
 }
 
 int gan_grad_pack(const float* src, void* dst_bf16, int64_t count, gan_stream_t stream) {

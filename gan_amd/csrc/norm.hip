@@ -455,7 +455,8 @@ int gan_norm_stats(const GanNormDesc* d, gan_stream_t stream) {
   hipStream_t st = (hipStream_t)stream;
   float* partial = (float*)d->workspace;
   rc = d->dtype == GAN_F32 ? launch_partial<float, 0>(p, g, d->groups, partial, st)
-                           : launch_partial<bf16_t, 0>(p, g, d->groups, partial, st);
+       : d->dtype == GAN_F16 ? launch_partial<f16_t, 0>(p, g, d->groups, partial, st)
+                             : launch_partial<bf16_t, 0>(p, g, d->groups, partial, st);
   if (rc) return rc;
   hipLaunchKernelGGL(stats_finalize_kernel, dim3((g.C + FC - 1) / FC, d->moving_mean ? 1 : d->groups), dim3(256), 0, st,
                      (const float*)partial, d->groups, g.chunks, g.C, g.rows_per_group, d->eps, d->mean, d->rstd,
@@ -488,7 +489,7 @@ int gan_norm_act_fwd(const GanNormDesc* d, gan_stream_t stream) {
   p.act = d->act; p.slope = d->slope;
   long long rows = (long long)d->y.n * g.hw;
   hipStream_t st = (hipStream_t)stream;
-  return d->dtype == GAN_F32 ? launch_fwd<float>(p, g, rows, st) : launch_fwd<bf16_t>(p, g, rows, st);
+  return d->dtype == GAN_F32 ? launch_fwd<float>(p, g, rows, st) : d->dtype == GAN_F16 ? launch_fwd<f16_t>(p, g, rows, st) : launch_fwd<bf16_t>(p, g, rows, st);
 }
 
 int gan_norm_act_bwd(const GanNormBwdDesc* d, gan_stream_t stream) {
@@ -509,13 +510,14 @@ int gan_norm_act_bwd(const GanNormBwdDesc* d, gan_stream_t stream) {
   p.sums = sums;
   hipStream_t st = (hipStream_t)stream;
   rc = d->dtype == GAN_F32 ? launch_bwd_partial<float>(p, g, d->groups, partial, st)
-                           : launch_bwd_partial<bf16_t>(p, g, d->groups, partial, st);
+       : d->dtype == GAN_F16 ? launch_bwd_partial<f16_t>(p, g, d->groups, partial, st)
+                             : launch_bwd_partial<bf16_t>(p, g, d->groups, partial, st);
   if (rc) return rc;
   hipLaunchKernelGGL(bwd_finalize_kernel, dim3((g.C + FC - 1) / FC), dim3(256), 0, st, (const float*)partial, d->groups,
                      g.chunks, g.C, sums, d->dgamma, d->dbeta, d->accumulate);
   GAN_CHECK_LAUNCH();
   long long rows = (long long)d->y.n * g.hw;
-  return d->dtype == GAN_F32 ? launch_bwd_apply<float>(p, g, rows, st) : launch_bwd_apply<bf16_t>(p, g, rows, st);
+  return d->dtype == GAN_F32 ? launch_bwd_apply<float>(p, g, rows, st) : d->dtype == GAN_F16 ? launch_bwd_apply<f16_t>(p, g, rows, st) : launch_bwd_apply<bf16_t>(p, g, rows, st);
 }
 
 static int bias_grad_impl(int32_t dtype, const GanTensor& dy, float* dbias, int32_t accumulate, void* workspace,
@@ -527,7 +529,7 @@ static int bias_grad_impl(int32_t dtype, const GanTensor& dy, float* dbias, int3
   NormP q = {};
   q.da = dy.ptr; q.dapitch = dy.pitch;
   float* partial = (float*)workspace;
-  rc = dtype == GAN_F32 ? launch_partial<float, 2>(q, g, 1, partial, st) : launch_partial<bf16_t, 2>(q, g, 1, partial, st);
+  rc = dtype == GAN_F32 ? launch_partial<float, 2>(q, g, 1, partial, st) : dtype == GAN_F16 ? launch_partial<f16_t, 2>(q, g, 1, partial, st) : launch_partial<bf16_t, 2>(q, g, 1, partial, st);
   if (rc) return rc;
   hipLaunchKernelGGL(bwd_finalize_kernel, dim3((g.C + FC - 1) / FC), dim3(256), 0, st, (const float*)partial, 1, g.chunks, g.C,
                      (float*)nullptr, (float*)nullptr, dbias, accumulate);
@@ -547,7 +549,7 @@ int gan_act_bwd(const GanActBwdDesc* d, gan_stream_t stream) {
   p.act = d->act; p.slope = d->slope; p.has_norm = 0;
   hipStream_t st = (hipStream_t)stream;
   long long rows = (long long)d->a.n * g.hw;
-  rc = d->dtype == GAN_F32 ? launch_act_bwd<float>(p, g, rows, st) : launch_act_bwd<bf16_t>(p, g, rows, st);
+  rc = d->dtype == GAN_F32 ? launch_act_bwd<float>(p, g, rows, st) : d->dtype == GAN_F16 ? launch_act_bwd<f16_t>(p, g, rows, st) : launch_act_bwd<bf16_t>(p, g, rows, st);
   if (rc) return rc;
   if (d->dbias) return bias_grad_impl(d->dtype, d->dy, d->dbias, d->accumulate, d->workspace, d->workspace_bytes, st);
   return 0;

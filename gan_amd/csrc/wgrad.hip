@@ -167,18 +167,18 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
           for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int e = 0; e < 8; ++e)
-              af[i][e] = *(const bf16_t*)(Ab + (ks * 32 + 8 * q + e) * RSA + (i * 16 + r) * 2);
+              ((uint16_t*)&af[i])[e] = *(const uint16_t*)(Ab + (ks * 32 + 8 * q + e) * RSA + (i * 16 + r) * 2);
 #pragma unroll
           for (int j = 0; j < NT; ++j)
 #pragma unroll
             for (int e = 0; e < 8; ++e)
-              bf[j][e] = *(const bf16_t*)(Bb + (ks * 32 + 8 * q + e) * RSB + (j * 16 + r) * 2);
+              ((uint16_t*)&bf[j])[e] = *(const uint16_t*)(Bb + (ks * 32 + 8 * q + e) * RSB + (j * 16 + r) * 2);
         }
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
           for (int j = 0; j < NT; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = mma16<T>(*(const uint4*)&af[i], *(const uint4*)&bf[j], acc[i][j]);
       }
     }
     }
@@ -248,7 +248,7 @@ struct WgradPlan { WgradParams p; int TA, TB; dim3 grid; size_t slab_bytes; };
 
 static int plan_wgrad(const GanWgradDesc* d, WgradPlan* pl, bool allow_swap = true) {
   if (!d || !d->big.ptr || !d->small.ptr || !d->dw) return GAN_E_ARG;
-  if (d->dtype != GAN_F32 && d->dtype != GAN_BF16) return GAN_E_ARG;
+  if (!gan_dtype_ok(d->dtype)) return GAN_E_ARG;
   if (((uintptr_t)d->dw | (uintptr_t)d->workspace) & 15) return GAN_E_ARG;      // float4 slab reduction
   const GanTensor &b = d->big, &s = d->small;
   if (b.c % 8 || s.c % 8 || b.pitch % 8 || s.pitch % 8 || b.pitch < b.c || s.pitch < s.c) return GAN_E_SHAPE;
@@ -284,7 +284,7 @@ static int plan_wgrad(const GanWgradDesc* d, WgradPlan* pl, bool allow_swap = tr
     TB = s.c >= 128 ? 128 : (s.c >= 64 ? 64 : 16);
     TA = b.c >= 128 ? 128 : (b.c >= 64 ? 64 : 16);
     { static int big = -1; if (big < 0) { const char* e = getenv("GAN_AMD_WGRAD_BIG"); big = e ? atoi(e) : 0; }
-      if (big && b.c >= 256 && s.c >= 128 && d->dtype == GAN_BF16) TA = 256; }
+      if (big && b.c >= 256 && s.c >= 128 && d->dtype != GAN_F32) TA = 256; }
     if (TB == 16) TA = TA == 16 ? 64 : TA;   // supported: (128|64, 16)
     if (TA == 64 && TB == 16) {}
     if (TA == 16 && TB == 16) return GAN_E_SHAPE;
@@ -480,7 +480,7 @@ __global__ __launch_bounds__(64 * WAVES_A * WAVES_B) void wgrad_dma_kernel(const
 #pragma unroll
           for (int j = 0; j < NT; ++j) {
             s16x8 bv = __builtin_shufflevector(blo[j], bhi[j], 0, 1, 2, 3, 4, 5, 6, 7);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(bf16x8*)&bv, *(bf16x8*)&av, acc[i][j], 0, 0, 0);
+            acc[i][j] = mma16<T>(*(const uint4*)&bv, *(const uint4*)&av, acc[i][j]);
           }
         }
       }
@@ -594,8 +594,10 @@ int gan_conv_wgrad(const GanWgradDesc* d, gan_stream_t stream) {
   if (pl.slab_bytes > d->workspace_bytes || (pl.slab_bytes && !d->workspace)) return GAN_E_WORKSPACE;
   if (pl.p.swap) { const size_t t = bb; bb = sb; sb = t; }
   if (dma_ok) rc = d->dtype == GAN_F32 ? launch_wgrad_dma<float>(pl, (unsigned)bb, (unsigned)sb, st)
-                                       : launch_wgrad_dma<bf16_t>(pl, (unsigned)bb, (unsigned)sb, st);
+                   : d->dtype == GAN_F16 ? launch_wgrad_dma<f16_t>(pl, (unsigned)bb, (unsigned)sb, st)
+                                         : launch_wgrad_dma<bf16_t>(pl, (unsigned)bb, (unsigned)sb, st);
   else if (d->dtype == GAN_F32) rc = launch_wgrad<float, false>(pl, st);
+  else if (d->dtype == GAN_F16) rc = wgrad_use_tr() ? launch_wgrad<f16_t, true>(pl, st) : launch_wgrad<f16_t, false>(pl, st);
   else rc = wgrad_use_tr() ? launch_wgrad<bf16_t, true>(pl, st) : launch_wgrad<bf16_t, false>(pl, st);
   if (rc) return rc;
   if (pl.p.splits > 1) {

@@ -47,9 +47,19 @@ class Ctx:
         if not torch.cuda.is_available():
             raise L.GanAmdError("gan_amd needs an MI355X (no CPU fallback)")
         self.device = torch.device(device)
+        if dtype not in ('f32', 'bf16', 'f16'):
+            raise ValueError(f"dtype {dtype!r}: expected 'f32', 'bf16' or 'f16'")
         self.dtype = dtype
-        self.dt = L.BF16 if dtype == 'bf16' else L.F32
-        self.tdtype = torch.bfloat16 if dtype == 'bf16' else torch.float32
+        self.dt = {'f32': L.F32, 'bf16': L.BF16, 'f16': L.F16}[dtype]
+        self.tdtype = {'f32': torch.float32, 'bf16': torch.bfloat16, 'f16': torch.float16}[dtype]
+        # fp16 path: dynamic loss scale on the device {scale, 1/scale, finite steps in a row, non-finite flag}
+        # (include/gan_amd.h, gan_grads_check / gan_loss_scale_update); None = no scaling
+        self.ls = None
+        if dtype == 'f16':
+            s0 = float(os.environ.get('GAN_AMD_LOSS_SCALE', 2.0 ** 15))
+            self.ls = torch.tensor([s0, 1.0 / s0, 0.0, 0.0], dtype=torch.float32, device=self.device)
+        self.ls_ptr = self.ls.data_ptr() if self.ls is not None else None
+        self.ls_growth_interval, self.ls_max = 2000, 2.0 ** 24        # Keras LossScaleOptimizer defaults
         # "Lanes": independent launch chains that may overlap on the GPU (separate HIP streams, also inside a
         # captured graph).  Lane 0 = the current stream; lane 1 = its wgrad side stream (wgrad kernels only
         # feed Adam, so they run beside the dgrad/norm chain); lane 2 / 3 = a second chain (discriminator
@@ -61,7 +71,6 @@ class Ctx:
         self.side = [torch.cuda.Stream(device=self.device) for _ in range(4)]     # lanes 1..4 (4: early optimiser step)
         # 0: everything on one stream; 1: one fork/join per step (deferred generator wgrads beside the
         # discriminator's parameter pass); 2: per-op wgrad side stream + second chain
-        import os
         self.ms_mode = int(os.environ.get('GAN_AMD_MS', '4'))
         self.multistream = self.ms_mode == 2
 
@@ -177,18 +186,18 @@ class ParamSet:
         self._segments = [self._kernel_table(names[a:b]) for a, b in zip(ks[:-1], ks[1:])]
 
     def adam_begin_ops(self, lr, b1, b2):
-        return [(self.ctx.lib.gan_adam_begin, (self.step.data_ptr(), self.lr_t.data_ptr(), lr, b1, b2), "adam_begin")]
+        return [(self.ctx.lib.gan_adam_begin, (self.step.data_ptr(), self.lr_t.data_ptr(), lr, b1, b2, self.ctx.ls_ptr), "adam_begin")]
 
     def adam_segment_ops(self, seg, b1, b2, eps=1e-7, grad_scale=1.0, vectors=False):
         """Fused Adam + NK refresh of kernel segment `seg` (split_kernels_at), optionally followed by the vectors'
         plain Adam.  gan_adam_begin must already have run this step."""
         lib = self.ctx.lib
         ptrs = (self.master.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), self.grad.data_ptr())
-        ops = [(lib.gan_adam_prepare_multi, self._segments[seg][1] + ptrs + (self.lr_t.data_ptr(), b1, b2, eps, grad_scale),
+        ops = [(lib.gan_adam_prepare_multi, self._segments[seg][1] + ptrs + (self.lr_t.data_ptr(), b1, b2, eps, grad_scale, self.ctx.ls_ptr),
                 "adam_prepare_multi")]
         nvec = self.total - self.vec_start
         if vectors and nvec > 0:
-            ops.append((lib.gan_adam_tf, tuple(p_ + 4 * self.vec_start for p_ in ptrs) + (nvec, self.lr_t.data_ptr(), b1, b2, eps, grad_scale),
+            ops.append((lib.gan_adam_tf, tuple(p_ + 4 * self.vec_start for p_ in ptrs) + (nvec, self.lr_t.data_ptr(), b1, b2, eps, grad_scale, self.ctx.ls_ptr),
                         "adam_tf"))
         return ops
 
@@ -198,6 +207,10 @@ class ParamSet:
     def tensor(self, name, which='master'):
         o, shape = self.entries[name]
         return getattr(self, which)[o:o + int(np.prod(shape))].view(shape)
+
+    def grads_check_ops(self):
+        """fp16 path: raise the loss-scale state's non-finite flag if this network's gradients hold an inf/nan."""
+        return [(self.ctx.lib.gan_grads_check, (self.grad.data_ptr(), self.total, self.ctx.ls_ptr), "grads_check")]
 
     def trainable_count(self):
         return int(sum(np.prod(s) for _, s in self.entries.values()))
@@ -226,12 +239,12 @@ class ParamSet:
         lib = self.ctx.lib
         table_ptr, n_ents, tiles, dt = self._prep_args
         ptrs = (self.master.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), self.grad.data_ptr())
-        ops = [(lib.gan_adam_begin, (self.step.data_ptr(), self.lr_t.data_ptr(), lr, b1, b2), "adam_begin"),
-               (lib.gan_adam_prepare_multi, (table_ptr, n_ents, tiles, dt) + ptrs + (self.lr_t.data_ptr(), b1, b2, eps, grad_scale),
+        ops = [(lib.gan_adam_begin, (self.step.data_ptr(), self.lr_t.data_ptr(), lr, b1, b2, self.ctx.ls_ptr), "adam_begin"),
+               (lib.gan_adam_prepare_multi, (table_ptr, n_ents, tiles, dt) + ptrs + (self.lr_t.data_ptr(), b1, b2, eps, grad_scale, self.ctx.ls_ptr),
                 "adam_prepare_multi")]
         nvec = self.total - self.vec_start
         if nvec > 0:
-            ops.append((lib.gan_adam_tf, tuple(p_ + 4 * self.vec_start for p_ in ptrs) + (nvec, self.lr_t.data_ptr(), b1, b2, eps, grad_scale),
+            ops.append((lib.gan_adam_tf, tuple(p_ + 4 * self.vec_start for p_ in ptrs) + (nvec, self.lr_t.data_ptr(), b1, b2, eps, grad_scale, self.ctx.ls_ptr),
                         "adam_tf"))
         if stream is not None:
             self.ctx.run_on(ops, stream)

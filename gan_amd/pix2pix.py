@@ -202,7 +202,7 @@ def parse_opt(argv=None):
     parser.add_argument('--beta-1', type=float, default=0.5, help='exponential decay rate for 1st moment of Adam optimizer for generator and discriminator')
     parser.add_argument('--beta-2', type=float, default=0.999, help='exponential decay rate for 2st moment of Adam optimizer for generator and discriminator')
     parser.add_argument('--weights', type=str, help='path to pretrained model weights for prediction', required='--predict' in argv)
-    parser.add_argument('--dtype', type=str, default='bf16', choices=['bf16', 'f32'], help='MI355X compute/storage dtype (f32 = exact parity path)')
+    parser.add_argument('--dtype', type=str, default='bf16', choices=['bf16', 'f16', 'f32'], help='MI355X compute/storage dtype (f32 = exact parity path)')
     parser.add_argument('--device', type=str, default='cuda:0')
     args = parser.parse_args(argv)
     assert (args.img_size == 256) or (args.img_size == 512), "img-size currently only supported for 256 x 256 or 512 x 512 pixels!"

@@ -22,13 +22,13 @@ class _StepBase:
     def _bce(self, logits_ptr, count, target, loss_idx, loss_scale, acc, grad_scale, dx_ptr):
         lib, ctx = self.ctx.lib, self.ctx
         rc = lib.gan_bce_logits(logits_ptr, count, target, loss_scale, int(acc), self.losses.data_ptr() + 4 * loss_idx,
-                                grad_scale, ctx.dt, dx_ptr, 8, self.bce_ws.data_ptr(), ctx.stream())
+                                grad_scale, ctx.dt, dx_ptr, 8, self.bce_ws.data_ptr(), ctx.ls_ptr, ctx.stream())
         L.check(rc, "bce_logits")
 
     def _l1(self, a, b, loss_idx, loss_scale, acc, grad_scale, da, stream=None):
         lib, ctx = self.ctx.lib, self.ctx
         rc = lib.gan_l1(ctx.dt, C.byref(a), C.byref(b), loss_scale, int(acc), self.losses.data_ptr() + 4 * loss_idx,
-                        grad_scale, C.byref(da) if da is not None else None, self.l1_ws.data_ptr(),
+                        grad_scale, C.byref(da) if da is not None else None, self.l1_ws.data_ptr(), ctx.ls_ptr,
                         stream.cuda_stream if stream is not None else ctx.stream())
         L.check(rc, "l1")
 
@@ -58,6 +58,10 @@ class _StepBase:
     def _update(self):
         gs = self.sync.grad_scale if self.sync is not None else 1.0
         early, done = getattr(self, '_early_adam', None), getattr(self, '_adam_done', ())
+        ctx = self.ctx
+        if ctx.ls is not None:        # fp16: a non-finite gradient anywhere skips the whole step (every network), then the scale adapts
+            for net in self.nets():
+                ctx.run(net.params.grads_check_ops())
         for net in self.nets():
             if net in done:        # updated at the end of its own backward chain
                 continue
@@ -69,6 +73,8 @@ class _StepBase:
                     self.ctx.run(net.params.adam_segment_ops(0, self.b1, self.b2, grad_scale=gs, vectors=True)[1:])
             else:
                 net.params.adam(self.lr, self.b1, self.b2, grad_scale=gs)
+        if ctx.ls is not None:
+            L.check(ctx.lib.gan_loss_scale_update(ctx.ls_ptr, ctx.ls_growth_interval, ctx.ls_max, ctx.stream()), "loss_scale_update")
         self._early_adam, self._adam_done = None, ()
 
     # ---- hipGraph capture of a whole step --------------------------------------------------------
@@ -84,7 +90,8 @@ class _StepBase:
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         split = training and self.sync is not None and self.sync.world > 1
-        if split and hasattr(self, '_capture_bucketed') and self.ctx.ms_mode == 4 and os.environ.get('GAN_AMD_DDP_BUCKETS', '1') == '1':
+        if (split and hasattr(self, '_capture_bucketed') and self.ctx.ms_mode == 4 and self.ctx.ls is None      # (fp16: the whole-step
+                and os.environ.get('GAN_AMD_DDP_BUCKETS', '1') == '1'):                                   # inf/nan check precedes every Adam)
             return self._capture_bucketed()
         g1 = torch.cuda.CUDAGraph()
         g2 = g3 = None
@@ -193,7 +200,7 @@ class Pix2PixStep(_StepBase):
         lp = self.losses.data_ptr()
         L.check(self.ctx.lib.gan_patchgan_losses(real_ptr, fake_ptr, cnt, self.ctx.dt, d.dlogits_b.t.data_ptr(), d.dlogits_ptr(0),
                                                  d.dlogits_ptr(1), 8, self.lam, lp + 8, lp, lp + 4, lp + 12,
-                                                 self.bce_ws.data_ptr(), self.ctx.stream()), "patchgan_losses")
+                                                 self.bce_ws.data_ptr(), self.ctx.ls_ptr, self.ctx.stream()), "patchgan_losses")
         if training:
             d.backward_input(1)                                       # dL_G/d gen through D(fake), pre-update D
             self._copy(d.dxin.view(Cc, Cc), g.dgen2.view(0, Cc))
@@ -235,7 +242,7 @@ class Pix2PixStep(_StepBase):
                 lane3 = self.ctx.lane_stream(3)
                 lane2.wait_stream(main)
                 self.ctx.run_on(d.params_ops(), lane2)
-                if getattr(self, '_updating', False) and self.sync is None:
+                if getattr(self, '_updating', False) and self.sync is None and self.ctx.ls is None:
                     # nothing else reads D's weights in this step: its (small) update runs at the end of its own chain
                     self.D.params.adam(self.lr, self.b1, self.b2, stream=lane2)
                     self._adam_done = (self.D,)
@@ -243,7 +250,7 @@ class Pix2PixStep(_StepBase):
                 # at its end (+2.5 % over one stage at the end; per-op dependencies, mode 5, lose 9 %)
                 g.wgrad_stream, g.wgrad_cuts = lane3, [int(c) for c in os.environ.get('GAN_AMD_WCUT', '8,12').split(',')]
                 g.stage_hook = None
-                if getattr(self, '_updating', False) and self.sync is None and os.environ.get('GAN_AMD_EARLY_ADAM', '1') == '1':
+                if getattr(self, '_updating', False) and self.sync is None and self.ctx.ls is None and os.environ.get('GAN_AMD_EARLY_ADAM', '1') == '1':
                     # a segment's kernel gradients are complete once its wgrads (a stage on lane 3) are done: its Adam +
                     # NK refresh (HBM-bound) runs on lane 4 beside the rest of the backward pass.  Stages: decoder
                     # (last, up6..up0) | down7..down4 | down3..down0 (the tail, updated after the join with the vectors)

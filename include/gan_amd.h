@@ -15,6 +15,8 @@
  *    are realised without a copy.
  *  - dtype GAN_F32: fp32 storage, exact-fp32 MFMA (v_mfma_f32_16x16x4_f32) — the parity path.
  *    dtype GAN_BF16: bf16 storage, v_mfma_f32_16x16x32_bf16, fp32 accumulate — the fast path.
+ *    dtype GAN_F16: fp16 storage, v_mfma_f32_16x16x32_f16, fp32 accumulate and fp32 master weights; used with the
+ *    dynamic loss scale below (BASELINE.json config 5; the reference itself has no mixed precision).
  *  - convolution weights are consumed in "NK" layout [16 taps][rows][k] (k contiguous), produced
  *    from the fp32 Keras-layout master by gan_weights_prepare().
  */
@@ -28,7 +30,7 @@ extern "C" {
 
 typedef void* gan_stream_t;
 
-enum { GAN_F32 = 0, GAN_BF16 = 1 };
+enum { GAN_F32 = 0, GAN_BF16 = 1, GAN_F16 = 2 };
 enum { GAN_ACT_NONE = 0, GAN_ACT_LRELU = 1, GAN_ACT_RELU = 2, GAN_ACT_TANH = 3 };
 enum { GAN_E_ARG = -1, GAN_E_SHAPE = -2, GAN_E_WORKSPACE = -3 };
 
@@ -107,7 +109,7 @@ int gan_weights_prepare_multi(const void* entries_dev, int32_t n, int32_t total_
  * (norm scales/offsets, biases) are updated with gan_adam_tf.  All four buffers 16-byte aligned. */
 int gan_adam_prepare_multi(const void* entries_dev, int32_t n, int32_t total_tiles, int32_t dtype, float* master, float* m,
                            float* v, const float* grad, const float* lr_t, float beta1, float beta2, float eps,
-                           float grad_scale, gan_stream_t stream);
+                           float grad_scale, const float* scale_state, gan_stream_t stream);
 
 /* ---- normalisation + activation ------------------------------------------------------------- */
 typedef struct GanNormDesc {
@@ -182,7 +184,7 @@ int gan_act_bwd(const GanActBwdDesc* d, gan_stream_t stream);
  * sums, added in a fixed order by a finalize launch). */
 int gan_bce_logits(const float* x, int64_t count, float target, float loss_scale, int32_t loss_accumulate,
                    float* loss_out, float grad_scale, int32_t dtype, void* dx, int32_t dx_pitch, float* workspace,
-                   gan_stream_t stream);
+                   const float* scale_state, gan_stream_t stream);
 /* The three BCE terms of one Pix2Pix / PatchGAN step in one pass (generator_loss pix2pix.py:167-188 and
  * discriminator_loss base_gan.py:227-245 with the 0.5 of pix2pix.py:206): gan_loss = BCE(1, fake),
  * disc_loss = 0.5*(BCE(1, real) + BCE(0, fake)), gradients (optional, `dtype`, element stride `pitch`):
@@ -190,19 +192,31 @@ int gan_bce_logits(const float* x, int64_t count, float target, float loss_scale
  * gan_loss + lambda * (*l1) (l1 = the already computed L1 term, pix2pix.py:184).  workspace >= 768 floats. */
 int gan_patchgan_losses(const float* real_logits, const float* fake_logits, int64_t count, int32_t dtype, void* g_dfake,
                         void* d_dreal, void* d_dfake, int32_t pitch, float lambda, const float* l1, float* gen_total,
-                        float* gan_loss, float* disc_loss, float* workspace, gan_stream_t stream);
+                        float* gan_loss, float* disc_loss, float* workspace, const float* scale_state, gan_stream_t stream);
 /* tf.reduce_mean(tf.abs(a - b)) (pix2pix.py:181, cycle_gan.py:167,176). loss_out (+)= loss_scale*mean.
  * da (optional, dtype, own pitch) = grad_scale * sign(a-b)/count. workspace >= 4096 floats. */
 int gan_l1(int32_t dtype, const GanTensor* a, const GanTensor* b, float loss_scale, int32_t loss_accumulate,
-           float* loss_out, float grad_scale, const GanTensor* da, float* workspace, gan_stream_t stream);
+           float* loss_out, float grad_scale, const GanTensor* da, float* workspace, const float* scale_state,
+           gan_stream_t stream);
 
 /* ---- optimiser ------------------------------------------------------------------------------ */
 /* tf.keras.optimizers.Adam (base_gan.py:247-252), TF form: lr_t = lr*sqrt(1-b2^t)/(1-b1^t);
  * m += (g-m)(1-b1); v += (g*g-v)(1-b2); p -= lr_t*m/(sqrt(v)+eps).  `step` is a device counter:
  * gan_adam_begin increments it and writes lr_t, so a captured graph advances correctly on replay. */
-int gan_adam_begin(int32_t* step, float* lr_t, float lr, float beta1, float beta2, gan_stream_t stream);
+int gan_adam_begin(int32_t* step, float* lr_t, float lr, float beta1, float beta2, const float* scale_state, gan_stream_t stream);
 int gan_adam_tf(float* param, float* m, float* v, const float* grad, int64_t count, const float* lr_t,
-                float beta1, float beta2, float eps, float grad_scale, gan_stream_t stream);
+                float beta1, float beta2, float eps, float grad_scale, const float* scale_state, gan_stream_t stream);
+
+/* Dynamic loss scaling for the fp16 path (GAN_F16; the reference trains in fp32 and has none - this is what
+ * tf.keras.mixed_precision.LossScaleOptimizer would add around base_gan.py:247-252).  scale_state: 4 floats on the
+ * device {scale, 1/scale, finite steps in a row, this step's gradients are non-finite}.  Every loss entry point above
+ * multiplies the GRADIENTS it writes by scale (reported losses stay unscaled); every Adam entry point multiplies the
+ * gradients it reads by 1/scale and does nothing - gan_adam_begin included - while the non-finite flag is set.
+ * Per step: backward -> gan_grads_check on each gradient buffer -> Adam -> gan_loss_scale_update (halves the scale after
+ * a non-finite step, doubles it after growth_interval finite ones, clears the flag).  scale_state == NULL everywhere:
+ * no scaling (fp32 / bf16 paths). */
+int gan_grads_check(const float* grad, int64_t count, float* scale_state, gan_stream_t stream);
+int gan_loss_scale_update(float* scale_state, int32_t growth_interval, float max_scale, gan_stream_t stream);
 
 /* ---- misc ----------------------------------------------------------------------------------- */
 /* Bernoulli(0.5) keep-mask from a counter hash of (seed, *step, stream_id, index). */

@@ -72,6 +72,8 @@ def _directional(step, nets_losses, ti, tt, eps_frac, tol):
     for net, li in nets_losses:
         P = net.params
         g, w0 = P.grad.clone(), P.master.clone()
+        if step.ctx.ls is not None:          # fp16 path: gradients carry the loss scale
+            g *= step.ctx.ls[1]
         g2 = float((g.double() ** 2).sum())
         eps = eps_frac * abs(float(base[li])) / g2
         vals = []
@@ -171,3 +173,94 @@ def test_cyclegan_bf16_directional_derivative(batch, size):
         call.set_dropmasks(O.dropout_masks(batch, size, seed=80 + i))
     tx, ty = torch.from_numpy(rx).to(ctx.device), torch.from_numpy(ry).to(ctx.device)
     _directional(st, ((st.Gg, 3), (st.Gf, 4), (st.Dx, 5), (st.Dy, 6)), tx, ty, 3e-2, 0.25)
+
+
+def test_loss_scale_state_machine():
+    """Dynamic loss scaling of the fp16 path on the device (include/gan_amd.h): a non-finite gradient raises the flag,
+    every Adam entry point then leaves weights, moments and the step counter alone, the update halves the scale; finite
+    steps un-scale the gradients and the scale doubles after `growth_interval` of them."""
+    from gan_amd.nets import Ctx
+    ctx = Ctx('cuda:0', 'f16')
+    lib, dev = ctx.lib, ctx.device
+    ls = torch.tensor([1024.0, 1.0 / 1024.0, 0.0, 0.0], device=dev)
+    n = 4096
+    rng = np.random.default_rng(0)
+    g_true = rng.standard_normal(n).astype(np.float32)
+    p0 = rng.standard_normal(n).astype(np.float32)
+    p = torch.from_numpy(p0.copy()).to(dev)
+    m, v = torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    step, lr_t = torch.zeros(1, dtype=torch.int32, device=dev), torch.zeros(1, device=dev)
+    st = ctx.stream()
+
+    def one_step(grad):
+        assert lib.gan_grads_check(grad.data_ptr(), n, ls.data_ptr(), st) == 0
+        assert lib.gan_adam_begin(step.data_ptr(), lr_t.data_ptr(), 2e-4, 0.5, 0.999, ls.data_ptr(), st) == 0
+        assert lib.gan_adam_tf(p.data_ptr(), m.data_ptr(), v.data_ptr(), grad.data_ptr(), n, lr_t.data_ptr(), 0.5, 0.999, 1e-7, 1.0,
+                               ls.data_ptr(), st) == 0
+        assert lib.gan_loss_scale_update(ls.data_ptr(), 2, 65536.0, st) == 0
+        torch.cuda.synchronize()
+
+    bad = torch.from_numpy(g_true * 1024.0).to(dev)
+    bad[1234] = float('inf')
+    one_step(bad)
+    assert step.item() == 0 and np.array_equal(p.cpu().numpy(), p0) and float(m.abs().max()) == 0.0     # skipped
+    assert ls.cpu().tolist() == [512.0, 1.0 / 512.0, 0.0, 0.0]
+    bad[1234] = float('nan')
+    one_step(bad)
+    assert step.item() == 0 and ls[0].item() == 256.0
+    opt, P = O.AdamTF(), {'w': p0.astype(np.float64)}
+    for k in range(2):                               # two finite steps: gradients arrive scaled, Adam un-scales them
+        scale = ls[0].item()
+        one_step(torch.from_numpy(g_true * scale).to(dev))
+        opt.apply(P, {'w': g_true.astype(np.float64)})
+        assert step.item() == k + 1
+        assert np.abs(p.cpu().numpy() - P['w']).max() < 1e-6
+    assert ls.cpu().tolist() == [512.0, 1.0 / 512.0, 0.0, 0.0]             # grew after growth_interval = 2 finite steps
+
+
+def test_pix2pix_f16_step_vs_oracle(monkeypatch):
+    """The fp16 storage path (v_mfma_f32_16x16x32_f16, fp32 master weights, loss-scaled gradients) on a Pix2Pix step."""
+    monkeypatch.setenv('GAN_AMD_LOSS_SCALE', '1024')
+    from gan_amd.nets import Ctx
+    from gan_amd.steps import Pix2PixStep
+    ctx = Ctx('cuda:0', 'f16')
+    B, S = 2, 256
+    st = Pix2PixStep(ctx, B, S, 1, lam=100.0, seed=123)
+    Gp, Dp = O.init_generator(1, seed=11), O.init_discriminator(1, True, seed=12)
+    st.G.params.load_numpy(Gp); st.D.params.load_numpy(Dp)
+    inp, tar = O.synthetic_pair(B, S, 1, seed=123)
+    masks = O.dropout_masks(B, S, seed=5)
+    st.g.set_dropmasks(masks)
+    G0 = {k: v.copy() for k, v in Gp.items()}
+    ref = O.pix2pix_train_step(Gp, Dp, O.AdamTF(), O.AdamTF(), inp, tar, 100.0, masks, True, return_grads=True)
+    losses = st.train_step(torch.from_numpy(inp).to(ctx.device), torch.from_numpy(tar).to(ctx.device), True).cpu().numpy()
+    gen = st.g.output_f32().cpu().numpy()
+    err = float(np.abs(gen - ref[4]).max())
+    print(f"[f16] gen max-abs err {err:.3e}; losses {losses} ref {[float(v) for v in ref[:4]]}; scale state {ctx.ls.cpu().tolist()}")
+    assert err < 2e-2 and np.allclose(losses, np.array(ref[:4], np.float64), rtol=1e-2)
+    assert ctx.ls.cpu().tolist() == [1024.0, 1.0 / 1024.0, 1.0, 0.0]        # finite step, nothing skipped
+    gG = st.G.params.to_numpy('grad')
+    gmax = max(np.linalg.norm(v) for v in ref[5].values())
+    for k, v in ref[5].items():
+        if np.linalg.norm(v) > 1e-3 * gmax:
+            assert _cos(gG[k] / 1024.0, v) > 0.98, (k, _cos(gG[k], v))
+            assert abs(np.linalg.norm(gG[k]) / 1024.0 / np.linalg.norm(v) - 1.0) < 0.05, k      # scaled by exactly the loss scale
+    newG = st.G.params.to_numpy()
+    d = np.abs(newG['down3.kernel'] - Gp['down3.kernel'])                  # Gp now holds the oracle's post-Adam weights
+    assert d.max() < 4.1e-4 and (d < 4.1e-5).mean() > 0.5
+    assert np.abs(newG['down3.kernel'] - G0['down3.kernel']).max() > 1e-4  # the step was applied
+
+
+def test_cyclegan_512_f16_batch16_directional_derivative(monkeypatch):
+    """BASELINE config 5's per-GPU shape: CycleGAN 512x512 fp16, batch 16."""
+    monkeypatch.setenv('GAN_AMD_LOSS_SCALE', '1024')
+    from gan_amd.nets import Ctx, workspace_mb_for
+    from gan_amd.steps import CycleGANStep
+    B, S = 16, 512
+    ctx = Ctx('cuda:0', 'f16', workspace_mb=workspace_mb_for(B, S))
+    st = CycleGANStep(ctx, B, S, 1, lam=10.0, seed=7, dropout=True)
+    rx, ry = O.synthetic_pair(B, S, 1, seed=31)
+    tx, ty = torch.from_numpy(rx).to(ctx.device), torch.from_numpy(ry).to(ctx.device)
+    _directional(st, ((st.Gg, 3), (st.Gf, 4), (st.Dx, 5), (st.Dy, 6)), tx, ty, 3e-2, 0.25)
+    l = st.train_step(tx, ty, True).cpu().numpy()                           # and a full step: finite, applied or cleanly skipped
+    assert np.isfinite(l).all() and ctx.ls[3].item() == 0.0
