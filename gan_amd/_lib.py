@@ -27,37 +27,45 @@ class GanPrepEntry(C.Structure):
                 ("B", C.c_int32), ("tile_start", C.c_int32), ("tiles_b", C.c_int32)]
 
 
-class GanConvDesc(C.Structure):
-    _fields_ = [("dtype", C.c_int32), ("stride", C.c_int32), ("x", GanTensor), ("y", GanTensor), ("w", C.c_void_p),
+class _Desc(C.Structure):
+    """Descriptor structs carry their own size first (include/gan_amd.h): filled in here, so call sites list only the
+    real fields; the library rejects a size it was not built with (GAN_E_ARG)."""
+
+    def __init__(self, *args, **kw):
+        super().__init__(C.sizeof(type(self)), *args, **kw)
+
+
+class GanConvDesc(_Desc):
+    _fields_ = [("struct_size", C.c_uint32), ("dtype", C.c_int32), ("stride", C.c_int32), ("x", GanTensor), ("y", GanTensor), ("w", C.c_void_p),
                 ("w_rows", C.c_int32), ("bias", C.c_void_p), ("act", C.c_int32), ("slope", C.c_float),
                 ("y_f32", C.c_int32), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
                 ("stats_partial", C.c_void_p), ("stats_groups", C.c_int32)]
 
 
-class GanWgradDesc(C.Structure):
-    _fields_ = [("dtype", C.c_int32), ("stride", C.c_int32), ("big", GanTensor), ("small", GanTensor),
+class GanWgradDesc(_Desc):
+    _fields_ = [("struct_size", C.c_uint32), ("dtype", C.c_int32), ("stride", C.c_int32), ("big", GanTensor), ("small", GanTensor),
                 ("dw", C.c_void_p), ("big_c", C.c_int32), ("small_c", C.c_int32), ("accumulate", C.c_int32),
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
 
 
-class GanNormDesc(C.Structure):
-    _fields_ = [("dtype", C.c_int32), ("y", GanTensor), ("a", GanTensor), ("groups", C.c_int32), ("eps", C.c_float),
+class GanNormDesc(_Desc):
+    _fields_ = [("struct_size", C.c_uint32), ("dtype", C.c_int32), ("y", GanTensor), ("a", GanTensor), ("groups", C.c_int32), ("eps", C.c_float),
                 ("gamma", C.c_void_p), ("beta", C.c_void_p), ("mean", C.c_void_p), ("rstd", C.c_void_p),
                 ("moving_mean", C.c_void_p), ("moving_var", C.c_void_p), ("momentum", C.c_float),
                 ("dropmask", C.c_void_p), ("act", C.c_int32), ("slope", C.c_float), ("workspace", C.c_void_p),
                 ("workspace_bytes", C.c_size_t)]
 
 
-class GanNormBwdDesc(C.Structure):
-    _fields_ = [("dtype", C.c_int32), ("y", GanTensor), ("da", GanTensor), ("da2", GanTensor), ("dy", GanTensor),
+class GanNormBwdDesc(_Desc):
+    _fields_ = [("struct_size", C.c_uint32), ("dtype", C.c_int32), ("y", GanTensor), ("da", GanTensor), ("da2", GanTensor), ("dy", GanTensor),
                 ("groups", C.c_int32), ("gamma", C.c_void_p), ("beta", C.c_void_p), ("mean", C.c_void_p),
                 ("rstd", C.c_void_p), ("dropmask", C.c_void_p), ("act", C.c_int32), ("slope", C.c_float),
                 ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("accumulate", C.c_int32), ("workspace", C.c_void_p),
                 ("workspace_bytes", C.c_size_t)]
 
 
-class GanActBwdDesc(C.Structure):
-    _fields_ = [("dtype", C.c_int32), ("a", GanTensor), ("da", GanTensor), ("da2", GanTensor), ("dy", GanTensor),
+class GanActBwdDesc(_Desc):
+    _fields_ = [("struct_size", C.c_uint32), ("dtype", C.c_int32), ("a", GanTensor), ("da", GanTensor), ("da2", GanTensor), ("dy", GanTensor),
                 ("act", C.c_int32), ("slope", C.c_float), ("dbias", C.c_void_p), ("accumulate", C.c_int32),
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
 

@@ -737,7 +737,7 @@ struct GemmPlan {
 };
 
 static int plan_gemm(const GanConvDesc* d, int op, GemmPlan* pl) {
-  if (!d || !d->x.ptr || !d->y.ptr || !d->w) return GAN_E_ARG;
+  if (!d || d->struct_size != sizeof(GanConvDesc) || !d->x.ptr || !d->y.ptr || !d->w) return GAN_E_ARG;
   if (!gan_dtype_ok(d->dtype)) return GAN_E_ARG;
   const int vec = d->dtype == GAN_F32 ? 4 : 8;
   const GanTensor &x = d->x, &y = d->y;

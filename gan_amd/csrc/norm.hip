@@ -445,7 +445,7 @@ size_t gan_norm_workspace_bytes(int32_t groups, int32_t c, int64_t rows_per_grou
 }
 
 int gan_norm_stats(const GanNormDesc* d, gan_stream_t stream) {
-  if (!d || !d->y.ptr || !d->mean || !d->rstd || !d->workspace) return GAN_E_ARG;
+  if (!d || d->struct_size != sizeof(GanNormDesc) || !d->y.ptr || !d->mean || !d->rstd || !d->workspace) return GAN_E_ARG;
   RedGeom g;
   int rc = red_geom(d->y, d->groups, d->dtype, &g);
   if (rc) return rc;
@@ -466,7 +466,7 @@ int gan_norm_stats(const GanNormDesc* d, gan_stream_t stream) {
 }
 
 int gan_norm_stats_finalize(const GanNormDesc* d, int32_t chunks, gan_stream_t stream) {
-  if (!d || !d->y.ptr || !d->mean || !d->rstd || !d->workspace || chunks <= 0) return GAN_E_ARG;
+  if (!d || d->struct_size != sizeof(GanNormDesc) || !d->y.ptr || !d->mean || !d->rstd || !d->workspace || chunks <= 0) return GAN_E_ARG;
   RedGeom g;
   int rc = red_geom(d->y, d->groups, d->dtype, &g);
   if (rc) return rc;
@@ -478,7 +478,7 @@ int gan_norm_stats_finalize(const GanNormDesc* d, int32_t chunks, gan_stream_t s
 }
 
 int gan_norm_act_fwd(const GanNormDesc* d, gan_stream_t stream) {
-  if (!d || !d->y.ptr || !d->a.ptr || !d->mean || !d->rstd || !d->gamma || !d->beta) return GAN_E_ARG;
+  if (!d || d->struct_size != sizeof(GanNormDesc) || !d->y.ptr || !d->a.ptr || !d->mean || !d->rstd || !d->gamma || !d->beta) return GAN_E_ARG;
   RedGeom g;
   int rc = red_geom(d->y, d->groups, d->dtype, &g);
   if (rc) return rc;
@@ -493,7 +493,8 @@ int gan_norm_act_fwd(const GanNormDesc* d, gan_stream_t stream) {
 }
 
 int gan_norm_act_bwd(const GanNormBwdDesc* d, gan_stream_t stream) {
-  if (!d || !d->y.ptr || !d->da.ptr || !d->dy.ptr || !d->mean || !d->rstd || !d->gamma || !d->beta || !d->workspace)
+  if (!d || d->struct_size != sizeof(GanNormBwdDesc) || !d->y.ptr || !d->da.ptr || !d->dy.ptr || !d->mean || !d->rstd || !d->gamma ||
+      !d->beta || !d->workspace)
     return GAN_E_ARG;
   RedGeom g;
   int rc = red_geom(d->y, d->groups, d->dtype, &g);
@@ -538,7 +539,7 @@ static int bias_grad_impl(int32_t dtype, const GanTensor& dy, float* dbias, int3
 }
 
 int gan_act_bwd(const GanActBwdDesc* d, gan_stream_t stream) {
-  if (!d || !d->a.ptr || !d->da.ptr || !d->dy.ptr) return GAN_E_ARG;
+  if (!d || d->struct_size != sizeof(GanActBwdDesc) || !d->a.ptr || !d->da.ptr || !d->dy.ptr) return GAN_E_ARG;
   RedGeom g;
   int rc = red_geom(d->a, 1, d->dtype, &g);
   if (rc) return rc;

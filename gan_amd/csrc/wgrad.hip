@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* slab, fl
 struct WgradPlan { WgradParams p; int TA, TB; dim3 grid; size_t slab_bytes; };
 
 static int plan_wgrad(const GanWgradDesc* d, WgradPlan* pl, bool allow_swap = true) {
-  if (!d || !d->big.ptr || !d->small.ptr || !d->dw) return GAN_E_ARG;
+  if (!d || d->struct_size != sizeof(GanWgradDesc) || !d->big.ptr || !d->small.ptr || !d->dw) return GAN_E_ARG;
   if (!gan_dtype_ok(d->dtype)) return GAN_E_ARG;
   if (((uintptr_t)d->dw | (uintptr_t)d->workspace) & 15) return GAN_E_ARG;      // float4 slab reduction
   const GanTensor &b = d->big, &s = d->small;
@@ -580,7 +580,7 @@ static bool wgrad_use_tr() {
 
 extern "C" {
 int gan_conv_wgrad(const GanWgradDesc* d, gan_stream_t stream) {
-  if (!d) return GAN_E_ARG;
+  if (!d || d->struct_size != sizeof(GanWgradDesc)) return GAN_E_ARG;
   hipStream_t st = (hipStream_t)stream;
   static int v1 = -1;
   if (v1 < 0) { const char* e = getenv("GAN_AMD_WGRAD_V1"); v1 = (e && e[0] == '1') ? 1 : 0; }

@@ -17,6 +17,8 @@
  *    dtype GAN_BF16: bf16 storage, v_mfma_f32_16x16x32_bf16, fp32 accumulate — the fast path.
  *    dtype GAN_F16: fp16 storage, v_mfma_f32_16x16x32_f16, fp32 accumulate and fp32 master weights; used with the
  *    dynamic loss scale below (BASELINE.json config 5; the reference itself has no mixed precision).
+ *  - every descriptor struct starts with `uint32_t struct_size` = sizeof(the struct) as the CALLER compiled it; an entry
+ *    point returns GAN_E_ARG when it differs from the library's own sizeof (descriptors grow by appending fields).
  *  - convolution weights are consumed in "NK" layout [16 taps][rows][k] (k contiguous), produced
  *    from the fp32 Keras-layout master by gan_weights_prepare().
  */
@@ -42,6 +44,7 @@ typedef struct GanTensor {
 
 /* ---- convolutions ------------------------------------------------------------------------- */
 typedef struct GanConvDesc {
+  uint32_t struct_size;  /* sizeof(GanConvDesc) of the caller's build */
   int32_t dtype;
   int32_t stride;        /* Conv2D: 1 or 2 (k4, zero pad 1 each side); Conv2DTranspose: 2 */
   GanTensor x;           /* GEMM-K side tensor; x.c must be a multiple of 8 (zero-padded channels) */
@@ -75,6 +78,7 @@ size_t gan_conv_workspace_bytes(const GanConvDesc* d, int op /*0 conv_fwd,1 conv
 int gan_conv_plan_info(const GanConvDesc* d, int op, int32_t* info);
 
 typedef struct GanWgradDesc {
+  uint32_t struct_size;  /* sizeof(GanWgradDesc) of the caller's build */
   int32_t dtype;
   int32_t stride;        /* 1 or 2 */
   GanTensor big;         /* tensor on the fine grid  (Conv2D: layer input x;  Conv2DTranspose: dy) */
@@ -113,6 +117,7 @@ int gan_adam_prepare_multi(const void* entries_dev, int32_t n, int32_t total_til
 
 /* ---- normalisation + activation ------------------------------------------------------------- */
 typedef struct GanNormDesc {
+  uint32_t struct_size;  /* sizeof(GanNormDesc) of the caller's build */
   int32_t dtype;
   GanTensor y;              /* raw convolution output */
   GanTensor a;              /* out: act(dropout(gamma * (y - mean) * rstd + beta)) */
@@ -141,6 +146,7 @@ int gan_norm_act_fwd(const GanNormDesc* d, gan_stream_t stream);
 size_t gan_norm_workspace_bytes(int32_t groups, int32_t c, int64_t rows_per_group);
 
 typedef struct GanNormBwdDesc {
+  uint32_t struct_size;  /* sizeof(GanNormBwdDesc) of the caller's build */
   int32_t dtype;
   GanTensor y;              /* raw convolution output saved by forward */
   GanTensor da;             /* upstream gradient w.r.t. a */
@@ -163,6 +169,7 @@ typedef struct GanNormBwdDesc {
 int gan_norm_act_bwd(const GanNormBwdDesc* d, gan_stream_t stream);
 
 typedef struct GanActBwdDesc { /* layers without normalisation: conv -> [bias] -> act */
+  uint32_t struct_size;  /* sizeof(GanActBwdDesc) of the caller's build */
   int32_t dtype;
   GanTensor a;              /* saved activation output (sign for LeakyReLU, value for tanh) */
   GanTensor da;

@@ -181,3 +181,40 @@ def test_bench_gpus_without_enough_devices_fails_loudly():
                        capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode != 0 and 'GPU(s) visible' in r.stderr, (r.returncode, r.stderr[-300:])
     assert '"metric"' not in r.stdout
+
+
+def test_header_ctypes_binding_and_integration_snippet_agree():
+    """include/gan_amd.h (parsed), gan_amd/_lib.py (the binding the product uses) and the ctypes stub printed in
+    INTEGRATION.md declare the same structs, field for field; the INTEGRATION.md snippet is executed (library load and
+    symbol binding included - no kernel is launched without a GPU)."""
+    import ctypes as C
+    import re
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, 'tools'))
+    import gen_binding
+    from gan_amd import _lib as L
+    structs = gen_binding.parse_structs()
+    assert set(structs) >= {'GanTensor', 'GanConvDesc', 'GanWgradDesc', 'GanPrepEntry', 'GanNormDesc', 'GanNormBwdDesc', 'GanActBwdDesc'}
+    for name, fields in structs.items():
+        cls = getattr(L, name)
+        got = [(f, t) for f, t in cls._fields_]
+        want = [(f, getattr(C, t[2:]) if t.startswith('C.') else getattr(L, t)) for f, t in fields]     # (c_int32 is an alias)
+        assert got == want, (name, got, want)
+        if name.endswith('Desc'):
+            assert fields[0] == ('struct_size', 'C.c_uint32') and cls().struct_size == C.sizeof(cls)
+    text = open(os.path.join(root, 'INTEGRATION.md')).read()
+    code = re.search(r"```python\nimport ctypes as C\n(.*?)```", text, flags=re.S).group(1)
+    gen = code[code.index('# --- generated'):code.index('# --- end of generated part')]
+    assert gen.split('\n', 1)[1].strip() == gen_binding.ctypes_source(['GanTensor', 'GanConvDesc']).strip()
+    ns = {}
+    cwd = os.getcwd()
+    os.chdir(root)
+    try:
+        exec("import ctypes as C\n" + code, ns)          # loads libgan_amd.so and binds gan_conv2d_fwd
+    finally:
+        os.chdir(cwd)
+    assert C.sizeof(ns['GanConvDesc']) == C.sizeof(L.GanConvDesc) and callable(ns['downsample_conv'])
+    # a descriptor with the wrong size is refused before anything is read through it
+    d = ns['GanConvDesc'](struct_size=C.sizeof(ns['GanConvDesc']) - 16, dtype=1, stride=2)
+    assert ns['lib'].gan_conv2d_fwd(C.byref(d), None) == -1

@@ -93,3 +93,16 @@ def test_cyclegan_class_one_step():
     assert len(out) == 7 and all(np.isfinite(out))
     assert abs(out[3] - (out[0] + out[2])) < out[3] and out[2] > 0      # total_g = gen_g + cycle + identity
     assert float(c.generator_g(x).abs().max()) <= 1.0
+
+
+def test_c_caller_of_the_abi():
+    """tests/c_abi_smoke.c: a plain C program (no Python, no torch) runs Conv2D + LeakyReLU through include/gan_amd.h,
+    checks it against its own scalar loop and checks that a descriptor with a wrong struct_size is refused."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, 'gan_amd', 'c_abi_smoke')
+    if not os.path.exists(exe):
+        subprocess.run(['make', '-C', os.path.join(root, 'gan_amd', 'csrc'), 'smoke'], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    print(r.stdout.strip(), r.stderr.strip())
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
