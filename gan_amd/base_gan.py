@@ -62,7 +62,7 @@ class GeneratorModel(_Model):
         B, S = x.shape[0], x.shape[1]
         key = (B, S)
         if key not in self._calls:
-            self._calls[key] = self.net.new_call(B, S, dropout=True, stream_id=7)
+            self._calls[key] = self.net.new_call(B, S, dropout=True, stream_id=40)     # (ids 0..5 / 16..21: the train / validation steps' generator calls)
         call = self._calls[key]
         call.set_input(x)
         call.forward()

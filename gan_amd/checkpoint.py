@@ -1,8 +1,9 @@
 """Checkpointing with the reference's directory / object naming (pix2pix.py:400-403,419-420,
 cycle_gan.py:437-444,460-461): `<dir>/checkpoint` (text, `model_checkpoint_path: "ckpt-N"`),
 `ckpt-N.index`, `ckpt-N.data-00000-of-00001`, keep-last-K.  Variable keys follow TF's object-graph naming
-(`generator/layer_with_weights-K/.../kernel/.ATTRIBUTES/VARIABLE_VALUE`, optimizer slots
-`.../.OPTIMIZER_SLOT/generator_optimizer/m/...`).  Kernels are stored in the Keras layouts (HWIO / HWOI), i.e.
+(`generator/layer_with_weights-K/.../kernel/.ATTRIBUTES/VARIABLE_VALUE`); optimizer hyper-parameters as
+`generator_optimizer/{iter,learning_rate,beta_1,beta_2,decay}/...`, Adam slots as
+`generator_optimizer/slot/{m,v}/<layer>.<variable>` (flat names of our own, not TF's `.OPTIMIZER_SLOT` paths).  Kernels are stored in the Keras layouts (HWIO / HWOI), i.e.
 byte-for-byte the master buffers.  The *container* is a self-describing native format (JSON index + raw
 little-endian data), NOT TensorFlow's TensorBundle SSTable: no TF-written checkpoint ships with the reference
 to pin that format against."""
@@ -84,7 +85,17 @@ class CheckpointManager:
 
     def __init__(self, checkpoint: Checkpoint, directory: str, max_to_keep: int = 1):
         self.ckpt, self.dir, self.keep = checkpoint, directory, max_to_keep
+        # a restarted run keeps honouring max_to_keep: pick up the checkpoints the state file already lists
         self.paths = []
+        state = os.path.join(directory, 'checkpoint')
+        if os.path.exists(state):
+            for name in re.findall(r'all_model_checkpoint_paths:\s*"([^"]+)"', open(state).read()):
+                if os.path.exists(os.path.join(directory, name + '.index')):
+                    self.paths.append(os.path.join(directory, name))
+            for pth in self.paths:
+                m = re.search(r'ckpt-(\d+)$', pth)
+                if m:
+                    self.ckpt.save_counter = max(self.ckpt.save_counter, int(m.group(1)))
 
     def save(self):
         os.makedirs(self.dir, exist_ok=True)

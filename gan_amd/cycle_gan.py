@@ -4,12 +4,9 @@ shared backward and four Adam updates run as one captured hipGraph (gan_amd/step
 from __future__ import annotations
 
 import argparse
-import json
 import os
 import random
 import sys
-import time
-from datetime import datetime
 
 import numpy as np
 import torch
@@ -18,7 +15,8 @@ from . import data as D
 from .base_gan import GAN
 from .checkpoint import Checkpoint, CheckpointManager, latest_checkpoint
 from .steps import CycleGANStep
-from .utils import cyclegan_losses, make_fig
+from .runner import Run, plot_loss_curves, run_epochs, save_panels
+from .utils import cyclegan_losses
 
 
 class CycleGAN(GAN):
@@ -98,7 +96,7 @@ class CycleGAN(GAN):
         if key not in self._steps:
             st = CycleGANStep(self.ctx, batch, self.config['img_size'], int(self.config['channels']), lam=self.config['lambda'],
                               lr=self.config['learning_rate'], beta_1=self.config['beta_1'], beta_2=self.config['beta_2'],
-                              seed=int(self.config.get('seed', 123)), nets=tuple(m.net for m in self._models()))
+                              seed=int(self.config.get('seed', 123)), mask_stream=0 if training else 16, nets=tuple(m.net for m in self._models()))
             st.sync = self.sync
             saved = [(ps, ps.master.clone(), ps.m.clone(), ps.v.clone(), ps.step.clone()) for ps in (m.net.params for m in self._models())]
             replay = st.capture(training=training)
@@ -116,72 +114,41 @@ class CycleGAN(GAN):
 
     # ---- images / loops (cycle_gan.py:179-204, 278-376) ------------------------------------------
     def generate_images(self, model, test_input, path_filename: str):
-        import matplotlib
-        matplotlib.use('Agg')
-        import matplotlib.pyplot as plt
-        prediction = model(test_input, training=True).cpu().numpy()
-        test_input = np.asarray(torch.as_tensor(test_input).cpu())
-        plt.figure(figsize=(12, 6))
-        display_list = [test_input[0], prediction[0]]
-        title = ['Input Image', 'Predicted Image']
-        for i in range(2):
-            plt.subplot(1, 2, i + 1)
-            plt.title(title[i])
-            if self.config['channels'] == '1':
-                plt.imshow(display_list[i][..., 0] * 0.5 + 0.5, cmap=plt.get_cmap('gray'))
-            else:
-                plt.imshow(np.clip(display_list[i] * 0.5 + 0.5, 0, 1))
-            plt.axis('off')
-            plt.tight_layout()
-        plt.savefig(path_filename, dpi=200)
-        plt.close()
+        """Input | `model(test_input, training=True)` (cycle_gan.py:186)."""
+        pred = model(test_input, training=True).cpu().numpy()
+        save_panels(path_filename, [('Input Image', np.asarray(torch.as_tensor(test_input).cpu())[0]), ('Predicted Image', pred[0])],
+                    gray=self.config['channels'] == '1')
+
+    @staticmethod
+    def _zipped(ds_x, ds_y):
+        """tf.data.Dataset.zip of the two unpaired sets (cycle_gan.py:297): stops at the shorter one; a last partial batch
+        on one side is cut to the other's size.  Both iterators are closed, so their decode threads end with the pass."""
+        ix, iy = iter(ds_x), iter(ds_y)
+        try:
+            for (x,), (y,) in zip(ix, iy):
+                n = min(x.shape[0], y.shape[0])
+                yield x[:n], y[:n]
+        finally:
+            ix.close(); iy.close()
 
     def fit(self, train_X, train_Y, val_X, val_Y, test, output_path: str, checkpoint_manager=None):
         print("\nTraining...\n", flush=True)
-        test = next(iter(test))[0]
-        start = time.time()
-        train_cost_functions, val_cost_functions = cyclegan_losses(), cyclegan_losses()
-        keys = list(train_cost_functions.keys())
-        for epoch in range(self.config['epochs']):
-            mini_batch_count = 1
-            tr, va = [], []
-            for (image_x,), (image_y,) in zip(train_X, train_Y):          # tf.data.Dataset.zip: stops at the shorter set
-                if image_x.shape[0] != image_y.shape[0]:
-                    n = min(image_x.shape[0], image_y.shape[0])
-                    image_x, image_y = image_x[:n], image_y[:n]
-                tr.append(torch.stack(self.train_step(image_x, image_y)))
-                if mini_batch_count % 100 == 0:
-                    print('.', end='', flush=True)
-                mini_batch_count += 1
-            for (image_x,), (image_y,) in zip(val_X, val_Y):
-                if image_x.shape[0] != image_y.shape[0]:
-                    n = min(image_x.shape[0], image_y.shape[0])
-                    image_x, image_y = image_x[:n], image_y[:n]
-                va.append(torch.stack(self.train_step(image_x, image_y, training=False)))
-            trm = torch.stack(tr).mean(0).cpu().tolist()
-            vam = torch.stack(va).mean(0).cpu().tolist() if va else [float('nan')] * 7
-            for k, a, b in zip(keys, trm, vam):
-                train_cost_functions[k].append(a)
-                val_cost_functions[k].append(b)
-            test_img_path = output_path + '/test_images'
-            os.makedirs(test_img_path, exist_ok=True)
-            if ((epoch + 1) % 5 == 0) and ((epoch + 1) != self.config['epochs']):
-                if checkpoint_manager is not None:
-                    checkpoint_manager.save()
-                self.generate_images(self.generator_g, test[:1], path_filename=os.path.join(test_img_path, f"epoch_{epoch + 1}.png"))
-            if (epoch + 1) == self.config['epochs']:
-                if checkpoint_manager is not None:
-                    checkpoint_manager.save()
-            print(f'\nCumulative training duration at end of epoch {epoch + 1}: {(time.time() - start) / 60:.2f} min')
-            print(f"Train X->Y generator loss: {round(train_cost_functions['Total X->Y Generator Loss'][-1], 2)}, "
-                  f"val: {round(val_cost_functions['Total X->Y Generator Loss'][-1], 2)}\n")
-        return train_cost_functions, val_cost_functions
+        it = iter(test)
+        example = next(it)[0]
+        it.close()
+        samples = os.path.join(output_path, 'test_images')
+        os.makedirs(samples, exist_ok=True)
+        save = checkpoint_manager.save if checkpoint_manager is not None else (lambda: None)
+        sample = lambda epoch: self.generate_images(self.generator_g, example[:1], os.path.join(samples, f"epoch_{epoch}.png"))
+        return run_epochs(self.config['epochs'], list(cyclegan_losses()), lambda: self._zipped(train_X, train_Y),
+                          lambda: self._zipped(val_X, val_Y), self.train_step, save, sample,
+                          ('Total X->Y Generator Loss', 'Discriminator Y Loss'))
 
     def predict(self, predict_ds, output_path: str):
         plot_path = os.path.join(output_path, 'prediction_images')
         os.makedirs(plot_path)
-        for img_counter, i in enumerate(predict_ds.unbatch()):
-            self.generate_images(self.generator_g, np.expand_dims(i[0], axis=0), plot_path + "/" + f"img{img_counter}.png")
+        for k, (img,) in enumerate(predict_ds.unbatch()):
+            self.generate_images(self.generator_g, img[None], os.path.join(plot_path, f"img{k}.png"))
 
 
 def parse_opt(argv=None):
@@ -219,51 +186,32 @@ def parse_opt(argv=None):
 
 
 def main(opt):
-    os.makedirs(opt.output, exist_ok=True)
-    full_path = opt.output + '/' + datetime.now().strftime("%Y-%m-%d-%Hh%M")
-    os.makedirs(full_path, exist_ok=True)
-    log_dir = os.path.join(full_path, 'logs')
-    os.makedirs(log_dir, exist_ok=True)
-    if opt.logging == 'true':
-        sys.stdout = open(os.path.join(log_dir, "Log.txt"), "w")
-        sys.stderr = sys.stdout
-    cgan = CycleGAN(vars(opt))
-    checkpoint = Checkpoint(generator_g=cgan.generator_g, generator_f=cgan.generator_f, discriminator_x=cgan.discriminator_x,
-                            discriminator_y=cgan.discriminator_y, generator_g_optimizer=cgan.generator_g_optimizer,
-                            generator_f_optimizer=cgan.generator_f_optimizer,
-                            discriminator_x_optimizer=cgan.discriminator_x_optimizer,
-                            discriminator_y_optimizer=cgan.discriminator_y_optimizer)
-    with open(os.path.join(log_dir, 'config.json'), 'w') as f:
-        json.dump(cgan.config, f)
-    if opt.predict:
-        prediction_dataset, _, _, _, _ = cgan.image_pipeline(predict=True)
-        checkpoint.restore(latest_checkpoint(opt.weights))
-        cgan.predict(prediction_dataset, full_path)
-    if opt.train:
-        train_X, train_Y, val_X, val_Y, test = cgan.image_pipeline(predict=False)
-        if opt.save_weights == 'true':
-            manager = CheckpointManager(checkpoint, os.path.join(full_path, 'training_checkpoints'), max_to_keep=3)
+    run = Run(opt.output, log_to_file=opt.logging == 'true', strict_logs=False)
+    try:
+        cgan = CycleGAN(vars(opt))
+        names = ('generator_g', 'generator_f', 'discriminator_x', 'discriminator_y')
+        objects = {n: getattr(cgan, n) for n in names}
+        objects.update({n + '_optimizer': getattr(cgan, n + '_optimizer') for n in names})
+        checkpoint = Checkpoint(**objects)                     # object names of cycle_gan.py:437-444
+        run.write_json('config.json', cgan.config)
+        if opt.predict:
+            dataset = cgan.image_pipeline(predict=True)[0]
+            checkpoint.restore(latest_checkpoint(opt.weights))
+            cgan.predict(dataset, run.root)
         else:
-            manager = None
-        train_metrics, val_metrics = cgan.fit(train_X, train_Y, val_X, val_Y, test, output_path=full_path, checkpoint_manager=manager)
-        final_test_imgs = full_path + '/final_test_imgs'
-        os.makedirs(final_test_imgs, exist_ok=False)
-        for img_counter, i in enumerate(test.unbatch()):
-            cgan.generate_images(cgan.generator_g, np.expand_dims(i[0], axis=0), final_test_imgs + "/" + f"img{img_counter}.png")
-        with open(os.path.join(log_dir, 'train_metrics.json'), 'w') as f:
-            json.dump(train_metrics, f)
-        with open(os.path.join(log_dir, 'val_metrics.json'), 'w') as f:
-            json.dump(val_metrics, f)
-        import pandas as pd
-        for key in train_metrics.keys():
-            tr = pd.DataFrame(train_metrics[key]).reset_index()
-            va = pd.DataFrame(val_metrics[key]).reset_index()
-            tr['index'] = tr['index'] + 1
-            tr = tr.set_index('index')
-            va['index'] = va['index'] + 1
-            va = va.set_index('index')
-            make_fig(tr, va, title='CycleGAN ' + key, output_path=os.path.join(full_path, 'figs'))
-    print("Done.")
+            train_X, train_Y, val_X, val_Y, test = cgan.image_pipeline(predict=False)
+            manager = (CheckpointManager(checkpoint, os.path.join(run.root, 'training_checkpoints'), max_to_keep=3)
+                       if opt.save_weights == 'true' else None)
+            train_metrics, val_metrics = cgan.fit(train_X, train_Y, val_X, val_Y, test, run.root, checkpoint_manager=manager)
+            final = run.dir('final_test_imgs', fresh=True)
+            for k, (img,) in enumerate(test.unbatch()):
+                cgan.generate_images(cgan.generator_g, img[None], os.path.join(final, f"img{k}.png"))
+            run.write_json('train_metrics.json', train_metrics)
+            run.write_json('val_metrics.json', val_metrics)
+            plot_loss_curves(train_metrics, val_metrics, 'CycleGAN', os.path.join(run.root, 'figs'))
+        print("Done.")
+    finally:
+        run.close()
 
 
 if __name__ == '__main__':

@@ -1,7 +1,7 @@
 """Host-side input pipeline: the reference's tf.data / tf.image steps restated with
 PIL + numpy — decode, left/right split, nearest-neighbour resize, random jitter, normalise, batch
 (base_gan.py:26-61, pix2pix.py:34-165, cycle_gan.py:40-152).  CPU I/O, not part of the accelerated path; a
-background thread keeps one batch ahead and uploads it to HBM."""
+background thread decodes ahead (CPU only), the consuming thread pins and uploads."""
 from __future__ import annotations
 
 import os
@@ -91,18 +91,31 @@ class Batches:
     def __len__(self):
         return (len(self.files) + self.bs - 1) // self.bs
 
-    def _produce(self, files, q):
+    def _produce(self, files, q, stop):
+        """Worker thread: decode + augment + stack on the CPU only.  It never touches the GPU (a pin_memory() or an upload
+        from here could land inside the main thread's hipGraph capture and invalidate it); errors travel to the consumer."""
         import torch
         try:
             for i in range(0, len(files), self.bs):
                 ex = [self.make_example(f) for f in files[i:i + self.bs]]
-                batch = tuple(torch.from_numpy(np.ascontiguousarray(np.stack([e[k] for e in ex]))) for k in range(len(ex[0])))
-                if self.device is not None:
-                    batch = tuple(t.pin_memory().to(self.device, non_blocking=True) if t.device.type == 'cpu' and
-                                  str(self.device).startswith('cuda') else t.to(self.device) for t in batch)
-                q.put(batch)
-        finally:
-            q.put(None)
+                item = tuple(torch.from_numpy(np.ascontiguousarray(np.stack([e[k] for e in ex]))) for k in range(len(ex[0])))
+                while not stop.is_set():
+                    try:
+                        q.put(item, timeout=0.1)
+                        break
+                    except queue.Full:
+                        continue
+                if stop.is_set():
+                    return
+            item = None
+        except BaseException as e:          # corrupt image, bad path ...: re-raised by __iter__
+            item = e
+        while not stop.is_set():
+            try:
+                q.put(item, timeout=0.1)
+                return
+            except queue.Full:
+                continue
 
     def __iter__(self):
         files = self.files
@@ -110,13 +123,22 @@ class Batches:
             r = random.Random(self.shuffle_seed + self.epoch)
             files = r.sample(files, len(files))
         self.epoch += 1
-        q = queue.Queue(maxsize=self.prefetch)
-        threading.Thread(target=self._produce, args=(files, q), daemon=True).start()
-        while True:
-            b = q.get()
-            if b is None:
-                return
-            yield b
+        q, stop = queue.Queue(maxsize=self.prefetch), threading.Event()
+        th = threading.Thread(target=self._produce, args=(files, q, stop), daemon=True)
+        th.start()
+        cuda = self.device is not None and str(self.device).startswith('cuda')
+        try:
+            while True:
+                b = q.get()
+                if b is None:
+                    return
+                if isinstance(b, BaseException):
+                    raise b
+                if self.device is not None:      # upload in the consumer (the thread that owns the stream / any capture)
+                    b = tuple((t.pin_memory() if cuda else t).to(self.device, non_blocking=cuda) for t in b)
+                yield b
+        finally:                                  # abandoned iterator (zip() of unequal sets, next(iter(..))): release the worker
+            stop.set()
 
     def unbatch(self):
         for f in self.files:

@@ -448,6 +448,12 @@ class GenCall:
             self.stats[name] = (torch.zeros(groups * c, dtype=f32, device=dev), torch.zeros(groups * c, dtype=f32, device=dev))
             return self.stats[name]
 
+        try:        # data-parallel replicas draw different masks (the hash mixes the rank in through the seed)
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized():
+                seed = (seed + 0x9E3779B1 * dist.get_rank()) & 0x7FFFFFFFFFFFFFFF
+        except Exception:
+            pass
         self.masks = [torch.ones((B, hs[6 - j], hs[6 - j], 512), dtype=torch.uint8, device=dev) for j in range(3)] if dropout else None
         self.mask_ops = []
         if dropout:          # the three Dropout(0.5) masks of this call in one launch

@@ -4,11 +4,8 @@ arithmetic of `train_step` runs as one captured hipGraph of hand-written MI355X 
 from __future__ import annotations
 
 import argparse
-import json
 import os
 import sys
-import time
-from datetime import datetime
 
 import numpy as np
 import torch
@@ -17,7 +14,8 @@ from . import data as D
 from .base_gan import GAN
 from .checkpoint import Checkpoint, CheckpointManager, latest_checkpoint
 from .steps import Pix2PixStep
-from .utils import make_fig, pix2pix_losses
+from .runner import Run, plot_loss_curves, run_epochs, save_panels
+from .utils import pix2pix_losses
 
 
 class Pix2Pix(GAN):
@@ -82,12 +80,11 @@ class Pix2Pix(GAN):
         if key not in self._steps:
             st = Pix2PixStep(self.ctx, batch, self.config['img_size'], int(self.config['channels']), lam=self.config['lambda'],
                              lr=self.config['learning_rate'], beta_1=self.config['beta_1'], beta_2=self.config['beta_2'],
-                             seed=int(self.config.get('seed', 123)), nets=(self.generator.net, self.discriminator.net))
+                             seed=int(self.config.get('seed', 123)), mask_stream=0 if training else 16, nets=(self.generator.net, self.discriminator.net))
             st.sync = self.sync
-            saved = self._snapshot() if training else None     # capture() runs warm-up steps: undo them
+            saved = self._snapshot()       # capture() runs warm-up passes (they also move BatchNorm's moving statistics): undo them
             replay = st.capture(training=training)
-            if saved is not None:
-                self._restore(saved)
+            self._restore(saved)
             self._steps[key] = (st, replay)
         return self._steps[key]
 
@@ -112,68 +109,30 @@ class Pix2Pix(GAN):
 
     # ---- images / loops (pix2pix.py:220-339) -----------------------------------------------------
     def generate_images(self, model, test_input, tar, path_filename: str):
-        import matplotlib
-        matplotlib.use('Agg')
-        import matplotlib.pyplot as plt
-        prediction = model(test_input, training=True).cpu().numpy()
-        test_input, tar = np.asarray(torch.as_tensor(test_input).cpu()), np.asarray(torch.as_tensor(tar).cpu())
-        plt.figure(figsize=(15, 6))
-        display_list = [test_input[0], tar[0], prediction[0]]
-        title = ['Input Image', 'Ground Truth', 'Predicted Image']
-        for i in range(3):
-            plt.subplot(1, 3, i + 1)
-            plt.title(title[i])
-            if self.config['channels'] == '1':
-                plt.imshow(display_list[i][..., 0] * 0.5 + 0.5, cmap=plt.get_cmap('gray'))
-            else:
-                plt.imshow(np.clip(display_list[i] * 0.5 + 0.5, 0, 1))
-            plt.axis('off')
-            plt.tight_layout()
-        plt.savefig(path_filename, dpi=200)
-        plt.close()
+        """Input | ground truth | `model(test_input, training=True)` (batch statistics and dropout on, pix2pix.py:228)."""
+        pred = model(test_input, training=True).cpu().numpy()
+        host = lambda t: np.asarray(torch.as_tensor(t).cpu())
+        save_panels(path_filename, [('Input Image', host(test_input)[0]), ('Ground Truth', host(tar)[0]), ('Predicted Image', pred[0])],
+                    gray=self.config['channels'] == '1')
 
     def fit(self, train_ds, val_ds, test_ds, output_path: str, checkpoint_manager=None):
         print("\nTraining...\n", flush=True)
-        example_input, example_target = next(iter(test_ds))
-        start = time.time()
-        train_cost_functions, val_cost_functions = pix2pix_losses(), pix2pix_losses()
-        keys = list(train_cost_functions.keys())
-        for epoch in range(self.config['epochs']):
-            mini_batch_count = 1
-            tr, va = [], []
-            for input_image, target in train_ds:
-                tr.append(torch.stack(self.train_step(input_image, target, True)))   # stays on device: no per-step sync
-                if mini_batch_count % 100 == 0:
-                    print('.', end='', flush=True)
-                mini_batch_count += 1
-            for input_image, target in val_ds:
-                va.append(torch.stack(self.train_step(input_image, target, False)))
-            trm = torch.stack(tr).mean(0).cpu().tolist()          # one drain per epoch
-            vam = torch.stack(va).mean(0).cpu().tolist() if va else [float('nan')] * 4
-            for k, a, b in zip(keys, trm, vam):
-                train_cost_functions[k].append(a)
-                val_cost_functions[k].append(b)
-            test_img_path = output_path + '/test_images'
-            os.makedirs(test_img_path, exist_ok=True)
-            if ((epoch + 1) % 5 == 0) and ((epoch + 1) != self.config['epochs']):
-                if checkpoint_manager is not None:
-                    checkpoint_manager.save()
-                self.generate_images(self.generator, example_input[:1], example_target[:1],
-                                     path_filename=os.path.join(test_img_path, f"epoch_{epoch + 1}.png"))
-            if (epoch + 1) == self.config['epochs']:
-                if checkpoint_manager is not None:
-                    checkpoint_manager.save()
-            print(f'\nCumulative training duration at end of epoch {epoch + 1}: {(time.time() - start) / 60:.2f} min')
-            print(f"Train generator loss: {round(train_cost_functions['Generator Total Loss'][-1], 2)}, train discriminator loss: {round(train_cost_functions['Discriminator Loss'][-1], 2)}")
-            print(f"Val generator loss: {round(val_cost_functions['Generator Total Loss'][-1], 2)}, val discriminator loss: {round(val_cost_functions['Discriminator Loss'][-1], 2)}\n")
-        return train_cost_functions, val_cost_functions
+        it = iter(test_ds)
+        example_input, example_target = next(it)
+        it.close()
+        samples = os.path.join(output_path, 'test_images')
+        os.makedirs(samples, exist_ok=True)
+        save = checkpoint_manager.save if checkpoint_manager is not None else (lambda: None)
+        sample = lambda epoch: self.generate_images(self.generator, example_input[:1], example_target[:1],
+                                                    os.path.join(samples, f"epoch_{epoch}.png"))
+        return run_epochs(self.config['epochs'], list(pix2pix_losses()), lambda: train_ds, lambda: val_ds, self.train_step,
+                          save, sample, ('Generator Total Loss', 'Discriminator Loss'))
 
     def predict(self, predict_ds, output_path: str):
         plot_path = os.path.join(output_path, 'prediction_images')
         os.makedirs(plot_path, exist_ok=False)
-        for img_counter, i in enumerate(predict_ds.unbatch()):
-            self.generate_images(self.generator, np.expand_dims(i[0], axis=0), np.expand_dims(i[1], axis=0),
-                                 plot_path + "/" + f"img{img_counter}.png")
+        for k, (inp, tar) in enumerate(predict_ds.unbatch()):
+            self.generate_images(self.generator, inp[None], tar[None], os.path.join(plot_path, f"img{k}.png"))
 
 
 def parse_opt(argv=None):
@@ -212,50 +171,30 @@ def parse_opt(argv=None):
 
 
 def main(opt):
-    os.makedirs(opt.output, exist_ok=True)
-    full_path = opt.output + '/' + datetime.now().strftime("%Y-%m-%d-%Hh%M")
-    os.makedirs(full_path, exist_ok=True)
-    log_dir = os.path.join(full_path, 'logs')
-    os.makedirs(log_dir, exist_ok=False)
-    if opt.logging == 'true':
-        sys.stdout = open(os.path.join(log_dir, "Log.txt"), "w")
-        sys.stderr = sys.stdout
-    p2p = Pix2Pix(vars(opt))
-    checkpoint = Checkpoint(generator_optimizer=p2p.generator_optimizer, discriminator_optimizer=p2p.discriminator_optimizer,
-                            generator=p2p.generator, discriminator=p2p.discriminator)
-    with open(os.path.join(log_dir, 'config.json'), 'w') as f:
-        json.dump(p2p.config, f)
-    if opt.predict:
-        prediction_dataset, _, _ = p2p.image_pipeline(predict=True)
-        checkpoint.restore(latest_checkpoint(opt.weights))
-        p2p.predict(prediction_dataset, full_path)
-    if opt.train:
-        train, validation, test = p2p.image_pipeline(predict=False)
-        if opt.save_weights == 'true':
-            manager = CheckpointManager(checkpoint, os.path.join(full_path, 'training_checkpoints'), max_to_keep=1)
+    run = Run(opt.output, log_to_file=opt.logging == 'true', strict_logs=True)
+    try:
+        p2p = Pix2Pix(vars(opt))
+        checkpoint = Checkpoint(generator_optimizer=p2p.generator_optimizer, discriminator_optimizer=p2p.discriminator_optimizer,
+                                generator=p2p.generator, discriminator=p2p.discriminator)
+        run.write_json('config.json', p2p.config)
+        if opt.predict:
+            dataset, _, _ = p2p.image_pipeline(predict=True)
+            checkpoint.restore(latest_checkpoint(opt.weights))
+            p2p.predict(dataset, run.root)
         else:
-            manager = None
-        train_metrics, val_metrics = p2p.fit(train_ds=train, val_ds=validation, test_ds=test, output_path=full_path,
-                                             checkpoint_manager=manager)
-        final_test_imgs = full_path + '/final_test_imgs'
-        os.makedirs(final_test_imgs, exist_ok=False)
-        for img_counter, i in enumerate(test.unbatch()):
-            p2p.generate_images(p2p.generator, np.expand_dims(i[0], axis=0), np.expand_dims(i[1], axis=0),
-                                final_test_imgs + "/" + f"img{img_counter}.png")
-        with open(os.path.join(log_dir, 'train_metrics.json'), 'w') as f:
-            json.dump(train_metrics, f)
-        with open(os.path.join(log_dir, 'val_metrics.json'), 'w') as f:
-            json.dump(val_metrics, f)
-        import pandas as pd
-        for key in train_metrics.keys():
-            tr = pd.DataFrame(train_metrics[key]).reset_index()
-            va = pd.DataFrame(val_metrics[key]).reset_index()
-            tr['index'] = tr['index'] + 1
-            tr = tr.set_index('index')
-            va['index'] = va['index'] + 1
-            va = va.set_index('index')
-            make_fig(tr, va, title='Pix2Pix ' + key, output_path=os.path.join(full_path, 'figs'))
-    print("Done.")
+            train, validation, test = p2p.image_pipeline(predict=False)
+            manager = (CheckpointManager(checkpoint, os.path.join(run.root, 'training_checkpoints'), max_to_keep=1)
+                       if opt.save_weights == 'true' else None)
+            train_metrics, val_metrics = p2p.fit(train, validation, test, run.root, checkpoint_manager=manager)
+            final = run.dir('final_test_imgs', fresh=True)
+            for k, (inp, tar) in enumerate(test.unbatch()):
+                p2p.generate_images(p2p.generator, inp[None], tar[None], os.path.join(final, f"img{k}.png"))
+            run.write_json('train_metrics.json', train_metrics)
+            run.write_json('val_metrics.json', val_metrics)
+            plot_loss_curves(train_metrics, val_metrics, 'Pix2Pix', os.path.join(run.root, 'figs'))
+        print("Done.")
+    finally:
+        run.close()
 
 
 if __name__ == '__main__':

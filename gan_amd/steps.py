@@ -132,7 +132,7 @@ class _StepBase:
 
 class Pix2PixStep(_StepBase):
     def __init__(self, ctx: Ctx, batch, size, channels=1, lam=100.0, lr=2e-4, beta_1=0.5, beta_2=0.999,
-                 seed=123, dropout=True, nets=None):
+                 seed=123, dropout=True, nets=None, mask_stream=0):
         self.ctx, self.B, self.S, self.C = ctx, batch, size, channels
         self.lam, self.lr, self.b1, self.b2 = float(lam), lr, beta_1, beta_2
         if nets is not None:          # share weights with an existing step / model objects
@@ -140,7 +140,7 @@ class Pix2PixStep(_StepBase):
         else:
             self.G = GeneratorNet(ctx, channels, 'batchnorm', seed=seed)          # pix2pix.py:29
             self.D = DiscriminatorNet(ctx, channels, True, 'batchnorm', seed=seed + 1)   # pix2pix.py:30
-        self.g = self.G.new_call(batch, size, dropout=dropout, seed=seed)
+        self.g = self.G.new_call(batch, size, dropout=dropout, seed=seed, stream_id=mask_stream)   # mask_stream: train / val steps draw different masks
         self.d = self.D.new_call(batch, size, calls=2)
         self.losses = torch.zeros(8, dtype=torch.float32, device=ctx.device)
         self.l1_ws = torch.zeros(4096, dtype=torch.float32, device=ctx.device)
@@ -397,7 +397,7 @@ class Pix2PixStep(_StepBase):
 
 class CycleGANStep(_StepBase):
     def __init__(self, ctx: Ctx, batch, size, channels=1, lam=10.0, lr=2e-4, beta_1=0.5, beta_2=0.999,
-                 seed=123, dropout=True, nets=None):
+                 seed=123, dropout=True, nets=None, mask_stream=0):
         self.ctx, self.B, self.S, self.C = ctx, batch, size, channels
         self.lam, self.lr, self.b1, self.b2 = float(lam), lr, beta_1, beta_2
         n = 'instancenorm'                                                    # cycle_gan.py:30-33
@@ -408,7 +408,7 @@ class CycleGANStep(_StepBase):
             self.Gf = GeneratorNet(ctx, channels, n, seed=seed + 1)
             self.Dx = DiscriminatorNet(ctx, channels, False, n, seed=seed + 2)
             self.Dy = DiscriminatorNet(ctx, channels, False, n, seed=seed + 3)
-        mk = lambda net, sid: net.new_call(batch, size, dropout=dropout, seed=seed, stream_id=sid)
+        mk = lambda net, sid: net.new_call(batch, size, dropout=dropout, seed=seed, stream_id=mask_stream + sid)
         self.fy, self.cx = mk(self.Gg, 0), mk(self.Gf, 1)      # fake_y = G_g(x); cycled_x = G_f(fake_y)
         self.fx, self.cy = mk(self.Gf, 2), mk(self.Gg, 3)      # fake_x = G_f(y); cycled_y = G_g(fake_x)
         self.sx, self.sy = mk(self.Gf, 4), mk(self.Gg, 5)      # same_x = G_f(x); same_y = G_g(y)

@@ -218,3 +218,33 @@ def test_header_ctypes_binding_and_integration_snippet_agree():
     # a descriptor with the wrong size is refused before anything is read through it
     d = ns['GanConvDesc'](struct_size=C.sizeof(ns['GanConvDesc']) - 16, dtype=1, stride=2)
     assert ns['lib'].gan_conv2d_fwd(C.byref(d), None) == -1
+
+
+def test_batches_forward_errors_and_release_their_worker(tmp_path):
+    """The prefetch worker is CPU-only, hands its exceptions to the consumer and ends when the iterator is abandoned."""
+    import threading
+    import time
+    from gan_amd import data as D
+    files = [f"f{i}" for i in range(20)]
+
+    def ok(f):
+        return (np.full((4, 4, 1), float(f[1:]), np.float32),)
+
+    def broken(f):
+        if f == 'f5':
+            raise ValueError("corrupt image f5")
+        return ok(f)
+
+    got = [b[0][:, 0, 0, 0].tolist() for b in D.Batches(files, ok, 3)]
+    assert sum(got, []) == [float(i) for i in range(20)] and len(got[-1]) == 2          # last partial batch kept
+    with pytest.raises(ValueError, match="corrupt image f5"):
+        list(D.Batches(files, broken, 2))
+    before = threading.active_count()
+    it = iter(D.Batches(files, ok, 1, prefetch=1))
+    next(it)
+    it.close()                                           # like zip() over unequal sets / next(iter(test_ds))
+    for _ in range(50):
+        if threading.active_count() <= before:
+            break
+        time.sleep(0.05)
+    assert threading.active_count() <= before

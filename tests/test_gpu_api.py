@@ -106,3 +106,42 @@ def test_c_caller_of_the_abi():
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     print(r.stdout.strip(), r.stderr.strip())
     assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+
+
+def _make_singles(d, n, rng):
+    from PIL import Image
+    os.makedirs(d, exist_ok=True)
+    for i in range(n):
+        Image.fromarray(rng.integers(0, 256, (80, 96), dtype=np.uint8), 'L').save(os.path.join(d, f"s{i}.png"))
+
+
+def test_cyclegan_cli_train_then_predict(tmp_path):
+    """cycle_gan.py --train / --predict end to end (cycle_gan.py:278-376, 416-497): unequal X / Y sets (the zip stops at the
+    shorter one), 5 epochs so that the mid-run checkpoint + sample image cadence is exercised, keep-3 manager, restore."""
+    from gan_amd import cycle_gan
+    rng = np.random.default_rng(1)
+    dx, dy = str(tmp_path / 'X'), str(tmp_path / 'Y')
+    _make_singles(dx, 7, rng)
+    _make_singles(dy, 5, rng)
+    out = str(tmp_path / 'out')
+    opt = cycle_gan.parse_opt(['--input-images', dx, '--target-images', dy, '--output', out, '--train', '--epochs', '6', '--batch-size', '2',
+                               '--test-img', '1', '--validation-size', '0.2', '--logging', 'true'])
+    cycle_gan.main(opt)
+    run = os.path.join(out, sorted(os.listdir(out))[0])
+    assert sorted(os.listdir(run)) == ['figs', 'final_test_imgs', 'logs', 'test_images', 'training_checkpoints']
+    assert sorted(os.listdir(os.path.join(run, 'logs'))) == ['Log.txt', 'config.json', 'train_metrics.json', 'val_metrics.json']
+    assert 'Cumulative training duration at end of epoch 6' in open(os.path.join(run, 'logs', 'Log.txt')).read()
+    tm = json.load(open(os.path.join(run, 'logs', 'train_metrics.json')))
+    vm = json.load(open(os.path.join(run, 'logs', 'val_metrics.json')))
+    keys = ['X->Y Generator Loss', 'Y->X Generator Loss', 'Total Cycle Loss', 'Total X->Y Generator Loss',
+            'Total Y->X Generator Loss', 'Discriminator X Loss', 'Discriminator Y Loss']
+    assert list(tm) == keys and list(vm) == keys
+    assert all(len(v) == 6 and np.isfinite(v).all() for v in tm.values()) and all(len(v) == 6 for v in vm.values())
+    assert os.listdir(os.path.join(run, 'test_images')) == ['epoch_5.png']              # (epoch+1) % 5 == 0 and not the last
+    ck = os.path.join(run, 'training_checkpoints')
+    assert sorted(os.listdir(ck)) == ['checkpoint', 'ckpt-1.data-00000-of-00001', 'ckpt-1.index', 'ckpt-2.data-00000-of-00001', 'ckpt-2.index']
+    assert len(os.listdir(os.path.join(run, 'figs'))) == 7 and os.listdir(os.path.join(run, 'final_test_imgs')) == ['img0.png']
+    out2 = str(tmp_path / 'pred')
+    cycle_gan.main(cycle_gan.parse_opt(['--input-images', dx, '--output', out2, '--predict', '--weights', ck, '--logging', 'false']))
+    run2 = os.path.join(out2, sorted(os.listdir(out2))[0])
+    assert len(os.listdir(os.path.join(run2, 'prediction_images'))) == 7
