@@ -39,6 +39,19 @@ def workspace_mb_for(batch, size, channels=1, calls=2):
     return max(256, (need >> 20) + 1)
 
 
+class LaneStream(torch.cuda.Stream):
+    """A side stream of the step schedule that remembers whether it has been forked into a hipGraph capture and not
+    joined back yet: ending a capture with an unjoined lane took the process down inside capture_end (round 1,
+    gpurun_out/crash.log) instead of raising.  `lane.wait_stream(x)` = fork, `Ctx.join(waiter, lane)` = join;
+    `Ctx.assert_lanes_joined()` runs before every capture ends."""
+    open_in_capture = False
+
+    def wait_stream(self, stream):
+        if torch.cuda.is_current_stream_capturing() or getattr(stream, 'open_in_capture', False):
+            self.open_in_capture = True
+        return super().wait_stream(stream)
+
+
 class Ctx:
     """Device, dtype, library handle and the shared split-K / reduction workspace."""
 
@@ -68,7 +81,7 @@ class Ctx:
         self.ws_lanes = [torch.empty(workspace_mb << 20, dtype=torch.uint8, device=self.device) for _ in range(4)]
         self.ws = self.ws_lanes[0]
         self.ws_ptr, self.ws_bytes = self.ws.data_ptr(), self.ws.numel()
-        self.side = [torch.cuda.Stream(device=self.device) for _ in range(4)]     # lanes 1..4 (4: early optimiser step)
+        self.side = [LaneStream(device=self.device) for _ in range(4)]     # lanes 1..4 (4: early optimiser step)
         # 0: everything on one stream; 1: one fork/join per step (deferred generator wgrads beside the
         # discriminator's parameter pass); 2: per-op wgrad side stream + second chain
         self.ms_mode = int(os.environ.get('GAN_AMD_MS', '4'))
@@ -76,6 +89,19 @@ class Ctx:
 
     def stream(self):
         return torch.cuda.current_stream(self.device).cuda_stream
+
+    def join(self, waiter, lane):
+        """`waiter` waits for everything queued on `lane` (the join of a fork made with lane.wait_stream)."""
+        waiter.wait_stream(lane)
+        if isinstance(lane, LaneStream) and not getattr(waiter, 'open_in_capture', False):
+            lane.open_in_capture = False          # joined into the capturing (or an already joined) stream
+
+    def assert_lanes_joined(self):
+        bad = [i + 1 for i, s in enumerate(self.side) if s.open_in_capture]
+        for s in self.side:
+            s.open_in_capture = False
+        if bad:
+            raise L.GanAmdError(f"step schedule bug: lane(s) {bad} were forked during graph capture and never joined")
 
     def lane_stream(self, lane):
         return torch.cuda.current_stream(self.device) if lane == 0 else self.side[lane - 1]
@@ -103,7 +129,7 @@ class Ctx:
             if rc:
                 L.check(rc, op[2])
         if used_side:
-            main.wait_stream(side)
+            self.join(main, side)
 
 
 class Buf:

@@ -98,18 +98,22 @@ class _StepBase:
         if not split:
             with torch.cuda.graph(g1):
                 self._run(*self._static_in, training=training)
+                self.ctx.assert_lanes_joined()
         else:
             # graph 1: forward, losses, generator-side backward  -> start the generators' (large) exchange
             # graph 2: discriminator parameter pass (overlaps it) -> start the discriminators' exchange
             # graph 3: Adam, after both exchanges have landed
             with torch.cuda.graph(g1):
                 self._forward_backward(*self._static_in, training, phase=1)
+                self.ctx.assert_lanes_joined()
             g2 = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g2):
                 self._forward_backward(*self._static_in, training, phase=2)
+                self.ctx.assert_lanes_joined()
             g3 = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g3):
                 self._update()
+                self.ctx.assert_lanes_joined()
         self._graphs = (g1, g2, g3)
         early, late = self.sync_order() if split else ((), ())
 
@@ -184,7 +188,7 @@ class Pix2PixStep(_StepBase):
         # forward when lanes are on), then all three BCE terms in one pass
         side = self.ctx.lane_stream(2) if self.ctx.ms_mode == 4 else None
         if dreal:
-            self.ctx.lane_stream(0).wait_stream(side)                 # D(real) done (its BatchNorm updates come first)
+            self.ctx.join(self.ctx.lane_stream(0), side)                 # D(real) done (its BatchNorm updates come first)
         if side is not None:
             side.wait_stream(self.ctx.lane_stream(0))
         self._l1(g.out_view(), d.xin.view(Cc, Cc, 0, B), 2, 1.0, False, self.lam, g.dgen.view(0, Cc), stream=side)
@@ -194,7 +198,7 @@ class Pix2PixStep(_StepBase):
         else:
             d.forward()                                               # pix2pix.py:202-203 (real ++ fake)
         if side is not None:
-            self.ctx.lane_stream(0).wait_stream(side)
+            self.ctx.join(self.ctx.lane_stream(0), side)
         real_ptr, cnt = d.logits_view(0)
         fake_ptr, _ = d.logits_view(1)
         lp = self.losses.data_ptr()
@@ -212,32 +216,32 @@ class Pix2PixStep(_StepBase):
                 lane3 = self.ctx.lane_stream(3)
                 g.wgrad_stream, g.wgrad_cuts = lane3, [8]
                 g.backward(use_dgen2=True, defer_wgrads='staged')
-                main.wait_stream(lane3)
+                self.ctx.join(main, lane3)
             elif phase == 1:
                 g.backward(use_dgen2=True)
             elif self.ctx.ms_mode == 2:
                 lane2.wait_stream(main)
                 d.backward_params()
                 g.backward(use_dgen2=True)
-                main.wait_stream(lane2)
+                self.ctx.join(main, lane2)
             elif self.ctx.ms_mode == 1:       # one fork/join: G's wgrads (they only feed Adam) beside D's pass
                 g.backward(use_dgen2=True, defer_wgrads=True)
                 lane2.wait_stream(main)
                 g.run_deferred_wgrads(lane2)
                 d.backward_params()
-                main.wait_stream(lane2)
+                self.ctx.join(main, lane2)
             elif self.ctx.ms_mode == 5:       # mode 3 + G's wgrads on their own side stream (per-op dependencies)
                 lane2.wait_stream(main)
                 self.ctx.run_on(d.params_ops(), lane2)
                 self.ctx.multistream = True
                 g.backward(use_dgen2=True)
                 self.ctx.multistream = False
-                main.wait_stream(lane2)
+                self.ctx.join(main, lane2)
             elif self.ctx.ms_mode == 3:       # D's parameter pass beside the whole G backward
                 lane2.wait_stream(main)
                 self.ctx.run_on(d.params_ops(), lane2)
                 g.backward(use_dgen2=True)
-                main.wait_stream(lane2)
+                self.ctx.join(main, lane2)
             elif self.ctx.ms_mode == 4:       # three chains: D params | G dgrad/norm chain | G wgrads in two stages
                 lane3 = self.ctx.lane_stream(3)
                 lane2.wait_stream(main)
@@ -265,7 +269,7 @@ class Pix2PixStep(_StepBase):
                     def hook(k):
                         if k >= nst or k > 1:          # the last stage's segment is updated after the join
                             return
-                        lane4.wait_stream(lane3)
+                        self.ctx.join(lane4, lane3)
                         ops = P.adam_begin_ops(self.lr, self.b1, self.b2) if k == 0 else []
                         self.ctx.run_on(ops + P.adam_segment_ops(2 - k, self.b1, self.b2), lane4)
                         self._early_segs.add(2 - k)
@@ -273,10 +277,10 @@ class Pix2PixStep(_StepBase):
                     self._early_adam = self.G
                 g.backward(use_dgen2=True, defer_wgrads='staged')
                 g.stage_hook = None
-                main.wait_stream(lane2)
-                main.wait_stream(lane3)
+                self.ctx.join(main, lane2)
+                self.ctx.join(main, lane3)
                 if self._early_adam is not None:
-                    main.wait_stream(self.ctx.lane_stream(4))
+                    self.ctx.join(main, self.ctx.lane_stream(4))
             else:
                 g.backward(use_dgen2=True)
                 d.backward_params()
@@ -321,6 +325,7 @@ class Pix2PixStep(_StepBase):
             gr = torch.cuda.CUDAGraph()
             with torch.cuda.graph(gr):
                 fn()
+                ctx.assert_lanes_joined()
             return gr
 
         def fork_join(side_ops, side_stream, main_fn):
@@ -328,7 +333,7 @@ class Pix2PixStep(_StepBase):
             side_stream.wait_stream(cur)
             ctx.run_on(side_ops, side_stream)
             main_fn()
-            cur.wait_stream(side_stream)
+            ctx.join(cur, side_stream)
 
         def g1():
             self._forward_backward(*self._static_in, True, phase=3)          # everything up to G's backward
@@ -386,7 +391,7 @@ class Pix2PixStep(_StepBase):
                             sync.wait(h)                   # lane 4 waits for the collective; the host does not
                             if ai is not None:
                                 A[ai].replay()
-            cur.wait_stream(lane4)
+            ctx.join(cur, lane4)
             return self.losses
         return replay
 
@@ -480,7 +485,7 @@ class CycleGANStep(_StepBase):
                 dx.backward_params(); dy.backward_params()            # :257-260, second chain beside the identity terms
                 sy.backward(accumulate=True)                          # identity_y -> G_g
                 sx.backward(accumulate=True)                          # identity_x -> G_f
-                main.wait_stream(lane2)
+                self.ctx.join(main, lane2)
             else:
                 sy.backward(accumulate=True)
                 sx.backward(accumulate=True)

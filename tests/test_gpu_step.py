@@ -371,3 +371,29 @@ def test_full_size_gradients_are_directional_derivatives(dtype, step, tol):
         pred = eps * g2
         print(f"loss[{li}] = {float(base[li]):.5f}: finite difference {fd:.6e} vs <g,delta> {pred:.6e}")
         assert abs(fd - pred) < tol * abs(pred), (li, fd, pred)
+
+
+def test_capture_guard_reports_an_unjoined_lane():
+    """A lane forked inside a hipGraph capture and not joined used to end in a crash inside capture_end (round 1); the
+    guard every capture runs before it ends raises instead."""
+    from gan_amd import _lib as L
+    from gan_amd.nets import Ctx
+    ctx = Ctx('cuda:0', 'bf16')
+    buf = torch.zeros(1024, device=ctx.device)
+    main, lane = torch.cuda.Stream(device=ctx.device), ctx.lane_stream(3)
+    main.wait_stream(torch.cuda.current_stream())
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(main):
+        with torch.cuda.graph(g, stream=main):
+            cur = torch.cuda.current_stream()
+            lane.wait_stream(cur)                               # fork
+            with torch.cuda.stream(lane):
+                buf.add_(1.0)
+            with pytest.raises(L.GanAmdError, match="never joined"):
+                ctx.assert_lanes_joined()
+            lane.wait_stream(cur)                               # (marks it again) ... and the proper join:
+            ctx.join(cur, lane)
+            ctx.assert_lanes_joined()
+    g.replay()
+    torch.cuda.synchronize()
+    assert float(buf[0]) == 1.0
