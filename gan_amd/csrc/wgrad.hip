@@ -14,6 +14,7 @@
 // (zero-padded C=1..6) BIG tensors by folding the 16 taps into the tile's channel axis, so the SMALL
 // tensor is read once instead of 16 times.  Large reductions split M across blockIdx.z into fp32 slabs.
 #include "common.h"
+#include <type_traits>
 
 struct WgradParams {
   const void* big; const void* small; float* dw; float* slab;
@@ -244,7 +245,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* slab, fl
   }
 }
 
-struct WgradPlan { WgradParams p; int TA, TB; dim3 grid; size_t slab_bytes; };
+struct WgradPlan { WgradParams p; int TA, TB; dim3 grid; size_t slab_bytes; bool pp; };
 
 static int plan_wgrad(const GanWgradDesc* d, WgradPlan* pl, bool allow_swap = true) {
   if (!d || d->struct_size != sizeof(GanWgradDesc) || !d->big.ptr || !d->small.ptr || !d->dw) return GAN_E_ARG;
@@ -289,6 +290,33 @@ static int plan_wgrad(const GanWgradDesc* d, WgradPlan* pl, bool allow_swap = tr
     if (TA == 64 && TB == 16) {}
     if (TA == 16 && TB == 16) return GAN_E_SHAPE;
     tilesA = (b.c + TA - 1) / TA;
+  }
+  pl->pp = false;
+  {
+    // big reductions on 16-bit storage: the 256 x 256 ping-pong kernel (rows = (tap, channel) pairs in units of 64)
+    static int use_pp = -1;
+    if (use_pp < 0) { const char* e = getenv("GAN_AMD_WGRAD_PP"); use_pp = e ? atoi(e) : 1; }
+    static int min_rows = -1;
+    if (min_rows < 0) { const char* e = getenv("GAN_AMD_WGRAD_PP_MINROWS"); min_rows = e ? atoi(e) : 1024; }
+    if (use_pp && allow_swap && !p.fold && !p.swap && d->dtype != GAN_F32 && (b.c == 64 || b.c == 128 || b.c % 256 == 0) &&
+        s.c % 256 == 0 && M >= 2 * min_rows &&
+        2.0 * (double)M * 16.0 * b.c * s.c >= 3.0e10) {      // every block writes a 256 KB fp32 slab tile (64 MB per launch with the
+                                                            // reduce pass): pays from ~30 GFLOP up (measured against the 128x128 kernel)
+      const long long tiles = (long long)(16 * b.c / 256) * (s.c / 256);
+      long long sp = (256 + tiles - 1) / tiles;
+      if (sp > M / min_rows) sp = M / min_rows;
+      if (sp < 1) sp = 1;
+      if (sp > 1024) sp = 1024;
+      p.tilesB = s.c / 256;
+      p.kchunks = (int)((M + 63) / 64);
+      if (sp >= 8) sp &= ~7LL;
+      p.splits = (int)sp;
+      pl->pp = true; pl->TA = 256; pl->TB = 256;
+      if (sp >= 8) sp &= ~7LL;                     // whole groups of 8 splits: one per XCD (wgrad_pp_kernel's block mapping)
+      pl->grid = dim3((unsigned)(tiles * sp), 1, 1);
+      pl->slab_bytes = sp > 1 ? (size_t)sp * 16 * p.CaReal * p.CbReal * sizeof(float) : 0;
+      return 0;
+    }
   }
   int tilesB = (p.Cb + TB - 1) / TB;
   p.tilesB = tilesB;
@@ -572,6 +600,230 @@ static int launch_wgrad_dma(const WgradPlan& pl, unsigned bigbytes, unsigned sma
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// v3: "ping-pong" kernel, 256 x 256 output tile (rows = (tap, BIG channel), columns = SMALL channel), 8 waves as
+// 2 x 4 with 128 x 64 wave tiles, the structure of conv_gemm_pp_kernel (conv_gemm.hip has the ordering rules): waves
+// 4..7 run one barrier behind waves 0..3, so that on every SIMD one wave multiplies while its partner stages and reads;
+// LDS-DMA pieces stay in flight across barriers behind a counted vmcnt.  A 128 x 128 tile needs twice the staged bytes
+// per FLOP and is bound by the CU's LDS-DMA rate at ~45 % of the MFMA peak; this one halves them.
+//
+// A K tile = 64 reduction rows m.  Both operands are staged as 64-row x 64-channel PANELS (128-byte rows, 8 KiB, 8
+// pieces): 4 BIG panels (wave row x row half; a panel is one tap's 64-channel slice) and 4 SMALL panels (one per wave
+// column).  A wave issues piece `wave` of every panel, so a lane serves ONE reduction row per K tile: the row is decoded
+// once per K tile (window origin + 16-bit tap mask, as in the convolution kernel).  16-byte chunks are XOR-swizzled
+// through the source address by ((row >> 1) & 1 | (row >> 3) & 1 << 1) << 1, which makes the transposing fragment reads
+// (ds_read_b64_tr_b16: rows 8q..8q+3 of a 32-byte column segment per 16-lane group) bank-conflict free and is the same
+// for every read a lane issues.
+// Slots of a K tile per wave, in staging order: A0 A0 | B B | B B | A1 A1 (A0/A1 = first/second 64 rows of each wave
+// row); first read in phase 0 0 0 0 0 0 2 2, last read 0 0 1 1 1 1 2 2 -> staged 6 phases ahead, at most 6 pieces
+// outstanding at the end of a load segment, 2 stages.
+template <int IMM> __device__ __forceinline__ void lds_read_tr(s16x4& d, unsigned addr) {
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(IMM));
+}
+template <int N, typename F> __device__ __forceinline__ void wg_static_for(F&& f) {
+  if constexpr (N > 0) { wg_static_for<N - 1>(f); f(std::integral_constant<int, N - 1>{}); }
+}
+
+template <typename T>
+__global__ __launch_bounds__(512) void wgrad_pp_kernel(const WgradParams p, unsigned bigbytes, unsigned smallbytes) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  static_assert(sizeof(T) == 2, "16-bit storage types");
+  constexpr int PANEL = 64 * 128, STAGE = 8 * PANEL, NB = 2, PH = 4, PP = 2, DP = 6, VMW = 6, QS = 8;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int r = lane & 15, q = lane >> 4;
+  // Block -> (tile, split).  Every tile of one split reads the same reduction rows of both tensors, so a split's tiles
+  // are kept on ONE XCD (blocks b and b + 8 share an XCD and its L2): XCD x takes the splits x, x + 8, ... and walks
+  // their tiles; otherwise each of the 8 L2s fetches every row once per tile.  (Speed only: any mapping is correct.)
+  const int tiles = (int)gridDim.x / p.splits;
+  int tile, split;
+  if ((p.splits & 7) == 0) {
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    tile = j % tiles; split = xcd + 8 * (j / tiles);
+  } else {
+    tile = blockIdx.x % tiles; split = blockIdx.x / tiles;
+  }
+  const int ta = tile / p.tilesB, tb = tile % p.tilesB;
+  const int tr0 = ta * 256, cb0 = tb * 256;
+  const __amdgpu_buffer_rsrc_t rbig = __builtin_amdgcn_make_buffer_rsrc((void*)p.big, 0, bigbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsmall = __builtin_amdgcn_make_buffer_rsrc((void*)p.small, 0, smallbytes, 0x00020000);
+
+  // staging: this lane's row inside every panel, its swizzled source chunk; the 4 BIG panels' tap / channel offsets
+  const int lrow = lane >> 3, prow = wave * 8 + lrow;
+  const int chunk16 = (((lane & 7) ^ ((((prow >> 1) & 1) | (((prow >> 3) & 1) << 1)) << 1)) << 4);
+  int s_aoff[4];
+  unsigned s_bit[4];
+#pragma unroll
+  for (int pn = 0; pn < 4; ++pn) {                       // panel pn = wave-row * 2 + half
+    const int row0 = tr0 + (pn >> 1) * 128 + (pn & 1) * 64;
+    const int tap = row0 / p.Ca, ch = row0 % p.Ca;
+    s_aoff[pn] = (((tap >> 2) * p.Wb + (tap & 3)) * p.bpitch + ch) * 2;
+    s_bit[pn] = 1u << tap;
+  }
+  const int kc_begin = (int)((long long)p.kchunks * split / p.splits);
+  const int kc_end = (int)((long long)p.kchunks * (split + 1) / p.splits);
+  const int nk = kc_end - kc_begin;
+
+  int a_org = 0, b_off = (int)0x80000000;
+  unsigned a_msk = 0;
+  auto rowinfo = [&](int ts) {                           // decode this lane's reduction row of K tile ts
+    const unsigned m = (unsigned)(kc_begin + ts) * 64u + (unsigned)prow;
+    a_msk = 0; a_org = 0; b_off = (int)0x80000000;
+    if (ts < nk && m < (unsigned)p.M) {
+      const unsigned t = fdiv(m, p.divW);
+      const int gx = (int)(m - t * p.divW.d);
+      const unsigned img = fdiv(t, p.divH);
+      const int gy = (int)(t - img * p.divH.d);
+      const int sy0 = gy * p.S - 1, sx0 = gx * p.S - 1;
+      unsigned vx = 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) vx |= ((unsigned)(sx0 + k) < (unsigned)p.Wb ? 1u : 0u) << k;
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if ((unsigned)(sy0 + k) < (unsigned)p.Hb) a_msk |= vx << (4 * k);
+      a_org = (int)((((long long)((int)img * p.Hb + sy0) * p.Wb + sx0) * (long long)p.bpitch) * 2) + chunk16;
+      b_off = (int)(((size_t)m * p.spitch + cb0) * 2) + chunk16;
+    }
+  };
+  auto issue_slots = [&](auto I0c, auto CNTc, int ts) {
+    constexpr int I0 = decltype(I0c)::value, CNT = decltype(CNTc)::value;
+    unsigned char* st = smem + (ts & 1) * STAGE + wave * 1024;
+    wg_static_for<CNT>([&](auto Ic) {
+      constexpr int i = I0 + decltype(Ic)::value;
+      if constexpr (i < 2 || i >= 6) {
+        constexpr int pn = (i & 1) * 2 + (i >= 6 ? 1 : 0);
+        const int off = (a_msk & s_bit[pn]) ? a_org + s_aoff[pn] : (int)0x80000000;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rbig, (__attribute__((address_space(3))) void*)(st + pn * PANEL), 16, off, 0, 0, 0);
+      } else {
+        constexpr int k = i - 2;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsmall, (__attribute__((address_space(3))) void*)(st + (4 + k) * PANEL), 16,
+                                                 b_off + k * 128, 0, 0, 0);
+      }
+    });
+  };
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // fragment reads: element column tile*16 + 4*(r&3) of rows s*32 + 8q + (r>>2) (+4): byte (tile ^ swz) << 5 | ((r>>1)&1) << 4 | 8*(r&1)
+  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  const unsigned swl = (unsigned)(((r >> 3) & 1) | ((q & 1) << 1));
+  const unsigned lrow_off = (unsigned)((8 * q + (r >> 2)) * 128 + (((r >> 1) & 1) << 4) + 8 * (r & 1));
+
+  // prologue: slots of phases -6 .. -1 = all of K tile 0 and A0, B, B of K tile 1
+  rowinfo(0);
+  issue_slots(std::integral_constant<int, 0>{}, std::integral_constant<int, 8>{}, 0);
+  rowinfo(1);
+  issue_slots(std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{}, 1);
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VMW) : "memory");
+  __builtin_amdgcn_s_barrier();
+  if (wr == 1) __builtin_amdgcn_s_barrier();
+
+  s16x4 alo[2][4], ahi[2][4], b0lo[2][2], b0hi[2][2], b1lo[2][2], b1hi[2][2];
+  for (int t = 0; t < nk; ++t) {
+    const unsigned so = lds_base + (unsigned)((t & 1) * STAGE) + lrow_off;
+    unsigned bt[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) bt[k] = so + ((k ^ swl) << 5);
+    wg_static_for<PH>([&](auto Pc) {
+      constexpr int ph = decltype(Pc)::value;
+      constexpr int mh = ph < 2 ? 0 : 1, nh = (ph == 1 || ph == 2) ? 1 : 0;
+      // ---- LOAD segment ----
+      constexpr int x0 = PP * (ph + DP);                   // 12, 14, 16, 18 -> (tile t+1: slots 4,5 | 6,7), (tile t+2: 0,1 | 2,3)
+      if constexpr (ph == 2) rowinfo(t + 2);
+      issue_slots(std::integral_constant<int, x0 % QS>{}, std::integral_constant<int, PP>{}, t + x0 / QS);
+      if constexpr (ph == 0 || ph == 1) {
+        wg_static_for<2>([&](auto Jc) {
+          constexpr int j = decltype(Jc)::value;
+          constexpr int imm = 4 * PANEL;                   // SMALL panels follow the 4 BIG panels
+          wg_static_for<2>([&](auto Sc) {
+            constexpr int s2 = decltype(Sc)::value;
+            if constexpr (nh == 0) { lds_read_tr<imm + s2 * 4096>(b0lo[s2][j], bt[j] + wc * PANEL); lds_read_tr<imm + s2 * 4096 + 512>(b0hi[s2][j], bt[j] + wc * PANEL); }
+            else { lds_read_tr<imm + s2 * 4096>(b1lo[s2][j], bt[2 + j] + wc * PANEL); lds_read_tr<imm + s2 * 4096 + 512>(b1hi[s2][j], bt[2 + j] + wc * PANEL); }
+          });
+        });
+      }
+      if constexpr (ph == 0 || ph == 2) {
+        wg_static_for<4>([&](auto Ic) {
+          constexpr int i = decltype(Ic)::value;
+          wg_static_for<2>([&](auto Sc) {
+            constexpr int s2 = decltype(Sc)::value;
+            constexpr int imm = mh * PANEL + s2 * 4096;
+            lds_read_tr<imm>(alo[s2][i], bt[i] + wr * 2 * PANEL); lds_read_tr<imm + 512>(ahi[s2][i], bt[i] + wr * 2 * PANEL);
+          });
+        });
+      }
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VMW) : "memory");
+      __builtin_amdgcn_s_barrier();
+      // ---- MATH segment ----
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          typedef __attribute__((ext_vector_type(8))) short s16x8;
+          const s16x8 av = __builtin_shufflevector(alo[s2][i], ahi[s2][i], 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const s16x8 bv = nh == 0 ? __builtin_shufflevector(b0lo[s2][j], b0hi[s2][j], 0, 1, 2, 3, 4, 5, 6, 7)
+                                     : __builtin_shufflevector(b1lo[s2][j], b1hi[s2][j], 0, 1, 2, 3, 4, 5, 6, 7);
+            acc[mh * 4 + i][nh * 2 + j] = mma16<T>(*(const uint4*)&bv, *(const uint4*)&av, acc[mh * 4 + i][nh * 2 + j]);
+          }
+        }
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_s_barrier();
+    });
+  }
+  if (wr == 0) __builtin_amdgcn_s_barrier();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  // acc[i][j][e] = dW[tile row wr*128 + i*16 + r][column wc*64 + j*16 + q*4 + e]
+  const size_t per_split = (size_t)16 * p.CaReal * p.CbReal;
+  float* out = p.splits > 1 ? p.slab + (size_t)split * per_split : p.dw;
+  const bool vec4 = p.CbReal % 4 == 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int R = tr0 + wr * 128 + i * 16 + r;
+    const int tap = R / p.Ca, ca = R % p.Ca;
+    if (tap >= 16 || ca >= p.CaReal) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int cb = cb0 + wc * 64 + j * 16 + q * 4;
+      float* o = out + ((size_t)tap * p.CaReal + ca) * p.CbReal + cb;
+      if (vec4) {
+        if (cb < p.CbReal) *(f32x4*)o = (p.splits == 1 && p.accumulate) ? *(f32x4*)o + acc[i][j] : acc[i][j];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (cb + e < p.CbReal) o[e] = (p.splits == 1 && p.accumulate) ? o[e] + acc[i][j][e] : acc[i][j][e];
+      }
+    }
+  }
+#endif
+}
+
+template <typename T>
+static int launch_wpp(const WgradPlan& pl, unsigned bigbytes, unsigned smallbytes, hipStream_t st) {
+  static bool attr_set = false;
+  constexpr size_t smem = 2 * 8 * 64 * 128;
+  auto kern = wgrad_pp_kernel<T>;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, pl.grid, dim3(512), smem, st, pl.p, bigbytes, smallbytes);
+  GAN_CHECK_LAUNCH();
+  return 0;
+}
+
 static bool wgrad_use_tr() {
   static int v = -1;
   if (v < 0) { const char* e = getenv("GAN_AMD_WGRAD_NO_TR"); v = (e && e[0] == '1') ? 0 : 1; }
@@ -593,7 +845,8 @@ int gan_conv_wgrad(const GanWgradDesc* d, gan_stream_t stream) {
   if (rc) return rc;
   if (pl.slab_bytes > d->workspace_bytes || (pl.slab_bytes && !d->workspace)) return GAN_E_WORKSPACE;
   if (pl.p.swap) { const size_t t = bb; bb = sb; sb = t; }
-  if (dma_ok) rc = d->dtype == GAN_F32 ? launch_wgrad_dma<float>(pl, (unsigned)bb, (unsigned)sb, st)
+  if (pl.pp) rc = d->dtype == GAN_F16 ? launch_wpp<f16_t>(pl, (unsigned)bb, (unsigned)sb, st) : launch_wpp<bf16_t>(pl, (unsigned)bb, (unsigned)sb, st);
+  else if (dma_ok) rc = d->dtype == GAN_F32 ? launch_wgrad_dma<float>(pl, (unsigned)bb, (unsigned)sb, st)
                    : d->dtype == GAN_F16 ? launch_wgrad_dma<f16_t>(pl, (unsigned)bb, (unsigned)sb, st)
                                          : launch_wgrad_dma<bf16_t>(pl, (unsigned)bb, (unsigned)sb, st);
   else if (d->dtype == GAN_F32) rc = launch_wgrad<float, false>(pl, st);
