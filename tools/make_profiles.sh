@@ -1,0 +1,16 @@
+#!/bin/bash
+# Round profiles of the headline bench (run on the GPU box through gpurun; outputs under gpurun_out/profiles_<tag>/, the
+# summaries are copied into profiles/ afterwards): kernel-trace statistics and separate PMC passes (FETCH_SIZE, WRITE_SIZE,
+# SQ_*), exactly the command the driver runs with fewer steps.
+tag=${1:-r02}
+out=$GRAFT_REPO_ROOT/gpurun_out/profiles_$tag
+mkdir -p $out
+cd /tmp && export TMPDIR=/tmp
+CMD="python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --repeats 1 --no-cpu-baseline"
+python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline > $out/bench_p16.json 2> $out/bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o s -- $CMD > $out/bench_under_rocprof.json 2>> $out/bench.err
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -o f -- $CMD > /dev/null 2>> $out/bench.err
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write -o w -- $CMD > /dev/null 2>> $out/bench.err
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU --output-format csv -d $out/sq -o q -- $CMD > /dev/null 2>> $out/bench.err
+python3 $GRAFT_REPO_ROOT/tools/summarize_pmc.py $out $tag
+ls -la $out

@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Summaries of tools/make_profiles.sh's rocprofv3 passes: per-kernel statistics CSV, HBM bytes per launch
+(FETCH_SIZE / WRITE_SIZE passes, corrected as MI355X_MICROARCH.md's HBM section prescribes: gfx950 counts a 128-B
+request as 64 B of FETCH_SIZE) and SQ counters per launch."""
+import csv, glob, json, os, re, shutil, sys
+
+out, tag = sys.argv[1], sys.argv[2]
+
+
+def friendly(sym):
+    m = re.match(r'_Z19conv_gemm_pp_kernelI(DF16b|DF16_|f)Li(\d+)E', sym)
+    if m:
+        return f"conv_gemm<{ {'DF16b': 'bf16', 'DF16_': 'f16', 'f': 'f32'}[m.group(1)] },256,{m.group(2)}>"
+    m = re.match(r'_Z16conv_gemm_kernelI(DF16b|DF16_|f)Li(\d+)ELi(\d+)E', sym)
+    if m:
+        return f"conv_gemm<{ {'DF16b': 'bf16', 'DF16_': 'f16', 'f': 'f32'}[m.group(1)] },{m.group(2)},{m.group(3)}>"
+    m = re.match(r'_Z16wgrad_dma_kernelI(DF16b|DF16_|f)Li(\d+)ELi(\d+)E', sym)
+    if m:
+        return f"wgrad<{ {'DF16b': 'bf16', 'DF16_': 'f16', 'f': 'f32'}[m.group(1)] },{m.group(2)},{m.group(3)}>"
+    m = re.match(r'_Z15wgrad_pp_kernelI(DF16b|DF16_)', sym)
+    if m:
+        return f"wgrad<{ {'DF16b': 'bf16', 'DF16_': 'f16'}[m.group(1)] },256,256>"
+    return re.sub(r'^void ', '', sym).split('(')[0][:70]
+
+
+def counters(d):
+    """{kernel: {counter: (sum, dispatches)}} from a --pmc pass."""
+    res = {}
+    for f in glob.glob(os.path.join(out, d, '**', '*counter_collection.csv'), recursive=True):
+        for r in csv.DictReader(open(f)):
+            k = friendly(r['Kernel_Name'])
+            e = res.setdefault(k, {}).setdefault(r['Counter_Name'], [0.0, 0])
+            e[0] += float(r['Counter_Value']); e[1] += 1
+    return res
+
+
+stats = glob.glob(os.path.join(out, 'stats', '**', '*kernel_stats.csv'), recursive=True)
+if stats:
+    shutil.copy(stats[0], os.path.join(out, f'{tag}_bench_p16_kernel_stats.csv'))
+fe, wr = counters('fetch'), counters('write')
+traffic = {"_note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `python bench.py --steps 5 --warmup 2 --repeats 1 "
+                    "--no-cpu-baseline`; per-launch averages; hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE counts 64 B per "
+                    "128-B request: MI355X_MICROARCH.md HBM section). Infinity-Cache hits are included in these fabric-side counters."}
+for k in sorted(set(fe) | set(wr)):
+    f = fe.get(k, {}).get('FETCH_SIZE', [0, 1]); w = wr.get(k, {}).get('WRITE_SIZE', [0, 1])
+    fk, wk = f[0] / max(1, f[1]), w[0] / max(1, w[1])
+    traffic[k] = {"launches": int(max(f[1], w[1])), "fetch_kb_avg": round(fk, 1), "write_kb_avg": round(wk, 1),
+                  "hbm_bytes_per_launch": int((2 * fk + wk) * 1024)}
+json.dump(traffic, open(os.path.join(out, f'{tag}_pmc_traffic.json'), 'w'), indent=1)
+sq = counters('sq')
+json.dump({"_note": "rocprofv3 --pmc SQ_* (one pass) on the same command; per-launch averages, summed over all SEs/XCDs.",
+           **{k: {c: round(v[0] / max(1, v[1]), 1) for c, v in sorted(d.items())} for k, d in sorted(sq.items())}},
+          open(os.path.join(out, f'{tag}_pmc_sq.json'), 'w'), indent=1)
+print("summaries written:", [f for f in os.listdir(out) if f.startswith(tag)])
