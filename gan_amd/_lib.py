@@ -112,6 +112,7 @@ SYMBOLS = {
     "gan_bias_grad": (C.c_int, [C.c_int32, C.POINTER(GanTensor), C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p]),
     "gan_grad_pack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "gan_grad_unpack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p]),
+    "gan_crc32c": (C.c_uint32, [C.c_uint32, C.c_void_p, C.c_size_t]),
     "gan_version": (C.c_char_p, []),
 }
 

@@ -42,6 +42,9 @@ class _Model:
                 P[k] = sd[key].astype(np.float32).reshape(P[k].shape)
         self.net.params.load_numpy(P)
 
+    def param_names(self):
+        return list(self.net.params.entries) + list(self.net.params.state)
+
     @property
     def trainable_variables(self):
         return [self.net.params.tensor(n) for n in self.net.params.names]
@@ -106,7 +109,7 @@ class AdamConfig:
         if self.params is None:
             return {}
         ps = self.params
-        out = {'iter/.ATTRIBUTES/VARIABLE_VALUE': ps.step.cpu().numpy().astype(np.int64),
+        out = {'iter/.ATTRIBUTES/VARIABLE_VALUE': ps.step.cpu().numpy().astype(np.int64).reshape(()),       # scalars, as Keras stores them
                'learning_rate/.ATTRIBUTES/VARIABLE_VALUE': np.float32(self.learning_rate),
                'beta_1/.ATTRIBUTES/VARIABLE_VALUE': np.float32(self.beta_1),
                'beta_2/.ATTRIBUTES/VARIABLE_VALUE': np.float32(self.beta_2),

@@ -1,12 +1,12 @@
-"""Checkpointing with the reference's directory / object naming (pix2pix.py:400-403,419-420,
-cycle_gan.py:437-444,460-461): `<dir>/checkpoint` (text, `model_checkpoint_path: "ckpt-N"`),
-`ckpt-N.index`, `ckpt-N.data-00000-of-00001`, keep-last-K.  Variable keys follow TF's object-graph naming
-(`generator/layer_with_weights-K/.../kernel/.ATTRIBUTES/VARIABLE_VALUE`); optimizer hyper-parameters as
-`generator_optimizer/{iter,learning_rate,beta_1,beta_2,decay}/...`, Adam slots as
-`generator_optimizer/slot/{m,v}/<layer>.<variable>` (flat names of our own, not TF's `.OPTIMIZER_SLOT` paths).  Kernels are stored in the Keras layouts (HWIO / HWOI), i.e.
-byte-for-byte the master buffers.  The *container* is a self-describing native format (JSON index + raw
-little-endian data), NOT TensorFlow's TensorBundle SSTable: no TF-written checkpoint ships with the reference
-to pin that format against."""
+"""Checkpointing with the reference's directory / object naming AND container (pix2pix.py:400-403,419-420,
+cycle_gan.py:437-444,460-461): `<dir>/checkpoint` (text proto, `model_checkpoint_path: "ckpt-N"`), `ckpt-N.index`,
+`ckpt-N.data-00000-of-00001` in TensorFlow's TensorBundle format (gan_amd/tfbundle.py: sorted string table of
+BundleEntryProto + raw little-endian tensor data + the `_CHECKPOINTABLE_OBJECT_GRAPH` string tensor), keep-last-K.
+Variable keys follow TF's object-graph naming: `generator/layer_with_weights-K[/layer_with_weights-J]/kernel/.ATTRIBUTES/
+VARIABLE_VALUE`; optimizer hyper-parameters `generator_optimizer/{iter,beta_1,beta_2,decay,learning_rate}/...`; Adam slots
+`<variable path>/.OPTIMIZER_SLOT/generator_optimizer/{m,v}/.ATTRIBUTES/VARIABLE_VALUE`; `save_counter/...`.  Kernels are
+stored in the Keras layouts (HWIO / HWOI), byte-for-byte the master buffers.  Format parity with TensorFlow is unpinned
+(tfbundle.py header); checkpoints written by round 1's JSON container are still readable."""
 from __future__ import annotations
 
 import json
@@ -15,14 +15,28 @@ import re
 
 import numpy as np
 
+from . import tfbundle
+
+# `layer_with_weights-K` numbering of the reference's Keras models (layers that own variables, in model order):
+# Generator (base_gan.py:168-225): 8 downsample Sequentials (0..7), 7 upsample Sequentials (8..14), the Conv2DTranspose
+# head (15).  Inside a Sequential: the convolution is `layer_with_weights-0`, its normalisation layer `-1`.
+# Discriminator (base_gan.py:124-166): 3 downsample Sequentials (0..2), then PLAIN layers: Conv2D (3), its
+# BatchNormalization / InstanceNormalization (4), the logits Conv2D (5).
+_NORM_ATTRS = ('gamma', 'beta', 'scale', 'offset', 'moving_mean', 'moving_variance')
+
 
 def tf_variable_key(obj_name: str, layer_names: list, param: str) -> str:
-    """'down3.gamma' of object 'generator' -> TF-style object-graph key."""
+    """'down3.gamma' of object 'generator' -> TF object-graph checkpoint key."""
     layer, attr = param.rsplit('.', 1)
-    k = layer_names.index(layer)
-    inner = {'kernel': 0, 'bias': 0, 'gamma': 1, 'beta': 1, 'scale': 1, 'offset': 1, 'moving_mean': 1,
-             'moving_variance': 1}[attr]
-    return f"{obj_name}/layer_with_weights-{k}/layer_with_weights-{inner}/{attr}/.ATTRIBUTES/VARIABLE_VALUE"
+    sequential = layer.startswith(('down', 'up'))
+    if sequential:
+        k = layer_names.index(layer)
+        path = f"layer_with_weights-{k}/layer_with_weights-{1 if attr in _NORM_ATTRS else 0}"
+    elif layer == 'conv':                       # discriminator: Conv2D and its norm layer are two model-level layers
+        path = f"layer_with_weights-{4 if attr in _NORM_ATTRS else 3}"
+    else:                                       # 'last': generator head (15) / discriminator logits layer (5)
+        path = f"layer_with_weights-{15 if len(layer_names) > 8 else 5}"
+    return f"{obj_name}/{path}/{attr}/.ATTRIBUTES/VARIABLE_VALUE"
 
 
 GEN_LAYERS = [f'down{i}' for i in range(8)] + [f'up{i}' for i in range(7)] + ['last']
@@ -30,53 +44,78 @@ DISC_LAYERS = ['down0', 'down1', 'down2', 'conv', 'last']
 
 
 class Checkpoint:
-    """Named collection of networks ({obj_name: (arrays_getter, arrays_setter, layer_names)}) like
-    tf.train.Checkpoint(generator=..., discriminator=..., generator_optimizer=...)."""
+    """tf.train.Checkpoint(generator=..., discriminator=..., generator_optimizer=..., ...): named objects exposing
+    state_dict() / load_state_dict().  An object named `<model>_optimizer` is the optimizer of `<model>`: its Adam slots
+    are stored under the model's variable paths, as TensorFlow does."""
+    SAVE_COUNTER = 'save_counter/.ATTRIBUTES/VARIABLE_VALUE'
 
     def __init__(self, **objects):
-        self.objects = objects       # name -> object exposing state_dict() / load_state_dict(dict)
+        self.objects = objects
         self.save_counter = 0
 
+    def _slot_key(self, opt_name, slot, param):
+        model = opt_name[:-len('_optimizer')]
+        var = tf_variable_key(model, self.objects[model].layers, param)
+        return var.replace('/.ATTRIBUTES/', f'/.OPTIMIZER_SLOT/{opt_name}/{slot}/.ATTRIBUTES/')
+
     def _gather(self):
-        out = {}
+        out, names, slots = {}, {}, []
         for name, obj in self.objects.items():
             for k, v in obj.state_dict().items():
-                out[f"{name}/{k}"] = np.ascontiguousarray(v)
-        out['save_counter/.ATTRIBUTES/VARIABLE_VALUE'] = np.array(self.save_counter, np.int64)
-        return out
+                if k.startswith('slot/'):
+                    _, slot, param = k.split('/', 2)
+                    key = self._slot_key(name, slot, param)
+                    model = name[:-len('_optimizer')]
+                    slots.append((name, slot, tf_variable_key(model, self.objects[model].layers, param), key))
+                else:
+                    key = f"{name}/{k}"
+                out[key] = np.asarray(v)
+                names[key] = key.split('/.ATTRIBUTES/')[0]
+        out[self.SAVE_COUNTER] = np.array(self.save_counter, np.int64)
+        names[self.SAVE_COUNTER] = 'save_counter'
+        return out, names, slots
 
     def write(self, prefix: str):
-        arrays = self._gather()
-        index, off = {}, 0
-        with open(prefix + '.data-00000-of-00001', 'wb') as f:
-            for k in sorted(arrays):
-                a = arrays[k]
-                b = a.tobytes()
-                index[k] = {'dtype': str(a.dtype), 'shape': list(a.shape), 'offset': off, 'size': len(b)}
-                f.write(b)
-                off += len(b)
-        with open(prefix + '.index', 'w') as f:
-            json.dump({'format': 'gan_amd-bundle-v1', 'tensors': index}, f)
-        return prefix
+        arrays, names, slots = self._gather()
+        return tfbundle.write_bundle(prefix, arrays, tfbundle.object_graph(names, slots))
+
+    def _read(self, prefix):
+        with open(prefix + '.index', 'rb') as f:
+            legacy = f.read(1) == b'{'
+        if not legacy:
+            return tfbundle.read_bundle(prefix)[0]
+        with open(prefix + '.index') as f:              # round-1 container: JSON index + raw data
+            index = json.load(f)['tensors']
+        data = np.memmap(prefix + '.data-00000-of-00001', dtype=np.uint8, mode='r')
+        out = {}
+        for k, meta in index.items():
+            a = np.frombuffer(data[meta['offset']:meta['offset'] + meta['size']].tobytes(), dtype=meta['dtype'])
+            out[k] = a.reshape(meta['shape'])
+        return out
 
     def restore(self, prefix: str):
         """Like `.restore(...).expect_partial()` (pix2pix.py:411): keys missing on either side are ignored."""
         if prefix is None:
             raise ValueError("no checkpoint found")
-        with open(prefix + '.index') as f:
-            index = json.load(f)['tensors']
-        data = np.memmap(prefix + '.data-00000-of-00001', dtype=np.uint8, mode='r')
+        arrays = self._read(prefix)
         per_obj = {name: {} for name in self.objects}
-        for k, meta in index.items():
+        for k, a in arrays.items():
+            m = re.match(r'(.+)/\.OPTIMIZER_SLOT/([^/]+)/([^/]+)/\.ATTRIBUTES/VARIABLE_VALUE$', k)
+            if m and m.group(2) in per_obj:              # slot of <optimizer>: hand it over under the optimizer's own naming
+                model = m.group(2)[:-len('_optimizer')]
+                if model in self.objects:
+                    for param in self.objects[model].param_names():
+                        if tf_variable_key(model, self.objects[model].layers, param).startswith(m.group(1) + '/'):
+                            per_obj[m.group(2)][f'slot/{m.group(3)}/{param}'] = a
+                            break
+                continue
             name, _, rest = k.partition('/')
             if name in per_obj:
-                a = np.frombuffer(data[meta['offset']:meta['offset'] + meta['size']].tobytes(), dtype=meta['dtype'])
-                per_obj[name][rest] = a.reshape(meta['shape'])
+                per_obj[name][rest] = a
         for name, obj in self.objects.items():
             obj.load_state_dict(per_obj[name])
-        if 'save_counter/.ATTRIBUTES/VARIABLE_VALUE' in index:
-            m = index['save_counter/.ATTRIBUTES/VARIABLE_VALUE']
-            self.save_counter = int(np.frombuffer(data[m['offset']:m['offset'] + m['size']].tobytes(), dtype=m['dtype'])[0])
+        if self.SAVE_COUNTER in arrays:
+            self.save_counter = int(np.asarray(arrays[self.SAVE_COUNTER]).reshape(-1)[0])
         return self
 
 

@@ -249,6 +249,9 @@ int gan_bias_grad(int32_t dtype, const GanTensor* dy, float* dbias, int32_t accu
  * before the RCCL all-reduce, and back (times `scale` = 1/world) before Adam.  count % 8 == 0, 16-byte aligned. */
 int gan_grad_pack(const float* src, void* dst_bf16, int64_t count, gan_stream_t stream);
 int gan_grad_unpack(const void* src_bf16, float* dst, int64_t count, float scale, gan_stream_t stream);
+/* Host utility (no GPU): CRC-32C of TensorFlow's TensorBundle checkpoint files (tf.train.Checkpoint /
+ * CheckpointManager, pix2pix.py:400-403,419-420; cycle_gan.py:437-444,460-461).  crc = 0 to start; chainable. */
+uint32_t gan_crc32c(uint32_t crc, const void* data, size_t n);
 const char* gan_version(void);
 
 #ifdef __cplusplus

@@ -248,3 +248,125 @@ def test_batches_forward_errors_and_release_their_worker(tmp_path):
             break
         time.sleep(0.05)
     assert threading.active_count() <= before
+
+
+def test_tensorbundle_container_structure_and_roundtrip(tmp_path):
+    """gan_amd/tfbundle.py: the TensorBundle files tf.train.Checkpoint writes (pix2pix.py:400-403,419-420), restated without
+    TensorFlow.  Checked here: CRC-32C known answers and masking, table magic / footer / block checksums / sorted keys with
+    prefix compression across restart points and several data blocks, BundleEntryProto fields, the string-tensor
+    encoding of the object graph, and a byte-exact round trip."""
+    import struct
+    from gan_amd import tfbundle as TB
+    assert TB._crc32c(b'123456789') == 0xE3069283 and TB._crc32c(b'') == 0                     # CRC-32C check value
+    assert TB._crc32c(b'6789', TB._crc32c(b'12345')) == 0xE3069283                              # chainable
+    assert TB._unmask(TB._mask(0x12345678)) == 0x12345678 and TB._mask(0) == 0xa282ead8
+    rng = np.random.default_rng(0)
+    arrays = {f'generator/layer_with_weights-{i}/layer_with_weights-0/kernel/.ATTRIBUTES/VARIABLE_VALUE':
+              rng.standard_normal((4, 4, 8, 16)).astype(np.float32) for i in range(40)}
+    arrays['generator_optimizer/iter/.ATTRIBUTES/VARIABLE_VALUE'] = np.array(12345, np.int64)
+    arrays['big/.ATTRIBUTES/VARIABLE_VALUE'] = rng.standard_normal((300, 300)).astype(np.float32)
+    names = {k: k.split('/.ATTRIBUTES/')[0] for k in arrays}
+    prefix = str(tmp_path / 'ckpt-1')
+    TB.write_bundle(prefix, arrays, TB.object_graph(names, []))
+    raw = open(prefix + '.index', 'rb').read()
+    assert struct.unpack('<Q', raw[-8:])[0] == 0xdb4775248b80fb57 and len(raw) >= 48          # table footer magic
+    items = TB.read_table(prefix + '.index')                                                    # verifies every block checksum
+    keys = [k for k, _ in items]
+    assert keys[0] == b'' and keys == sorted(keys) and len(keys) == len(arrays) + 2            # header + tensors + object graph
+    hdr = dict((n, v) for n, _, v in TB._parse(items[0][1]))
+    assert hdr[1] == 1 and dict((n, v) for n, _, v in TB._parse(hdr[3]))[1] == 1                # num_shards 1, version.producer 1
+    ent = dict((n, v) for n, _, v in TB._parse(dict(items)[b'big/.ATTRIBUTES/VARIABLE_VALUE']))
+    assert ent[1] == 1 and ent[5] == 300 * 300 * 4                                              # DT_FLOAT, size in bytes
+    got, graph = TB.read_bundle(prefix)
+    assert set(got) == set(arrays) and all(np.array_equal(got[k], arrays[k]) and got[k].dtype == arrays[k].dtype for k in arrays)
+    nodes = TB.parse_object_graph(graph)
+    n = nodes[0]['children']['generator']
+    n = nodes[n]['children']['layer_with_weights-7']
+    n = nodes[n]['children']['layer_with_weights-0']
+    n = nodes[n]['children']['kernel']
+    assert nodes[n]['keys'] == ['generator/layer_with_weights-7/layer_with_weights-0/kernel/.ATTRIBUTES/VARIABLE_VALUE']
+    # a table with many small entries spans several restart intervals and data blocks
+    many = [(f'k{i:06d}'.encode(), (b'v%d' % i) * 50) for i in range(5000)]
+    TB.write_table(str(tmp_path / 't.index'), many)
+    assert TB.read_table(str(tmp_path / 't.index')) == many
+    bad = bytearray(open(tmp_path / 't.index', 'rb').read())
+    bad[100] ^= 1
+    open(tmp_path / 'bad.index', 'wb').write(bad)
+    with pytest.raises(ValueError, match="checksum"):
+        TB.read_table(str(tmp_path / 'bad.index'))
+
+
+def test_checkpoint_keys_follow_the_keras_object_graph(tmp_path):
+    """Variable naming of the reference's models under tf.train.Checkpoint (which layers are nested Sequentials, which sit
+    directly in the functional model: base_gan.py:124-225), Adam slots under the variable's path, legacy (round-1 JSON)
+    checkpoints still readable."""
+    import json
+    from gan_amd.checkpoint import DISC_LAYERS, GEN_LAYERS, Checkpoint, tf_variable_key
+    from gan_amd import tfbundle as TB
+    K = lambda o, l, p: tf_variable_key(o, l, p).replace('/.ATTRIBUTES/VARIABLE_VALUE', '')
+    assert K('generator', GEN_LAYERS, 'down0.kernel') == 'generator/layer_with_weights-0/layer_with_weights-0/kernel'
+    assert K('generator', GEN_LAYERS, 'up6.beta') == 'generator/layer_with_weights-14/layer_with_weights-1/beta'
+    assert K('generator', GEN_LAYERS, 'last.bias') == 'generator/layer_with_weights-15/bias'                   # plain Conv2DTranspose
+    assert K('discriminator', DISC_LAYERS, 'down2.moving_mean') == 'discriminator/layer_with_weights-2/layer_with_weights-1/moving_mean'
+    assert K('discriminator', DISC_LAYERS, 'conv.kernel') == 'discriminator/layer_with_weights-3/kernel'      # plain Conv2D ...
+    assert K('discriminator', DISC_LAYERS, 'conv.gamma') == 'discriminator/layer_with_weights-4/gamma'        # ... and its own norm layer
+    assert K('discriminator_x', DISC_LAYERS, 'last.kernel') == 'discriminator_x/layer_with_weights-5/kernel'
+
+    class Model:
+        layers, obj_name = DISC_LAYERS, 'discriminator'
+
+        def __init__(self, seed):
+            r = np.random.default_rng(seed)
+            self.P = {'conv.kernel': r.standard_normal((4, 4, 8, 4)).astype(np.float32), 'last.bias': r.standard_normal(1).astype(np.float32)}
+
+        def param_names(self):
+            return list(self.P)
+
+        def state_dict(self):
+            return {tf_variable_key('discriminator', DISC_LAYERS, k).split('/', 1)[1]: v for k, v in self.P.items()}
+
+        def load_state_dict(self, sd):
+            self.loaded = sd
+
+    class Opt:
+        def __init__(self, model, seed):
+            r = np.random.default_rng(seed)
+            self.sd = {'iter/.ATTRIBUTES/VARIABLE_VALUE': np.array(3, np.int64)}
+            for slot in ('m', 'v'):
+                for k, v in model.P.items():
+                    self.sd[f'slot/{slot}/{k}'] = r.standard_normal(v.shape).astype(np.float32)
+
+        def state_dict(self):
+            return self.sd
+
+        def load_state_dict(self, sd):
+            self.loaded = sd
+
+    m = Model(1)
+    o = Opt(m, 2)
+    ck = Checkpoint(discriminator=m, discriminator_optimizer=o)
+    ck.save_counter = 4
+    prefix = ck.write(str(tmp_path / 'ckpt-4'))
+    arrays, graph = TB.read_bundle(prefix)
+    assert 'discriminator/layer_with_weights-3/kernel/.OPTIMIZER_SLOT/discriminator_optimizer/m/.ATTRIBUTES/VARIABLE_VALUE' in arrays
+    assert 'discriminator_optimizer/iter/.ATTRIBUTES/VARIABLE_VALUE' in arrays and int(arrays['save_counter/.ATTRIBUTES/VARIABLE_VALUE']) == 4
+    nodes = TB.parse_object_graph(graph)
+    opt = nodes[nodes[0]['children']['discriminator_optimizer']]
+    assert sorted(s for _, s, _ in opt['slots']) == ['m', 'm', 'v', 'v']
+    orig, slot, sv = opt['slots'][0]
+    assert nodes[orig]['keys'][0].startswith('discriminator/layer_with_weights-') and '.OPTIMIZER_SLOT' in nodes[sv]['keys'][0]
+    m2 = Model(7)
+    o2 = Opt(m2, 8)
+    ck2 = Checkpoint(discriminator=m2, discriminator_optimizer=o2).restore(prefix)
+    assert ck2.save_counter == 4
+    assert np.array_equal(m2.loaded['layer_with_weights-3/kernel/.ATTRIBUTES/VARIABLE_VALUE'], m.P['conv.kernel'])
+    assert np.array_equal(o2.loaded['slot/v/last.bias'], o.sd['slot/v/last.bias']) and int(o2.loaded['iter/.ATTRIBUTES/VARIABLE_VALUE']) == 3
+    # round-1 container (JSON index + raw data) is still readable
+    a = m.P['conv.kernel']
+    with open(tmp_path / 'old.data-00000-of-00001', 'wb') as f:
+        f.write(a.tobytes())
+    json.dump({'format': 'gan_amd-bundle-v1', 'tensors': {'discriminator/layer_with_weights-3/kernel/.ATTRIBUTES/VARIABLE_VALUE':
+              {'dtype': 'float32', 'shape': list(a.shape), 'offset': 0, 'size': a.nbytes}}}, open(tmp_path / 'old.index', 'w'))
+    m3 = Model(9)
+    Checkpoint(discriminator=m3).restore(str(tmp_path / 'old'))
+    assert np.array_equal(m3.loaded['layer_with_weights-3/kernel/.ATTRIBUTES/VARIABLE_VALUE'], a)
