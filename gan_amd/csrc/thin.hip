@@ -1,4 +1,4 @@
-// Streaming convolution kernels for the layers that have <= 8 channels on one side (bf16 path).
+// Streaming convolution kernels for the layers that have <= 8 channels on one side (16-bit paths: bf16 and fp16).
 //
 // The U-Net's first/last layers and the PatchGAN's first/last layers (base_gan.py:141-166, :176-204) move
 // 50-100 MB of activations for a few GFLOP: they are HBM-bound, and the LDS-tiled implicit GEMM spends its
@@ -18,12 +18,10 @@
 #include "common.h"
 #include "conv_params.h"
 #include <stdlib.h>
+#include <type_traits>
 
 typedef __attribute__((ext_vector_type(8))) short s16x8;
 
-__device__ __forceinline__ f32x4 mfma_bf16(const uint4& a, const uint4& b, f32x4 c) {
-  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&a, *(const bf16x8*)&b, c, 0, 0, 0);
-}
 
 // ------------------------------------------------------------------------------------------------
 // thin-K: Y[pixel, co] = act(bias + sum_{tap, c<8} X[src(pixel, tap), c] * W[tap][co][c])
@@ -31,12 +29,13 @@ __device__ __forceinline__ f32x4 mfma_bf16(const uint4& a, const uint4& b, f32x4
 // A wave owns 64 output channels (blockIdx.y) and walks 16-pixel tiles.  The 16 A rows of an MFMA pair are
 // mapped to channels so that a lane ends up with 8 consecutive channels of its pixel: one 16-byte store.
 struct ThinKParams {
-  const bf16_t* x; const bf16_t* w; bf16_t* y; const float* bias;
+  const void* x; const void* w; void* y; const float* bias;
   int Hs, Ws, xpitch, Hg, Wg, M, S, dy0, dstep, Wrows, ypitch, act, tiles;
   float slope;
   FastDiv divWg, divHg;
 };
 
+template <typename T>
 __global__ __launch_bounds__(256) void conv_thin_k_kernel(const ThinKParams p) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n = lane & 15, q = lane >> 4;
@@ -46,7 +45,7 @@ __global__ __launch_bounds__(256) void conv_thin_k_kernel(const ThinKParams p) {
   for (int ct = 0; ct < 4; ++ct) {
     const int ch = cbase + (ct >> 1) * 32 + (n >> 2) * 8 + (ct & 1) * 4 + (n & 3);
 #pragma unroll
-    for (int s = 0; s < 4; ++s) wf[ct][s] = *(const uint4*)(p.w + ((size_t)(s * 4 + q) * p.Wrows + ch) * 8);
+    for (int s = 0; s < 4; ++s) wf[ct][s] = *(const uint4*)((const T*)p.w + ((size_t)(s * 4 + q) * p.Wrows + ch) * 8);
   }
   float bv[2][8];
 #pragma unroll
@@ -68,17 +67,17 @@ __global__ __launch_bounds__(256) void conv_thin_k_kernel(const ThinKParams p) {
       const int sy = gy * p.S + p.dy0 + s * p.dstep;
       xf[s] = make_uint4(0, 0, 0, 0);
       if (rowok && (unsigned)sy < (unsigned)p.Hs && (unsigned)sx < (unsigned)p.Ws)
-        xf[s] = *(const uint4*)(p.x + ((size_t)(img * p.Hs + sy) * p.Ws + sx) * p.xpitch);
+        xf[s] = *(const uint4*)((const T*)p.x + ((size_t)(img * p.Hs + sy) * p.Ws + sx) * p.xpitch);
     }
     f32x4 acc[4];
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) {
       acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int s = 0; s < 4; ++s) acc[ct] = mfma_bf16(wf[ct][s], xf[s], acc[ct]);
+      for (int s = 0; s < 4; ++s) acc[ct] = mma16<T>(wf[ct][s], xf[s], acc[ct]);
     }
     if (rowok) {
-      bf16_t* yp = p.y + ((size_t)(img * p.Hg + gy) * p.Wg + gx) * p.ypitch + cbase + q * 8;
+      T* yp = (T*)p.y + ((size_t)(img * p.Hg + gy) * p.Wg + gx) * p.ypitch + cbase + q * 8;
 #pragma unroll
       for (int pr = 0; pr < 2; ++pr) {
         float v[8];
@@ -87,7 +86,7 @@ __global__ __launch_bounds__(256) void conv_thin_k_kernel(const ThinKParams p) {
           v[i] = apply_act(acc[2 * pr][i] + bv[pr][i], p.act, p.slope);
           v[4 + i] = apply_act(acc[2 * pr + 1][i] + bv[pr][4 + i], p.act, p.slope);
         }
-        *(uint4*)(yp + pr * 32) = pack16<bf16_t>(v);
+        *(uint4*)(yp + pr * 32) = pack16<T>(v);
       }
     }
   }
@@ -97,11 +96,11 @@ __global__ __launch_bounds__(256) void conv_thin_k_kernel(const ThinKParams p) {
 // thin-N step 1: Z[pixel][c][tap] = sum_ci X[pixel, ci] * W[tap][c][ci]   (fp32 Z, taps = the MFMA's 16 rows)
 // Weight fragments sit in LDS in operand order (CO * KS KiB); x is read once with 16-byte loads.
 struct ThinNParams {
-  const bf16_t* x; const bf16_t* w; float* z;
+  const void* x; const void* w; float* z;
   int Mx, xpitch, Cin, Wrows, CO, tiles;
 };
 
-template <int KS>      // Cin = 32 * KS
+template <typename T, int KS>      // Cin = 32 * KS
 __global__ __launch_bounds__(256) void conv_thin_n_kernel(const ThinNParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint4* wl = (uint4*)smem;                                // [c][s][lane]
@@ -109,20 +108,20 @@ __global__ __launch_bounds__(256) void conv_thin_n_kernel(const ThinNParams p) {
   const int n = lane & 15, q = lane >> 4;
   for (int e = threadIdx.x; e < p.CO * KS * 64; e += 256) {
     const int l = e & 63, s = (e >> 6) % KS, c = (e >> 6) / KS;
-    wl[e] = *(const uint4*)(p.w + ((size_t)(l & 15) * p.Wrows + c) * p.Cin + s * 32 + (l >> 4) * 8);
+    wl[e] = *(const uint4*)((const T*)p.w + ((size_t)(l & 15) * p.Wrows + c) * p.Cin + s * 32 + (l >> 4) * 8);
   }
   __syncthreads();
   for (int tile = blockIdx.x * 4 + wave; tile < p.tiles; tile += gridDim.x * 4) {
     const int pix = tile * 16 + n;
     const bool ok = pix < p.Mx;
     uint4 xf[KS];
-    const bf16_t* xp = p.x + (size_t)pix * p.xpitch + q * 8;
+    const T* xp = (const T*)p.x + (size_t)pix * p.xpitch + q * 8;
 #pragma unroll
     for (int s = 0; s < KS; ++s) xf[s] = ok ? *(const uint4*)(xp + s * 32) : make_uint4(0, 0, 0, 0);
     for (int c = 0; c < p.CO; ++c) {
       f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int s = 0; s < KS; ++s) acc = mfma_bf16(wl[(c * KS + s) * 64 + lane], xf[s], acc);
+      for (int s = 0; s < KS; ++s) acc = mma16<T>(wl[(c * KS + s) * 64 + lane], xf[s], acc);
       if (ok) *(f32x4*)(p.z + ((size_t)pix * p.CO + c) * 16 + q * 4) = acc;
     }
   }
@@ -131,7 +130,7 @@ __global__ __launch_bounds__(256) void conv_thin_n_kernel(const ThinNParams p) {
 // thin-N step 2: Y[out pixel, c] = act(bias[c] + sum over the valid taps of Z[src pixel][c][tap])
 struct Col2imParams {
   const float* z; void* y; const float* bias;
-  int Hs, Ws, Ho, Wo, CO, ypitch, out_f32, act, parity, S, dy0, dstep;
+  int Hs, Ws, Ho, Wo, CO, ypitch, out_f32, act, parity, S, dy0, dstep, f16;
   float slope;
   long long total;
   FastDiv divWo, divHo;
@@ -179,6 +178,7 @@ __global__ __launch_bounds__(256) void conv_thin_col2im_kernel(const Col2imParam
     float v = acc[c] + (p.bias ? p.bias[c] : 0.f);
     v = apply_act(v, p.act, p.slope);
     if (p.out_f32) ((float*)p.y)[o + c] = v;
+    else if (p.f16) ((f16_t*)p.y)[o + c] = (f16_t)v;
     else ((bf16_t*)p.y)[o + c] = (bf16_t)v;
   }
 }
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256) void conv_thin_col2im_kernel(const Col2imParam
 int thin_family(const GanConvDesc* d, int op, const GemmParams& p) {
   static int off = -1;
   if (off < 0) { const char* e = getenv("GAN_AMD_NO_THIN"); off = e ? atoi(e) : 0; }
-  if (off == 1 || d->dtype != GAN_BF16) return 0;
+  if (off == 1 || d->dtype == GAN_F32) return 0;
   const GanTensor &x = d->x, &y = d->y;
   // thin-N: few output channels.  Z needs one MFMA tile per output channel; weights CO*KS KiB of LDS.
   if (!(off & 2) && y.c <= 6 && (x.c == 64 || x.c == 128 || x.c == 512) && (x.c / 32) * y.c <= 48 &&
@@ -209,7 +209,7 @@ int thin_launch(int family, const GanConvDesc* d, const GemmParams& p, hipStream
   const GanTensor &x = d->x, &y = d->y;
   if (family == 2) {
     ThinKParams k;
-    k.x = (const bf16_t*)p.x; k.w = (const bf16_t*)p.w; k.y = (bf16_t*)p.y; k.bias = p.bias;
+    k.x = p.x; k.w = p.w; k.y = p.y; k.bias = p.bias;
     k.Hs = p.Hs; k.Ws = p.Ws; k.xpitch = p.xpitch; k.Hg = p.Hg; k.Wg = p.Wg; k.M = p.M; k.S = p.S;
     k.dy0 = p.dy0; k.dstep = p.dstep; k.Wrows = p.Wrows; k.ypitch = p.ypitch; k.act = p.act; k.slope = p.slope;
     k.tiles = (p.M + 15) / 16;
@@ -218,7 +218,8 @@ int thin_launch(int family, const GanConvDesc* d, const GemmParams& p, hipStream
     int gx = (k.tiles + 3) / 4;
     const int cap = 2048 / groups > 256 ? 2048 / groups : 256;
     if (gx > cap) gx = cap;
-    hipLaunchKernelGGL(conv_thin_k_kernel, dim3((unsigned)gx, (unsigned)groups), dim3(256), 0, st, k);
+    if (d->dtype == GAN_F16) hipLaunchKernelGGL(conv_thin_k_kernel<f16_t>, dim3((unsigned)gx, (unsigned)groups), dim3(256), 0, st, k);
+    else hipLaunchKernelGGL(conv_thin_k_kernel<bf16_t>, dim3((unsigned)gx, (unsigned)groups), dim3(256), 0, st, k);
     GAN_CHECK_LAUNCH();
     return 0;
   }
@@ -226,20 +227,25 @@ int thin_launch(int family, const GanConvDesc* d, const GemmParams& p, hipStream
   const size_t zbytes = thin_workspace_bytes(1, d, p);
   if (!d->workspace || d->workspace_bytes < zbytes) return GAN_E_WORKSPACE;
   ThinNParams n;
-  n.x = (const bf16_t*)p.x; n.w = (const bf16_t*)p.w; n.z = (float*)d->workspace;
+  n.x = p.x; n.w = p.w; n.z = (float*)d->workspace;
   n.Mx = x.n * x.h * x.w; n.xpitch = p.xpitch; n.Cin = x.c; n.Wrows = p.Wrows; n.CO = y.c;
   n.tiles = (n.Mx + 15) / 16;
   const int KS = x.c / 32;
   int gx = (n.tiles + 3) / 4;
   if (gx > 2048) gx = 2048;
   const size_t smem = (size_t)n.CO * KS * 1024;
-  if (KS == 2) hipLaunchKernelGGL(conv_thin_n_kernel<2>, dim3((unsigned)gx), dim3(256), smem, st, n);
-  else if (KS == 4) hipLaunchKernelGGL(conv_thin_n_kernel<4>, dim3((unsigned)gx), dim3(256), smem, st, n);
-  else hipLaunchKernelGGL(conv_thin_n_kernel<16>, dim3((unsigned)gx), dim3(256), smem, st, n);
+  auto launch_n = [&](auto* tag) {
+    typedef typename std::remove_pointer<decltype(tag)>::type T;
+    if (KS == 2) hipLaunchKernelGGL((conv_thin_n_kernel<T, 2>), dim3((unsigned)gx), dim3(256), smem, st, n);
+    else if (KS == 4) hipLaunchKernelGGL((conv_thin_n_kernel<T, 4>), dim3((unsigned)gx), dim3(256), smem, st, n);
+    else hipLaunchKernelGGL((conv_thin_n_kernel<T, 16>), dim3((unsigned)gx), dim3(256), smem, st, n);
+  };
+  if (d->dtype == GAN_F16) launch_n((f16_t*)nullptr); else launch_n((bf16_t*)nullptr);
   GAN_CHECK_LAUNCH();
   Col2imParams c;
   c.z = n.z; c.y = p.y; c.bias = p.bias;
   c.Hs = p.Hs; c.Ws = p.Ws; c.Ho = p.Ho; c.Wo = p.Wo; c.CO = y.c; c.ypitch = p.ypitch; c.out_f32 = p.out_f32;
+  c.f16 = d->dtype == GAN_F16;
   c.act = p.act; c.parity = p.parity; c.S = p.S; c.dy0 = p.dy0; c.dstep = p.dstep; c.slope = p.slope;
   c.total = (long long)x.n * p.Ho * p.Wo;
   c.divWo = make_fastdiv((uint32_t)p.Wo); c.divHo = make_fastdiv((uint32_t)p.Ho);
