@@ -100,6 +100,7 @@ SYMBOLS = {
     "gan_adam_begin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
     "gan_adam_tf": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_float,
                               C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
+    "gan_sum3": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "gan_grads_check": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "gan_loss_scale_update": (C.c_int, [C.c_void_p, C.c_int32, C.c_float, C.c_void_p]),
     "gan_dropout_mask": (C.c_int, [C.c_void_p, C.c_int64, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p]),

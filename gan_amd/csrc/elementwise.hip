@@ -363,6 +363,12 @@ template <typename F> static inline int with_dtype(int dtype, F&& f) {
 }
 #define GAN_TAG_T(tag) typename std::remove_pointer<decltype(tag)>::type
 
+// out[k] = a[k] + b[k] + c[k] for n <= 64 loss scalars (CycleGAN's total generator losses, cycle_gan.py:243-244)
+__global__ void sum3_kernel(const float* a, const float* b, const float* c, float* out, int n) {
+  const int k = threadIdx.x;
+  if (k < n) out[k] = a[k] + b[k] + c[k];
+}
+
 // gradient wire format of the data-parallel exchange (gan_amd/ddp.py): fp32 <-> bf16, 8 elements per thread
 __global__ __launch_bounds__(256) void grad_pack_kernel(const float4* __restrict__ src, uint4* __restrict__ dst, long long n8) {
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
@@ -609,6 +615,12 @@ int gan_copy_view(int32_t dtype, const GanTensor* src, const GanTensor* dst, gan
   });
 }
 
+int gan_sum3(const float* a, const float* b, const float* c, float* out, int32_t n, gan_stream_t stream) {
+  if (!a || !b || !c || !out || n <= 0 || n > 64) return GAN_E_ARG;
+  hipLaunchKernelGGL(sum3_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a, b, c, out, n);
+  GAN_CHECK_LAUNCH();
+  return 0;
+}
 int gan_grad_pack(const float* src, void* dst_bf16, int64_t count, gan_stream_t stream) {
   if (!src || !dst_bf16 || count <= 0 || count % 8 || (((uintptr_t)src | (uintptr_t)dst_bf16) & 15)) return GAN_E_ARG;
   const long long n8 = count / 8;

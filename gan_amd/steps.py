@@ -443,8 +443,8 @@ class CycleGANStep(_StepBase):
             self.dx.backward_params(); self.dy.backward_params()
             return self.losses
         fy, cx, fx, cy, sx, sy, dx, dy = self.fy, self.cx, self.fx, self.cy, self.sx, self.sy, self.dx, self.dy
-        self._pack(real_x, fy.xin.view(0, Cc)); self._pack(real_x, sx.xin.view(0, Cc)); self._pack(real_x, dx.xin.view(0, Cc, 0, B))
-        self._pack(real_y, fx.xin.view(0, Cc)); self._pack(real_y, sy.xin.view(0, Cc)); self._pack(real_y, dy.xin.view(0, Cc, 0, B))
+        self._pack_multi([(real_x, fy.xin.view(0, Cc)), (real_x, sx.xin.view(0, Cc)), (real_y, fx.xin.view(0, Cc)), (real_y, sy.xin.view(0, Cc))])
+        self._pack_multi([(real_x, dx.xin.view(0, Cc, 0, B)), (real_y, dy.xin.view(0, Cc, 0, B))])
         fy.forward()                                                  # cycle_gan.py:220
         self._copy(fy.out_view(), cx.xin.view(0, Cc)); self._copy(fy.out_view(), dy.xin.view(0, Cc, B, B))
         cx.forward()                                                  # :221
@@ -462,8 +462,9 @@ class CycleGANStep(_StepBase):
         self._l1(cy.out_view(), yv, 2, lam, True, lam, cy.dgen.view(0, Cc))
         self._l1(sy.out_view(), yv, 7, lam * 0.5, False, lam * 0.5, sy.dgen.view(0, Cc))  # identity :243
         self._l1(sx.out_view(), xv, 8, lam * 0.5, False, lam * 0.5, sx.dgen.view(0, Cc))  # identity :244
-        self.losses[3:4] = self.losses[0:1] + self.losses[2:3] + self.losses[7:8]
-        self.losses[4:5] = self.losses[1:2] + self.losses[2:3] + self.losses[8:9]
+        lp = self.losses.data_ptr()               # total_gen_g / total_gen_f (:243-244): gen + cycle + identity, one tiny launch
+        L.check(self.ctx.lib.gan_sum3(lp, lp + 8, lp + 28, lp + 12, 1, self.ctx.stream()), "sum3")      # [3] = [0] + [2] + [7]
+        L.check(self.ctx.lib.gan_sum3(lp + 4, lp + 8, lp + 32, lp + 16, 1, self.ctx.stream()), "sum3")  # [4] = [1] + [2] + [8]
         self._bce(rx_ptr, cnt, 1.0, 5, 0.5, False, 0.5, dx.dlogits_ptr(0))                # disc_x_loss :246
         self._bce(fxl_ptr, cnt, 0.0, 5, 0.5, True, 0.5, dx.dlogits_ptr(1))
         self._bce(ry_ptr, cnt, 1.0, 6, 0.5, False, 0.5, dy.dlogits_ptr(0))                # disc_y_loss :247

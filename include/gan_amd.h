@@ -206,6 +206,10 @@ int gan_l1(int32_t dtype, const GanTensor* a, const GanTensor* b, float loss_sca
            float* loss_out, float grad_scale, const GanTensor* da, float* workspace, const float* scale_state,
            gan_stream_t stream);
 
+/* out[k] = a[k] + b[k] + c[k], n <= 64 device scalars: total_gen_g_loss = gen_g_loss + total_cycle_loss + identity_loss
+ * (cycle_gan.py:243-244) without leaving the captured step. */
+int gan_sum3(const float* a, const float* b, const float* c, float* out, int32_t n, gan_stream_t stream);
+
 /* ---- optimiser ------------------------------------------------------------------------------ */
 /* tf.keras.optimizers.Adam (base_gan.py:247-252), TF form: lr_t = lr*sqrt(1-b2^t)/(1-b1^t);
  * m += (g-m)(1-b1); v += (g*g-v)(1-b2); p -= lr_t*m/(sqrt(v)+eps).  `step` is a device counter:

@@ -34,7 +34,11 @@ def check_grads(dtype, pairs, f32_tol):
                 assert c > 0.999, (name, c)
         elif np.linalg.norm(ref) > 1e-3 * gmax:
             worst_cos = min(worst_cos, c)
-            assert c > 0.8, (name, c, r)     # InstanceNorm over the 2x2 bottleneck maps amplifies bf16 rounding (0.89 seen)
+            if c < 0.95:
+                print(f"    [bf16] {name}: cosine {c:.4f}")
+            # measured per tensor (round 2): every Pix2Pix tensor >= 0.9459, every CycleGAN tensor >= 0.9492 - the lowest are the
+            # 4x4 .. 32x32 layers of the generators, where the L1 term's sign() and the ReLU masks flip under bf16 rounding
+            assert c > 0.92, (name, c, r)
     print(f"[{dtype}] gradients: worst per-tensor rel err {worst_rel:.3e}, worst cosine {worst_cos:.5f}")
 
 
