@@ -613,8 +613,12 @@ class GenCall:
             inner_hook()
             self.ctx.run(self.fwd_ops[self.fwd_inner_start:])
 
-    def out_view(self):
-        return self.out.view(0, self.C)
+    def out_view(self, n0=0, n=None):
+        return self.out.view(0, self.C, n0, n)
+
+    def half(self, n0, n):
+        """Samples [n0, n0 + n) of this call as a call-like object (CycleGAN batches two logical calls of one generator)."""
+        return CallSlice(self, n0, n)
 
     def backward(self, use_dgen2=False, need_dx=False, accumulate=False, defer_wgrads=False):
         """Upstream gradient(s) w.r.t. the tanh output must be in self.dgen (and self.dgen2)."""
@@ -665,6 +669,30 @@ class GenCall:
         v = self.out_view()
         L.check(self.ctx.lib.gan_unpack(self.ctx.dt, C.byref(v), o.data_ptr(), self.ctx.stream()), "unpack")
         return o
+
+
+class CallSlice:
+    """A batch slice of a GenCall that stands for one logical generator invocation (masks, output, gradient slots)."""
+
+    def __init__(self, call, n0, n):
+        self.call, self.n0, self.n, self.C = call, n0, n, call.C
+
+    def set_dropmasks(self, masks):
+        for t, m in zip(self.call.masks, masks):
+            t[self.n0:self.n0 + self.n].copy_(torch.from_numpy(np.asarray(m)).to(torch.uint8))
+        self.call.auto_masks = False
+
+    def out_view(self):
+        return self.call.out.view(0, self.C, self.n0, self.n)
+
+    def xin_view(self):
+        return self.call.xin.view(0, self.C, self.n0, self.n)
+
+    def dgen_view(self, second=False):
+        return (self.call.dgen2 if second else self.call.dgen).view(0, self.C, self.n0, self.n)
+
+    def output_f32(self):
+        return self.call.output_f32()[self.n0:self.n0 + self.n]
 
 
 # --------------------------------------------------------------------------------------------------

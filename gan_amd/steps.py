@@ -417,6 +417,16 @@ class CycleGANStep(_StepBase):
         self.fy, self.cx = mk(self.Gg, 0), mk(self.Gf, 1)      # fake_y = G_g(x); cycled_x = G_f(fake_y)
         self.fx, self.cy = mk(self.Gf, 2), mk(self.Gg, 3)      # fake_x = G_f(y); cycled_y = G_g(fake_x)
         self.sx, self.sy = mk(self.Gf, 4), mk(self.Gg, 5)      # same_x = G_f(x); same_y = G_g(y)
+        # Small batches are launch-bound (~1,200 launches per step): G_g(x) and G_g(y) - likewise G_f(y), G_f(x) - use the same
+        # weights and InstanceNormalization is per sample, so the two invocations run as ONE call of batch 2B (exactly the
+        # same arithmetic per sample, a third fewer generator launches); the cycle calls depend on their outputs and stay.
+        mm = os.environ.get('GAN_AMD_CYC_MERGE', 'auto')
+        self.merged = (batch <= 4) if mm == 'auto' else mm == '1'
+        if self.merged:
+            self.gA = self.Gg.new_call(2 * batch, size, dropout=dropout, seed=seed, stream_id=mask_stream + 0)   # [fake_y ; same_y]
+            self.gB = self.Gf.new_call(2 * batch, size, dropout=dropout, seed=seed, stream_id=mask_stream + 2)   # [fake_x ; same_x]
+            self.fy, self.sy = self.gA.half(0, batch), self.gA.half(batch, batch)
+            self.fx, self.sx = self.gB.half(0, batch), self.gB.half(batch, batch)
         self.dx = self.Dx.new_call(batch, size, calls=2)       # D_x(real_x) ++ D_x(fake_x)
         self.dy = self.Dy.new_call(batch, size, calls=2)
         self.losses = torch.zeros(12, dtype=torch.float32, device=ctx.device)
@@ -442,6 +452,8 @@ class CycleGANStep(_StepBase):
         if phase == 2:
             self.dx.backward_params(); self.dy.backward_params()
             return self.losses
+        if self.merged:
+            return self._forward_backward_merged(real_x, real_y, training, phase)
         fy, cx, fx, cy, sx, sy, dx, dy = self.fy, self.cx, self.fx, self.cy, self.sx, self.sy, self.dx, self.dy
         self._pack_multi([(real_x, fy.xin.view(0, Cc)), (real_x, sx.xin.view(0, Cc)), (real_y, fx.xin.view(0, Cc)), (real_y, sy.xin.view(0, Cc))])
         self._pack_multi([(real_x, dx.xin.view(0, Cc, 0, B)), (real_y, dy.xin.view(0, Cc, 0, B))])
@@ -493,6 +505,51 @@ class CycleGANStep(_StepBase):
                 if phase != 1:
                     dx.backward_params(); dy.backward_params()
         return self.losses                                            # four Adam applies: _update() (:263-273)
+
+    def _forward_backward_merged(self, real_x, real_y, training, phase):
+        """The same step with [fake_y ; same_y] = G_g([x ; y]) and [fake_x ; same_x] = G_f([y ; x]) as two batch-2B calls."""
+        B, Cc, lam = self.B, self.C, self.lam
+        gA, gB, cx, cy, dx, dy = self.gA, self.gB, self.cx, self.cy, self.dx, self.dy
+        fy, sy, fx, sx = self.fy, self.sy, self.fx, self.sx
+        self._pack_multi([(real_x, fy.xin_view()), (real_y, sy.xin_view()), (real_y, fx.xin_view()), (real_x, sx.xin_view())])
+        self._pack_multi([(real_x, dx.xin.view(0, Cc, 0, B)), (real_y, dy.xin.view(0, Cc, 0, B))])
+        gA.forward()                                                  # cycle_gan.py:220 and :228
+        gB.forward()                                                  # :223 and :227
+        self._copy(fy.out_view(), cx.xin.view(0, Cc)); self._copy(fy.out_view(), dy.xin.view(0, Cc, B, B))
+        self._copy(fx.out_view(), cy.xin.view(0, Cc)); self._copy(fx.out_view(), dx.xin.view(0, Cc, B, B))
+        cx.forward()                                                  # :221
+        cy.forward()                                                  # :224
+        dx.forward(); dy.forward()                                    # :230-234
+        rx_ptr, cnt = dx.logits_view(0); fxl_ptr, _ = dx.logits_view(1)
+        ry_ptr, _ = dy.logits_view(0); fyl_ptr, _ = dy.logits_view(1)
+        xv, yv = fy.xin_view(), sy.xin_view()                         # typed real_x / real_y
+        self._bce(fyl_ptr, cnt, 1.0, 0, 1.0, False, 1.0, dy.dlogits_b.t.data_ptr())      # gen_g_loss :237
+        self._bce(fxl_ptr, cnt, 1.0, 1, 1.0, False, 1.0, dx.dlogits_b.t.data_ptr())      # gen_f_loss :238
+        self._l1(cx.out_view(), xv, 2, lam, False, lam, cx.dgen.view(0, Cc))              # total_cycle_loss :240
+        self._l1(cy.out_view(), yv, 2, lam, True, lam, cy.dgen.view(0, Cc))
+        self._l1(sy.out_view(), yv, 7, lam * 0.5, False, lam * 0.5, sy.dgen_view())       # identity :243
+        self._l1(sx.out_view(), xv, 8, lam * 0.5, False, lam * 0.5, sx.dgen_view())       # identity :244
+        lp = self.losses.data_ptr()
+        L.check(self.ctx.lib.gan_sum3(lp, lp + 8, lp + 28, lp + 12, 1, self.ctx.stream()), "sum3")
+        L.check(self.ctx.lib.gan_sum3(lp + 4, lp + 8, lp + 32, lp + 16, 1, self.ctx.stream()), "sum3")
+        self._bce(rx_ptr, cnt, 1.0, 5, 0.5, False, 0.5, dx.dlogits_ptr(0))                # disc_x_loss :246
+        self._bce(fxl_ptr, cnt, 0.0, 5, 0.5, True, 0.5, dx.dlogits_ptr(1))
+        self._bce(ry_ptr, cnt, 1.0, 6, 0.5, False, 0.5, dy.dlogits_ptr(0))                # disc_y_loss :247
+        self._bce(fyl_ptr, cnt, 0.0, 6, 0.5, True, 0.5, dy.dlogits_ptr(1))
+        if training:
+            cx.backward(need_dx=True, accumulate=False)               # G_f grads (cycle_x), d/d fake_y
+            cy.backward(need_dx=True, accumulate=False)               # G_g grads (cycle_y), d/d fake_x
+            dy.backward_input(1)                                      # adversarial term through D_y(fake_y)
+            self._copy(dy.dxin.view(0, Cc), fy.dgen_view()); self._copy(cx.dxin.view(0, Cc), fy.dgen_view(second=True))
+            dx.backward_input(1)
+            self._copy(dx.dxin.view(0, Cc), fx.dgen_view()); self._copy(cy.dxin.view(0, Cc), fx.dgen_view(second=True))
+            # second upstream slot of the identity halves stays zero (never written); one backward per generator covers the
+            # adversarial + cycle gradient of fake_* and the identity gradient of same_*
+            gA.backward(use_dgen2=True, accumulate=True)              # G_g
+            gB.backward(use_dgen2=True, accumulate=True)              # G_f
+            if phase != 1:
+                dx.backward_params(); dy.backward_params()
+        return self.losses
 
     def train_step(self, real_x, real_y, training=True):
         """7 losses in the reference's order (cycle_gan.py:275-276)."""
