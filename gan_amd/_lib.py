@@ -35,11 +35,17 @@ class _Desc(C.Structure):
         super().__init__(C.sizeof(type(self)), *args, **kw)
 
 
+class GanBwdFuse(C.Structure):
+    _fields_ = [("ref", GanTensor), ("add", GanTensor), ("mean", C.c_void_p), ("rstd", C.c_void_p), ("gamma", C.c_void_p),
+                ("beta", C.c_void_p), ("dropmask", C.c_void_p), ("mask_pitch", C.c_int32), ("act", C.c_int32), ("slope", C.c_float),
+                ("cols", C.c_int32)]
+
+
 class GanConvDesc(_Desc):
     _fields_ = [("struct_size", C.c_uint32), ("dtype", C.c_int32), ("stride", C.c_int32), ("x", GanTensor), ("y", GanTensor), ("w", C.c_void_p),
                 ("w_rows", C.c_int32), ("bias", C.c_void_p), ("act", C.c_int32), ("slope", C.c_float),
                 ("y_f32", C.c_int32), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
-                ("stats_partial", C.c_void_p), ("stats_groups", C.c_int32)]
+                ("stats_partial", C.c_void_p), ("stats_groups", C.c_int32), ("bwd_fuse", C.c_void_p)]
 
 
 class GanWgradDesc(_Desc):
@@ -90,6 +96,7 @@ SYMBOLS = {
     "gan_norm_act_fwd": (C.c_int, [C.POINTER(GanNormDesc), C.c_void_p]),
     "gan_norm_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int64]),
     "gan_norm_act_bwd": (C.c_int, [C.POINTER(GanNormBwdDesc), C.c_void_p]),
+    "gan_norm_act_bwd_fused": (C.c_int, [C.POINTER(GanNormBwdDesc), C.c_int32, C.c_void_p]),
     "gan_act_bwd": (C.c_int, [C.POINTER(GanActBwdDesc), C.c_void_p]),
     "gan_bce_logits": (C.c_int, [C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_int32, C.c_void_p, C.c_float,
                                  C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -67,12 +67,57 @@ __device__ __forceinline__ void store_out(const GemmParams& p, size_t pix_off, i
   else st_f((T*)p.y + pix_off + n, v);
 }
 
-__device__ __forceinline__ size_t out_pixel_offset(const GemmParams& p, int m, int py, int px) {
+__device__ __forceinline__ size_t out_pixel_index(const GemmParams& p, int m, int py, int px) {
   const unsigned t = fdiv((unsigned)m, p.divWg);
   const int gx = m - t * p.Wg;
   const unsigned img = fdiv(t, p.divHg);
   const int gy = t - img * p.Hg;
-  return ((size_t)(img * p.Ho + gy * p.OS + py) * p.Wo + (gx * p.OS + px)) * (size_t)p.ypitch;
+  return (size_t)(img * p.Ho + gy * p.OS + py) * p.Wo + (gx * p.OS + px);
+}
+__device__ __forceinline__ size_t out_pixel_offset(const GemmParams& p, int m, int py, int px) {
+  return out_pixel_index(p, m, py, px) * (size_t)p.ypitch;
+}
+
+// Fused backward epilogue (GanBwdFuse): bf_mode = 1 norm+LeakyReLU, 2 norm+ReLU, 3 norm+ReLU+dropout mask, 4 LeakyReLU on the
+// saved activation.  One 16-byte channel vector: g = da (+ add) in, dz out; s1 += dz, s2 += dz*xhat (norm modes).
+// The arithmetic is reduce_partial_kernel's (norm.hip), so that fused and unfused paths agree to rounding of dz.
+template <typename T, int MODE, int VEC>
+__device__ __forceinline__ uint4 bwd_fuse_vec(const GemmParams& p, uint4 raw, const uint4& refv, const uint4& addv, const uint2& maskv,
+                                              const float* mu, const float* rs, const float* ga, const float* be, float* s1, float* s2) {
+  float g[VEC], rf[VEC];
+  unpack16<T>(raw, g);
+  if (p.bf_add) {
+    float a2[VEC];
+    unpack16<T>(addv, a2);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) g[e] += a2[e];
+  }
+  unpack16<T>(refv, rf);
+  if constexpr (MODE == 4) {
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) g[e] = rf[e] > 0.f ? g[e] : g[e] * p.bf_slope;
+  } else {
+    float mk[VEC];
+    if constexpr (MODE == 3) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        mk[e] = 2.f * (float)((maskv.x >> (8 * e)) & 0xff);
+        if constexpr (VEC == 8) mk[4 + e] = 2.f * (float)((maskv.y >> (8 * e)) & 0xff);
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const float xh = (rf[e] - mu[e]) * rs[e];
+      const float z = fmaf(ga[e], xh, be[e]);
+      const float zd = MODE == 3 ? z * mk[e] : z;
+      float d = MODE == 3 ? g[e] * mk[e] : g[e];
+      if (MODE == 1) d = zd > 0.f ? d : d * p.bf_slope;
+      else d = zd > 0.f ? d : 0.f;
+      s1[e] += d; s2[e] = fmaf(d, xh, s2[e]);
+      g[e] = d;
+    }
+  }
+  return pack16<T>(g);
 }
 
 __device__ __forceinline__ void glds16(const void* gsrc, unsigned char* lds_wave_base) {
@@ -130,9 +175,19 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
     // a thread sums one 16-byte column group (VEC channels) over a slice of the staged rows
     constexpr int CG = BN / VEC, SL = NTHREADS / CG;          // column groups; row slices (NTHREADS >= BN)
     const int scg = tid % CG, sslice = tid / CG;
+    static_assert(NTHREADS % VPR == 0 && CG == VPR, "a thread keeps one column group in the store loop");
     float ssum[VEC], ssq[VEC];
 #pragma unroll
     for (int e = 0; e < VEC; ++e) ssum[e] = ssq[e] = 0.f;
+    float cmu[VEC], crs[VEC], cga[VEC], cbe[VEC];              // fused backward epilogue: this thread's per-channel constants
+    if (p.bf_mode >= 1 && p.bf_mode <= 3 && bn0 + scg * VEC < p.bf_cols) {
+      const int grp = p.stats_tpg ? (bm0 / BM) / p.stats_tpg : 0, c0 = bn0 + scg * VEC;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        cmu[e] = p.bf_mean[grp * p.bf_cols + c0 + e]; crs[e] = p.bf_rstd[grp * p.bf_cols + c0 + e];
+        cga[e] = p.bf_gamma[c0 + e]; cbe[e] = p.bf_beta[c0 + e];
+      }
+    }
 #pragma unroll
     for (int ip = 0; ip < MT / IPP; ++ip) {
       if (ip) __syncthreads();
@@ -157,14 +212,75 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
       else if (p.act == GAN_ACT_RELU) stage(std::integral_constant<int, GAN_ACT_RELU>{});
       else stage(std::integral_constant<int, GAN_ACT_TANH>{});
       __syncthreads();
-      for (int idx = tid; idx < WAVES_M * IPP * 16 * VPR; idx += NTHREADS) {
-        const int sr = idx / VPR, v = idx % VPR;
-        const int g16 = sr >> 4;
-        const int m = bm0 + (g16 / IPP) * WTM + (ip * IPP + g16 % IPP) * 16 + (sr & 15), n = bn0 + v * VEC;
-        if (m < p.M && n < p.Cout)
-          *(uint4*)((T*)p.y + out_pixel_offset(p, m, py, px) + n) = *(const uint4*)(Cs + sr * CS + v * 16);
+      auto store_rows = [&](auto modec) {
+        constexpr int MODE = decltype(modec)::value;
+        constexpr int TOTAL = WAVES_M * IPP * 16 * VPR;
+        if constexpr (MODE == 0 || TOTAL % NTHREADS != 0) {
+          for (int idx = tid; idx < TOTAL; idx += NTHREADS) {
+            const int sr = idx / VPR, v = idx % VPR;             // v == scg for every idx of a thread (NTHREADS % VPR == 0)
+            const int g16 = sr >> 4;
+            const int m = bm0 + (g16 / IPP) * WTM + (ip * IPP + g16 % IPP) * 16 + (sr & 15), n = bn0 + v * VEC;
+            if (m < p.M && n < p.Cout) {
+              uint4 raw = *(const uint4*)(Cs + sr * CS + v * 16);
+              const size_t pix = out_pixel_index(p, m, py, px);
+              if constexpr (MODE != 0) {
+                if (n < p.bf_cols) {
+                  const uint4 rv = *(const uint4*)((const T*)p.bf_ref + pix * (size_t)p.bf_refpitch + n);
+                  uint4 av = make_uint4(0, 0, 0, 0); uint2 mv = make_uint2(0, 0);
+                  if (p.bf_add) av = *(const uint4*)((const T*)p.bf_add + pix * (size_t)p.bf_addpitch + n);
+                  if constexpr (MODE == 3) {
+                    if constexpr (VEC == 8) mv = *(const uint2*)(p.bf_mask + pix * (size_t)p.bf_maskpitch + n);
+                    else mv.x = *(const uint32_t*)(p.bf_mask + pix * (size_t)p.bf_maskpitch + n);
+                  }
+                  raw = bwd_fuse_vec<T, MODE, VEC>(p, raw, rv, av, mv, cmu, crs, cga, cbe, ssum, ssq);
+                }
+              }
+              *(uint4*)((T*)p.y + pix * (size_t)p.ypitch + n) = raw;
+            }
+          }
+        } else {
+          // fused backward epilogue: the reference / skip / mask vectors of U rows are requested together before any of them
+          // is used (one dependent global load per iteration made this loop pure latency: +9..+40 us per launch)
+          constexpr int ITERS = TOTAL / NTHREADS, U = ITERS % 4 == 0 ? 4 : (ITERS % 2 == 0 ? 2 : 1);
+          const int n = bn0 + scg * VEC;
+          const bool colok = n < p.Cout, fuse = n < p.bf_cols;
+          for (int it0 = 0; it0 < ITERS; it0 += U) {
+            uint4 rv[U], av[U]; uint2 mv[U]; size_t pix[U]; bool ok[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+              const int sr = (tid + (it0 + u) * NTHREADS) / VPR, g16 = sr >> 4;
+              const int m = bm0 + (g16 / IPP) * WTM + (ip * IPP + g16 % IPP) * 16 + (sr & 15);
+              ok[u] = m < p.M && colok;
+              pix[u] = ok[u] ? out_pixel_index(p, m, py, px) : 0;
+              rv[u] = av[u] = make_uint4(0, 0, 0, 0); mv[u] = make_uint2(0, 0);
+              if (ok[u] && fuse) {
+                rv[u] = *(const uint4*)((const T*)p.bf_ref + pix[u] * (size_t)p.bf_refpitch + n);
+                if (p.bf_add) av[u] = *(const uint4*)((const T*)p.bf_add + pix[u] * (size_t)p.bf_addpitch + n);
+                if constexpr (MODE == 3) {
+                  if constexpr (VEC == 8) mv[u] = *(const uint2*)(p.bf_mask + pix[u] * (size_t)p.bf_maskpitch + n);
+                  else mv[u].x = *(const uint32_t*)(p.bf_mask + pix[u] * (size_t)p.bf_maskpitch + n);
+                }
+              }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+              if (!ok[u]) continue;
+              const int sr = (tid + (it0 + u) * NTHREADS) / VPR;
+              uint4 raw = *(const uint4*)(Cs + sr * CS + scg * 16);
+              if (fuse) raw = bwd_fuse_vec<T, MODE, VEC>(p, raw, rv[u], av[u], mv[u], cmu, crs, cga, cbe, ssum, ssq);
+              *(uint4*)((T*)p.y + pix[u] * (size_t)p.ypitch + n) = raw;
+            }
+          }
+        }
+      };
+      switch (p.bf_mode) {
+        case 1: store_rows(std::integral_constant<int, 1>{}); break;
+        case 2: store_rows(std::integral_constant<int, 2>{}); break;
+        case 3: store_rows(std::integral_constant<int, 3>{}); break;
+        case 4: store_rows(std::integral_constant<int, 4>{}); break;
+        default: store_rows(std::integral_constant<int, 0>{}); break;
       }
-      if (p.stats) {
+      if (p.stats && !p.bf_mode) {
         for (int sr = sslice; sr < WAVES_M * IPP * 16; sr += SL) {
           const int g16 = sr >> 4;
           const int m = bm0 + (g16 / IPP) * WTM + (ip * IPP + g16 % IPP) * 16 + (sr & 15);
@@ -185,7 +301,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
         red[(sslice * BN + scg * VEC + e) * 2] = ssum[e]; red[(sslice * BN + scg * VEC + e) * 2 + 1] = ssq[e];
       }
       __syncthreads();
-      if (tid < BN && bn0 + tid < p.Cout) {
+      if (tid < BN && bn0 + tid < p.stats_C) {
         float a = 0.f, b = 0.f;
 #pragma unroll
         for (int k = 0; k < SL; ++k) { a += red[(k * BN + tid) * 2]; b += red[(k * BN + tid) * 2 + 1]; }
@@ -680,18 +796,62 @@ __global__ __launch_bounds__(256) void splitk_reduce4_kernel(const GemmParams p,
   float v[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) v[e] = apply_act(s[e] + (p.bias ? p.bias[n + e] : 0.f), p.act, p.slope);
-  const size_t o = out_pixel_offset(p, m, par >> 1, par & 1) + n;
+  const size_t pix = out_pixel_index(p, m, par >> 1, par & 1);
+  const size_t o = pix * (size_t)p.ypitch + n;
+  float sx[4] = {0.f, 0.f, 0.f, 0.f};       // fused backward epilogue: dz * xhat
+  const bool bf = p.bf_mode && n < p.bf_cols;
+  if (bf) {                                  // GanBwdFuse on 4 channels of one pixel (same arithmetic as bwd_fuse_vec)
+    auto ld4 = [](const void* base, size_t off, float* out) {
+      if constexpr (sizeof(T) == 4) { const f32x4 q = *(const f32x4*)((const float*)base + off); out[0] = q[0]; out[1] = q[1]; out[2] = q[2]; out[3] = q[3]; }
+      else { float t8[8]; const uint2 q = *(const uint2*)((const T*)base + off); unpack16<T>(make_uint4(q.x, q.y, 0u, 0u), t8); out[0] = t8[0]; out[1] = t8[1]; out[2] = t8[2]; out[3] = t8[3]; }
+    };
+    float rf[4], a2[4];
+    if (!p.out_f32) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = (float)(T)v[e];     // da as the unfused path would have stored and re-read it
+    }
+    if (p.bf_add) {
+      ld4(p.bf_add, pix * (size_t)p.bf_addpitch + n, a2);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] += a2[e];
+    }
+    ld4(p.bf_ref, pix * (size_t)p.bf_refpitch + n, rf);
+    if (p.bf_mode == 4) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = rf[e] > 0.f ? v[e] : v[e] * p.bf_slope;
+    } else {
+      const int RBq = 256 / c4, grp = (m / RBq) / p.stats_tpg;
+      float mk[4] = {1.f, 1.f, 1.f, 1.f};
+      if (p.bf_mode == 3) {
+        const uint32_t w = *(const uint32_t*)(p.bf_mask + pix * (size_t)p.bf_maskpitch + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) mk[e] = 2.f * (float)((w >> (8 * e)) & 0xff);
+      }
+      const f32x4 mu = *(const f32x4*)(p.bf_mean + grp * p.bf_cols + n), rs = *(const f32x4*)(p.bf_rstd + grp * p.bf_cols + n);
+      const f32x4 ga = *(const f32x4*)(p.bf_gamma + n), be = *(const f32x4*)(p.bf_beta + n);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float xh = (rf[e] - mu[e]) * rs[e];
+        const float z = fmaf(ga[e], xh, be[e]);
+        const float zd = z * mk[e];
+        float d = v[e] * mk[e];
+        d = zd > 0.f ? d : (p.bf_mode == 1 ? d * p.bf_slope : 0.f);
+        v[e] = d; sx[e] = d * xh;
+      }
+    }
+  }
   if (p.out_f32) *(f32x4*)((float*)p.y + o) = f32x4{v[0], v[1], v[2], v[3]};
   else *(uint2*)((T*)p.y + o) = make_uint2(pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]));
   if (p.stats) {
     // fused normalisation statistics of a split-K layer: a block covers RB = 256 / c4 whole rows of one parity and
     // one statistics group (the planner guarantees it); per-channel (sum, sum^2) of the STORED values over those
     // rows = one chunk, laid out like the tile partials of the unsplit epilogue: [group][chunk][C][2]
+    // (fused backward epilogue: (sum dz, sum dz*xhat) of the channels < bf_cols instead)
     __shared__ float red[256][8];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const float w = p.out_f32 ? v[e] : (float)(T)v[e];                  // as stored (bf16-rounded on the fast path)
-      red[threadIdx.x][2 * e] = w; red[threadIdx.x][2 * e + 1] = w * w;
+      red[threadIdx.x][2 * e] = p.bf_mode ? v[e] : w; red[threadIdx.x][2 * e + 1] = p.bf_mode ? sx[e] : w * w;
     }
     __syncthreads();
     const int RB = 256 / c4;
@@ -706,8 +866,10 @@ __global__ __launch_bounds__(256) void splitk_reduce4_kernel(const GemmParams p,
       const int rpb = p.stats_tpg;                             // row blocks per group (per parity)
       const int grp = mb / rpb, chunk = (mb % rpb) * P + par;
       float* dst = p.stats + (((size_t)grp * rpb * P + chunk) * p.stats_C + n) * 2;
+      if (n < p.stats_C) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) dst[e] = acc8[e];
+        for (int e = 0; e < 8; ++e) dst[e] = acc8[e];
+      }
     }
   }
 }
@@ -732,6 +894,7 @@ struct GemmPlan {
   GemmParams p;
   int BM, BN, P, stats_chunks;
   bool pp;                 // 256-row tile on the ping-pong kernel
+  bool bf_requested;       // the caller asked for a fused backward epilogue (carried iff p.bf_mode != 0)
   dim3 grid;
   size_t slab_bytes;
 };
@@ -819,22 +982,66 @@ static int plan_gemm(const GanConvDesc* d, int op, GemmPlan* pl) {
   p.splits = splits;
   p.stats = nullptr; p.stats_tpg = 0; p.stats_C = y.c;
   pl->stats_chunks = 0;
-  if (d->stats_groups > 0 && splits == 1 && p.vec_store && BN <= 64 * 8 && x.n % d->stats_groups == 0) {
+  // fused backward epilogue request (GanBwdFuse): validated here, honoured below if this launch shape can carry it
+  const GanBwdFuse* bf = d->bwd_fuse;
+  int bf_mode = 0;
+  p.bf_ref = p.bf_add = nullptr; p.bf_mean = p.bf_rstd = p.bf_gamma = p.bf_beta = nullptr; p.bf_mask = nullptr;
+  p.bf_refpitch = p.bf_addpitch = p.bf_maskpitch = p.bf_mode = p.bf_cols = 0; p.bf_slope = 0.f;
+  pl->bf_requested = bf != nullptr;
+  if (bf) {
+    if ((op != 1 && op != 3) || !bf->ref.ptr || bf->cols <= 0 || bf->cols % 8 || bf->cols > y.c || d->bias || d->act != GAN_ACT_NONE || d->y_f32)
+      return GAN_E_ARG;
+    if (bf->ref.n != y.n || bf->ref.h != y.h || bf->ref.w != y.w || bf->ref.c < bf->cols || bf->ref.pitch % vec ||
+        ((uintptr_t)bf->ref.ptr & 15))
+      return GAN_E_SHAPE;
+    if (bf->add.ptr && (bf->add.n != y.n || bf->add.h != y.h || bf->add.w != y.w || bf->add.c < bf->cols || bf->add.pitch % vec ||
+                        ((uintptr_t)bf->add.ptr & 15)))
+      return GAN_E_SHAPE;
+    if (bf->mean) {
+      if (!bf->rstd || !bf->gamma || !bf->beta || d->stats_groups <= 0 || !d->stats_partial) return GAN_E_ARG;
+      if (bf->dropmask && (bf->mask_pitch % 8 || bf->mask_pitch < bf->cols || ((uintptr_t)bf->dropmask & 7))) return GAN_E_SHAPE;
+      bf_mode = bf->act == GAN_ACT_LRELU && !bf->dropmask ? 1 : bf->act == GAN_ACT_RELU ? (bf->dropmask ? 3 : 2) : 0;
+    } else {
+      bf_mode = bf->act == GAN_ACT_LRELU && !bf->dropmask ? 4 : 0;
+    }
+    if (!bf_mode) return GAN_E_ARG;
+    p.stats_C = bf_mode == 4 ? y.c : bf->cols;
+  }
+  const bool reduce4_ok = p.vec_store && y.c % 4 == 0 && (p.out_f32 || d->dtype != GAN_F32);
+  const bool want_stats = d->stats_groups > 0 && bf_mode != 4;
+  if (want_stats && splits == 1 && p.vec_store && BN <= 64 * 8 && x.n % d->stats_groups == 0) {
     const long long rpg = M / d->stats_groups;            // GEMM rows per statistics group (per parity)
     if (rpg % BM == 0 && (BM == 256 ? 512 : 256) >= BN) {
       p.stats_tpg = (int)(rpg / BM);
       pl->stats_chunks = p.stats_tpg * P;
       p.stats = d->stats_partial;
     }
-  } else if (d->stats_groups > 0 && splits > 1 && p.vec_store && x.n % d->stats_groups == 0) {
+  } else if (want_stats && splits > 1 && reduce4_ok && x.n % d->stats_groups == 0) {
     // split-K layer: the slab-reduce kernel emits the partials (one chunk per 256-thread block = RB whole rows)
     const int c4 = y.c / 4;
     const long long rpg = M / d->stats_groups;
-    if (y.c % 4 == 0 && c4 <= 256 && 256 % c4 == 0 && rpg % (256 / c4) == 0 &&
+    if (c4 <= 256 && 256 % c4 == 0 && rpg % (256 / c4) == 0 &&
         rpg / (256 / c4) * P <= 1024) {        // beyond ~1k chunks the finalize's walk costs more than a separate pass
       p.stats_tpg = (int)(rpg / (256 / c4));
       pl->stats_chunks = p.stats_tpg * P;
       p.stats = d->stats_partial;
+    }
+  }
+  if (bf_mode) {
+    // the slab-reduce kernel of a split-K launch carries it at no cost (streaming kernel, the slabs are read anyway); a tile
+    // epilogue re-reads the reference tensor at the tile's strided pixel order (break-even per launch, +0.8 % on the captured step): GAN_AMD_BF_TILE = 0 never, 1 always, 2 not
+    // on the 64-column tiles
+    static const int bf_tile = tune("BF_TILE", 1);
+    const bool carrier = p.vec_store && (splits == 1 ? (bf_tile == 1 || (bf_tile == 2 && BN != 64)) : reduce4_ok);
+    if (carrier && (bf_mode == 4 || p.stats)) {
+      p.bf_mode = bf_mode; p.bf_cols = bf->cols; p.bf_slope = bf->slope;
+      p.bf_ref = bf->ref.ptr; p.bf_refpitch = bf->ref.pitch;
+      p.bf_add = bf->add.ptr; p.bf_addpitch = bf->add.pitch;
+      p.bf_mean = bf->mean; p.bf_rstd = bf->rstd; p.bf_gamma = bf->gamma; p.bf_beta = bf->beta;
+      p.bf_mask = bf->dropmask; p.bf_maskpitch = bf->mask_pitch;
+      if (bf_mode == 4) pl->stats_chunks = 1;          // plan_info()[4] > 0 = "the epilogue is fused"
+    } else {
+      p.stats = nullptr; p.stats_tpg = 0; pl->stats_chunks = 0; p.stats_C = y.c;
     }
   }
   p.NslabPitch = tilesN * BN;
@@ -921,7 +1128,9 @@ static int run_gemm(const GanConvDesc* d, int op, gan_stream_t stream) {
   int rc = plan_gemm(d, op, &pl);
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
-  if (const int fam = thin_family(d, op, pl.p)) return thin_launch(fam, d, pl.p, st);   // <= 8-channel streaming layers
+  const int fam = thin_family(d, op, pl.p);
+  if (pl.bf_requested && (fam || !pl.p.bf_mode)) return GAN_E_SHAPE;   // the caller must consult gan_conv_plan_info()[4] first
+  if (fam) return thin_launch(fam, d, pl.p, st);   // <= 8-channel streaming layers
   if (pl.slab_bytes > d->workspace_bytes || (pl.slab_bytes && !d->workspace)) return GAN_E_WORKSPACE;
   return d->dtype == GAN_F32 ? launch_gemm<float>(pl, st) : d->dtype == GAN_F16 ? launch_gemm<f16_t>(pl, st) : launch_gemm<bf16_t>(pl, st);
 }

@@ -17,6 +17,12 @@ struct GemmParams {
   unsigned xbytes, wbytes;   // extents for the buffer descriptors (out-of-range offsets read zeros)
   float* stats; int stats_tpg, stats_C;   // fused per-channel (sum, sum^2) partials: tiles per group, channel count
   FastDiv divWg, divHg;      // GEMM-grid width / height (row -> (image, gy, gx) decode)
+  // fused backward epilogue of a dgrad launch (GanBwdFuse, include/gan_amd.h): the stored value becomes
+  // dz = (da + add) * act'(.) [* 2*dropmask] for channels < bf_cols; with bf_mean the (sum dz, sum dz*xhat) partials go to `stats`
+  const void* bf_ref; const void* bf_add;
+  const float* bf_mean; const float* bf_rstd; const float* bf_gamma; const float* bf_beta;
+  const unsigned char* bf_mask;
+  int bf_refpitch, bf_addpitch, bf_maskpitch, bf_mode, bf_cols; float bf_slope;
 #ifdef GAN_DIAG
   unsigned long long* diag;  // diagnostic build: per-block stamps
 #endif

@@ -521,6 +521,35 @@ int gan_norm_act_bwd(const GanNormBwdDesc* d, gan_stream_t stream) {
   return d->dtype == GAN_F32 ? launch_bwd_apply<float>(p, g, rows, st) : d->dtype == GAN_F16 ? launch_bwd_apply<f16_t>(p, g, rows, st) : launch_bwd_apply<bf16_t>(p, g, rows, st);
 }
 
+/* Second half of a normalisation backward whose first half ran in the producing dgrad's epilogue (GanBwdFuse): d->da holds
+ * dz, d->workspace the producer's partial sums [groups][chunks][C][2] followed by room for the finalized [groups][C][2]. */
+int gan_norm_act_bwd_fused(const GanNormBwdDesc* d, int32_t chunks, gan_stream_t stream) {
+  if (!d || d->struct_size != sizeof(GanNormBwdDesc) || !d->y.ptr || !d->da.ptr || !d->dy.ptr || !d->mean || !d->rstd || !d->gamma ||
+      !d->beta || !d->workspace || chunks <= 0 || d->da2.ptr)
+    return GAN_E_ARG;
+  RedGeom g;
+  int rc = red_geom(d->y, d->groups, d->dtype, &g);
+  if (rc) return rc;
+  if (d->da.pitch % 8 || d->dy.pitch % 8) return GAN_E_SHAPE;
+  if (red_ws_bytes(d->groups, chunks, g.C) > d->workspace_bytes) return GAN_E_WORKSPACE;
+  NormP p = {};
+  p.y = d->y.ptr; p.ypitch = d->y.pitch; p.da = d->da.ptr; p.dapitch = d->da.pitch;
+  p.out = d->dy.ptr; p.outpitch = d->dy.pitch;
+  p.gamma = d->gamma; p.beta = d->beta; p.mean = d->mean; p.rstd = d->rstd;
+  p.act = GAN_ACT_NONE; p.slope = d->slope; p.has_norm = 1;        // dz already carries activation derivative and mask
+  float* partial = (float*)d->workspace;
+  float* sums = partial + (size_t)d->groups * chunks * g.C * 2;
+  p.sums = sums;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(bwd_finalize_kernel, dim3((g.C + FC - 1) / FC), dim3(256), 0, st, (const float*)partial, d->groups,
+                     chunks, g.C, sums, d->dgamma, d->dbeta, d->accumulate);
+  GAN_CHECK_LAUNCH();
+  long long rows = (long long)d->y.n * g.hw;
+  return d->dtype == GAN_F32 ? launch_rows(norm_act_bwd_kernel<float, GAN_ACT_NONE, false>, p, g, rows, st)
+       : d->dtype == GAN_F16 ? launch_rows(norm_act_bwd_kernel<f16_t, GAN_ACT_NONE, false>, p, g, rows, st)
+                             : launch_rows(norm_act_bwd_kernel<bf16_t, GAN_ACT_NONE, false>, p, g, rows, st);
+}
+
 static int bias_grad_impl(int32_t dtype, const GanTensor& dy, float* dbias, int32_t accumulate, void* workspace,
                           size_t workspace_bytes, hipStream_t st) {
   RedGeom g;

@@ -25,6 +25,7 @@ LEAKY_ALPHA = 0.3                                    # Keras LeakyReLU() default
 BN_EPS, IN_EPS, BN_MOMENTUM = 1e-3, 1e-5, 0.99       # Keras BatchNormalization defaults; utils.py:9
 
 
+FUSE_BWD = os.environ.get('GAN_AMD_FUSE_BWD', '1') == '1'    # dgrad epilogues start the backward of the layer below
 STATS_RESERVE = 8 << 20      # room kept behind a conv's split-K slabs for its fused statistics partials
 
 
@@ -347,11 +348,30 @@ class _Builder:
         self.keep.append(d)
         return C.byref(d)
 
-    def conv(self, op, x, y, w, w_rows, stride=2, bias=None, act=None, y_f32=0, k_real=None, stats_groups=0):
+    def fuse_spec(self, ref, add=None, name=None, groups=0, mean_ptr=None, rstd_ptr=None, act='lrelu', mask_ptr=None, mask_pitch=0,
+                  cols=None):
+        """Description of the layer-below backward a dgrad launch should start in its epilogue (GanBwdFuse): `name` = its
+        normalisation layer (None: activation only, `ref` = saved activation)."""
+        z = L.GanTensor(None, 0, 0, 0, 0, 0)
+        gk, bk = self.norm_names()
+        f = L.GanBwdFuse(ref, add if add is not None else z, mean_ptr, rstd_ptr,
+                         self.P.ptr(name + gk) if name else None, self.P.ptr(name + bk) if name else None,
+                         mask_ptr, mask_pitch, L.ACTS[act], LEAKY_ALPHA, cols if cols is not None else ref.c)
+        return (f, groups if name else 0)
+
+    def conv(self, op, x, y, w, w_rows, stride=2, bias=None, act=None, y_f32=0, k_real=None, stats_groups=0, bwd_fuse=None):
         """stats_groups > 0: ask the GEMM epilogue to also emit normalisation-statistics partials; the number of
-        chunks it will write (0 = not fusable for this shape) is left in self.last_stats_chunks."""
+        chunks it will write (0 = not fusable for this shape) is left in self.last_stats_chunks.
+        bwd_fuse = fuse_spec(...): ask a dgrad launch to start the backward of the layer below in its epilogue;
+        self.last_bwd_fused > 0 (the chunk count for gan_norm_act_bwd_fused) if this launch shape carries it."""
+        if bwd_fuse is not None and not FUSE_BWD:
+            bwd_fuse = None
+        if bwd_fuse is not None:
+            self.keep.append(bwd_fuse[0])
+            stats_groups = bwd_fuse[1]
         d = L.GanConvDesc(self.ctx.dt, stride, x, y, w, w_rows, bias, L.ACTS[act], LEAKY_ALPHA, y_f32,
-                          self.ws_ptr, self.ws_bytes, self.ws_ptr if stats_groups else None, stats_groups)
+                          self.ws_ptr, self.ws_bytes, self.ws_ptr if stats_groups else None, stats_groups,
+                          C.addressof(bwd_fuse[0]) if bwd_fuse is not None else None)
         opi = {'conv_fwd': 0, 'conv_dgrad': 1, 'convT_fwd': 2, 'convT_dgrad': 3}[op]
         fn = [self.lib.gan_conv2d_fwd, self.lib.gan_conv2d_dgrad, self.lib.gan_convT2d_fwd, self.lib.gan_convT2d_dgrad][opi]
         need = self.lib.gan_conv_workspace_bytes(C.byref(d), opi)
@@ -363,9 +383,17 @@ class _Builder:
             d.stats_partial = self.last_stats_ptr
         info = (C.c_int32 * 5)()
         self.lib.gan_conv_plan_info(C.byref(d), opi, info)
-        self.last_stats_chunks = info[4] if (stats_groups and not os.environ.get('GAN_AMD_NO_FUSED_STATS')) else 0
-        if stats_groups and not self.last_stats_chunks:
-            d.stats_partial, d.stats_groups = None, 0
+        self.last_bwd_fused = 0
+        if bwd_fuse is not None:
+            self.last_stats_chunks = 0
+            self.last_bwd_fused = info[4]
+            if not info[4]:            # this launch shape (thin kernel, odd group size ...) cannot carry it: plain dgrad
+                d.bwd_fuse = None
+                d.stats_partial, d.stats_groups = None, 0
+        else:
+            self.last_stats_chunks = info[4] if (stats_groups and not os.environ.get('GAN_AMD_NO_FUSED_STATS')) else 0
+            if stats_groups and not self.last_stats_chunks:
+                d.stats_partial, d.stats_groups = None, 0
         T = 4 if info[3] == 4 else 16
         # algorithmic FLOPs, SURVEY.md 8(d) convention: real channel counts, border taps not discounted
         creal = k_real or x.c
@@ -422,6 +450,17 @@ class _Builder:
                              self.P.ptr(name + bk, 'grad') if want_param_grads else None,
                              int(accumulate), self.ws_ptr, self.ws_bytes)
         return (self.lib.gan_norm_act_bwd, (self._desc(d),), f"norm_act_bwd({name})")
+
+    def norm_bwd_fused(self, name, y, dz, dy, groups, mean_ptr, rstd_ptr, chunks, partial_ptr, want_param_grads, accumulate):
+        """Second half (finalize + apply) of a layer backward whose first half ran in the producing dgrad's epilogue."""
+        gk, bk = self.norm_names()
+        z = L.GanTensor(None, 0, 0, 0, 0, 0)
+        d = L.GanNormBwdDesc(self.ctx.dt, y, dz, z, dy, groups, self.P.ptr(name + gk), self.P.ptr(name + bk), mean_ptr, rstd_ptr, None,
+                             L.ACTS[None], LEAKY_ALPHA,
+                             self.P.ptr(name + gk, 'grad') if want_param_grads else None,
+                             self.P.ptr(name + bk, 'grad') if want_param_grads else None,
+                             int(accumulate), partial_ptr, self.ws_bytes - (partial_ptr - self.ws_ptr))
+        return (self.lib.gan_norm_act_bwd_fused, (self._desc(d), chunks), f"norm_act_bwd_fused({name})")
 
     def act_bwd(self, a, da, da2, dy, act):
         z = L.GanTensor(None, 0, 0, 0, 0, 0)
@@ -537,24 +576,47 @@ class GenCall:
         self._bwd_cache = {}
 
     def _build_bwd(self, use_dgen2, need_dx, accumulate):
+        """Backward op list.  Wherever the launch shape allows it, the dgrad that produces the gradient w.r.t. a layer's
+        activation starts that layer's backward in its epilogue (dz + partial sums; `fused` = chunk count) and the layer is
+        finished by finalize + apply; otherwise the three-launch normalisation backward / act_bwd follows."""
         bd, P, C_, groups = self._bd, self.net.params, self.C, self.groups
         ops = []
         ops.append(bd.act_bwd(self.out.view(), self.dgen.view(), self.dgen2.view() if use_dgen2 else None,
                               self.dpre.view(), 'tanh'))
         ops.append(bd.wgrad(self.dpre.view(), self.cat[6].view(), P.ptr('last.kernel', 'grad'), C_, 128, 2, accumulate))
         ops.append(bd.bias_grad(self.dpre.view(), P.ptr('last.bias', 'grad'), accumulate))
-        ops.append(bd.conv('convT_dgrad', self.dpre.view(), self.dcat[6].view(), P.tr['last.kernel'].data_ptr(), 128, 2, k_real=C_))
+
+        def up_spec(j):         # backward of up j (ReLU [+ dropout] after the norm) on the leading G_UP[j] channels of dcat[j]
+            mean, rstd = self.stats[f'up{j}']
+            mptr = self.masks[j].data_ptr() if (self.masks is not None and j < 3) else None
+            return bd.fuse_spec(self.y_up[j].view(), None, f'up{j}', groups, mean.data_ptr(), rstd.data_ptr(), 'relu', mptr, 512,
+                                cols=G_UP[j])
+
+        ops.append(bd.conv('convT_dgrad', self.dpre.view(), self.dcat[6].view(), P.tr['last.kernel'].data_ptr(), 128, 2, k_real=C_,
+                           bwd_fuse=up_spec(6)))
+        fused, fptr = bd.last_bwd_fused, bd.last_stats_ptr
         for j in range(6, -1, -1):
             name = f'up{j}'
             mean, rstd = self.stats[name]
             mptr = self.masks[j].data_ptr() if (self.masks is not None and j < 3) else None
-            ops.append(bd.norm_bwd(name, self.y_up[j].view(), self.dcat[j].view(0, G_UP[j]), None, self.dy_up[j].view(),
-                                   groups, mean.data_ptr(), rstd.data_ptr(), 'relu', mptr, True, accumulate))
+            if fused:
+                ops.append(bd.norm_bwd_fused(name, self.y_up[j].view(), self.dcat[j].view(0, G_UP[j]), self.dy_up[j].view(), groups,
+                                             mean.data_ptr(), rstd.data_ptr(), fused, fptr, True, accumulate))
+            else:
+                ops.append(bd.norm_bwd(name, self.y_up[j].view(), self.dcat[j].view(0, G_UP[j]), None, self.dy_up[j].view(),
+                                       groups, mean.data_ptr(), rstd.data_ptr(), 'relu', mptr, True, accumulate))
             xin = self.a7 if j == 0 else self.cat[j - 1]
             dxin = self.da7 if j == 0 else self.dcat[j - 1]
             cin = xin.c
             ops.append(bd.wgrad(self.dy_up[j].view(), xin.view(), P.ptr(name + '.kernel', 'grad'), G_UP[j], cin, 2, accumulate))
-            ops.append(bd.conv('convT_dgrad', self.dy_up[j].view(), dxin.view(), P.tr[name + '.kernel'].data_ptr(), cin, 2))
+            if j > 0:
+                spec = up_spec(j - 1)
+            else:               # da7: gradient w.r.t. the bottleneck activation = down7's backward
+                m7, r7 = self.stats['down7']
+                spec = bd.fuse_spec(self.y_down[7].view(), None, 'down7', groups, m7.data_ptr(), r7.data_ptr(), 'lrelu')
+            ops.append(bd.conv('convT_dgrad', self.dy_up[j].view(), dxin.view(), P.tr[name + '.kernel'].data_ptr(), cin, 2, bwd_fuse=spec))
+            fused, fptr = bd.last_bwd_fused, bd.last_stats_ptr
+        dy0 = self.dy_down[0]
         for i in range(7, -1, -1):
             name = f'down{i}'
             if i == 7:
@@ -563,11 +625,20 @@ class GenCall:
                 j = 6 - i
                 da, da2 = self.dcat[j].view(G_UP[j], G_DOWN[i]), self.dA[i].view()
             if i == 0:
-                ops.append(bd.act_bwd(self.cat[6].view(G_UP[6], 64), da, da2, self.dy_down[0].view(), 'lrelu'))
+                if fused:
+                    dy0 = self.dA[0]        # the epilogue of down1's dgrad already applied LeakyReLU' and the skip gradient
+                else:
+                    ops.append(bd.act_bwd(self.cat[6].view(G_UP[6], 64), da, da2, self.dy_down[0].view(), 'lrelu'))
             else:
                 mean, rstd = self.stats[name]
-                ops.append(bd.norm_bwd(name, self.y_down[i].view(), da, da2, self.dy_down[i].view(), groups,
-                                       mean.data_ptr(), rstd.data_ptr(), 'lrelu', None, True, accumulate))
+                if fused:
+                    dz = self.da7.view() if i == 7 else self.dA[i].view()
+                    ops.append(bd.norm_bwd_fused(name, self.y_down[i].view(), dz, self.dy_down[i].view(), groups,
+                                                 mean.data_ptr(), rstd.data_ptr(), fused, fptr, True, accumulate))
+                else:
+                    ops.append(bd.norm_bwd(name, self.y_down[i].view(), da, da2, self.dy_down[i].view(), groups,
+                                           mean.data_ptr(), rstd.data_ptr(), 'lrelu', None, True, accumulate))
+            dyi = dy0 if i == 0 else self.dy_down[i]
             if i == 0:
                 xin, cin_real = self.xin.view(), C_
             elif i == 1:
@@ -575,12 +646,21 @@ class GenCall:
             else:
                 jj = 6 - (i - 1)
                 xin, cin_real = self.cat[jj].view(G_UP[jj], G_DOWN[i - 1]), G_DOWN[i - 1]
-            ops.append(bd.wgrad(xin, self.dy_down[i].view(), P.ptr(name + '.kernel', 'grad'), cin_real, G_DOWN[i], 2, accumulate))
+            ops.append(bd.wgrad(xin, dyi.view(), P.ptr(name + '.kernel', 'grad'), cin_real, G_DOWN[i], 2, accumulate))
+            fused = 0
             if i > 0:
-                ops.append(bd.conv('conv_dgrad', self.dy_down[i].view(), self.dA[i - 1].view(),
-                                   P.nat[name + '.kernel'].data_ptr(), G_DOWN[i - 1], 2))
+                jb = 6 - (i - 1)                                     # layer below: down i-1, its skip gradient sits in dcat[jb]
+                skip = self.dcat[jb].view(G_UP[jb], G_DOWN[i - 1])
+                if i - 1 == 0:
+                    spec = bd.fuse_spec(self.cat[6].view(G_UP[6], 64), skip, None, act='lrelu')
+                else:
+                    mb, rb = self.stats[f'down{i - 1}']
+                    spec = bd.fuse_spec(self.y_down[i - 1].view(), skip, f'down{i - 1}', groups, mb.data_ptr(), rb.data_ptr(), 'lrelu')
+                ops.append(bd.conv('conv_dgrad', dyi.view(), self.dA[i - 1].view(),
+                                   P.nat[name + '.kernel'].data_ptr(), G_DOWN[i - 1], 2, bwd_fuse=spec))
+                fused, fptr = bd.last_bwd_fused, bd.last_stats_ptr
             elif need_dx:
-                ops.append(bd.conv('conv_dgrad', self.dy_down[0].view(), self.dxin.view(0, C_),
+                ops.append(bd.conv('conv_dgrad', dyi.view(), self.dxin.view(0, C_),
                                    P.nat[name + '.kernel'].data_ptr(), C_, 2))
         return ops
 
@@ -810,22 +890,41 @@ class DiscCall:
         if wgrads:
             ops.append(bd.wgrad(sv(self.a['conv']), dl, P.ptr('last.kernel', 'grad'), 512, 1, 1, accumulate))
             ops.append(bd.bias_grad(dl, P.ptr('last.bias', 'grad'), accumulate))
-        ops.append(bd.conv('conv_dgrad', dl, gv(self.dA['conv']), P.nat['last.kernel'].data_ptr(), 512, 1, k_real=1))
+        def spec_for(layer):          # backward of `layer` started in the epilogue of the dgrad that produces dA[layer]
+            if layer == 'down0':
+                return bd.fuse_spec(sv(self.a0), None, None, act='lrelu')
+            m_, r_ = self.stats[layer]
+            c_ = self.y[layer].c
+            return bd.fuse_spec(sv(self.y[layer]), None, layer, groups, m_.data_ptr() + 4 * stat_off * c_,
+                                r_.data_ptr() + 4 * stat_off * c_, 'lrelu')
+
+        ops.append(bd.conv('conv_dgrad', dl, gv(self.dA['conv']), P.nat['last.kernel'].data_ptr(), 512, 1, k_real=1,
+                           bwd_fuse=spec_for('conv')))
+        fused, fptr = bd.last_bwd_fused, bd.last_stats_ptr
         order = [('conv', 'down2', 1, 256), ('down2', 'down1', 2, 128), ('down1', 'down0', 2, 64)]
         for name, prev, stride, cprev in order:
             mean, rstd = self.stats[name]
             c = self.y[name].c
-            ops.append(bd.norm_bwd(name, sv(self.y[name]), gv(self.dA[name]), None, gv(self.dy[name]), groups,
-                                   mean.data_ptr() + 4 * stat_off * c, rstd.data_ptr() + 4 * stat_off * c, 'lrelu', None,
-                                   wgrads, accumulate))
+            if fused:
+                ops.append(bd.norm_bwd_fused(name, sv(self.y[name]), gv(self.dA[name]), gv(self.dy[name]), groups,
+                                             mean.data_ptr() + 4 * stat_off * c, rstd.data_ptr() + 4 * stat_off * c, fused, fptr,
+                                             wgrads, accumulate))
+            else:
+                ops.append(bd.norm_bwd(name, sv(self.y[name]), gv(self.dA[name]), None, gv(self.dy[name]), groups,
+                                       mean.data_ptr() + 4 * stat_off * c, rstd.data_ptr() + 4 * stat_off * c, 'lrelu', None,
+                                       wgrads, accumulate))
             if wgrads:
                 ops.append(bd.wgrad(sv(self.a[prev]), gv(self.dy[name]), P.ptr(name + '.kernel', 'grad'), cprev, c, stride, accumulate))
-            ops.append(bd.conv('conv_dgrad', gv(self.dy[name]), gv(self.dA[prev]), P.nat[name + '.kernel'].data_ptr(), cprev, stride))
-        ops.append(bd.act_bwd(sv(self.a0), gv(self.dA['down0']), None, gv(self.dy['down0']), 'lrelu'))
+            ops.append(bd.conv('conv_dgrad', gv(self.dy[name]), gv(self.dA[prev]), P.nat[name + '.kernel'].data_ptr(), cprev, stride,
+                               bwd_fuse=spec_for(prev)))
+            fused, fptr = bd.last_bwd_fused, bd.last_stats_ptr
+        dy0 = self.dA['down0'] if fused else self.dy['down0']
+        if not fused:
+            ops.append(bd.act_bwd(sv(self.a0), gv(self.dA['down0']), None, gv(self.dy['down0']), 'lrelu'))
         if wgrads:
-            ops.append(bd.wgrad(sv(self.xin), gv(self.dy['down0']), P.ptr('down0.kernel', 'grad'), self.net.cin, 64, 2, accumulate))
+            ops.append(bd.wgrad(sv(self.xin), gv(dy0), P.ptr('down0.kernel', 'grad'), self.net.cin, 64, 2, accumulate))
         if need_dx:
-            ops.append(bd.conv('conv_dgrad', gv(self.dy['down0']), self.dxin.view(0, self.net.cin, 0, n),
+            ops.append(bd.conv('conv_dgrad', gv(dy0), self.dxin.view(0, self.net.cin, 0, n),
                                P.nat['down0.kernel'].data_ptr(), self.net.cin, 2))
         return ops
 

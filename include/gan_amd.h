@@ -43,6 +43,29 @@ typedef struct GanTensor {
 } GanTensor;
 
 /* ---- convolutions ------------------------------------------------------------------------- */
+/* Optional fused backward epilogue of the two dgrad entry points: the backward of the layer BELOW (its
+ * normalisation + activation, base_gan.py:83-87 / :113-120 under tf.GradientTape) starts in the epilogue of the
+ * launch that produces the gradient w.r.t. that layer's activation.  For the first `cols` channels of y the stored
+ * value is not da but
+ *     dz = (da + add) * act'(z) * 2*dropmask,   z = gamma*(ref - mean)*rstd + beta      (mean != NULL; ref = that layer's y)
+ *     dz = (da + add) * act'(ref)                                                       (mean == NULL; ref = saved activation)
+ * and, with mean != NULL, per-tile partial sums (sum dz, sum dz*xhat) are written to GanConvDesc.stats_partial as
+ * [group][chunk][cols][2] (groups = GanConvDesc.stats_groups); gan_norm_act_bwd_fused() finishes the layer.  Channels
+ * >= cols (the skip half of a decoder concat) are stored unchanged.  Honoured only when gan_conv_plan_info()[4] > 0. */
+typedef struct GanBwdFuse {
+  GanTensor ref;             /* y (pre-normalisation) or the saved activation a; same n, h, w as GanConvDesc.y */
+  GanTensor add;             /* optional second upstream gradient (skip connection); ptr NULL = none */
+  const float* mean;         /* [groups][cols]; NULL = activation-only backward */
+  const float* rstd;
+  const float* gamma;        /* [cols] */
+  const float* beta;
+  const uint8_t* dropmask;   /* optional dense 0/1 bytes [n][h][w][mask_pitch] */
+  int32_t mask_pitch;
+  int32_t act;               /* GAN_ACT_LRELU | GAN_ACT_RELU */
+  float slope;
+  int32_t cols;              /* multiple of 8 */
+} GanBwdFuse;
+
 typedef struct GanConvDesc {
   uint32_t struct_size;  /* sizeof(GanConvDesc) of the caller's build */
   int32_t dtype;
@@ -59,6 +82,7 @@ typedef struct GanConvDesc {
   size_t workspace_bytes;
   float* stats_partial;  /* optional: fused normalisation statistics — per-tile (sum, sum^2) partials of y,   */
   int32_t stats_groups;  /* laid out [group][chunk][y.c][2]; emitted only if gan_conv_plan_info()[4] > 0     */
+  const GanBwdFuse* bwd_fuse; /* optional (dgrad entry points only), see above */
 } GanConvDesc;
 
 /* Conv2D(k4, strides=s, no bias | bias) — base_gan.py:77-79 ('same', s=2), :145-148 and :157-161
@@ -167,6 +191,10 @@ typedef struct GanNormBwdDesc {
   size_t workspace_bytes;
 } GanNormBwdDesc;
 int gan_norm_act_bwd(const GanNormBwdDesc* d, gan_stream_t stream);
+/* The same layer backward when its first half already ran in the producing dgrad's epilogue (GanBwdFuse above): d->da holds
+ * dz (da2, dropmask, act are ignored / must be NULL), d->workspace the producer's partial sums, `chunks` per group as
+ * reported by gan_conv_plan_info()[4], followed by room for [groups][c][2] floats.  Finalize + apply: dy, dgamma, dbeta. */
+int gan_norm_act_bwd_fused(const GanNormBwdDesc* d, int32_t chunks, gan_stream_t stream);
 
 typedef struct GanActBwdDesc { /* layers without normalisation: conv -> [bias] -> act */
   uint32_t struct_size;  /* sizeof(GanActBwdDesc) of the caller's build */

@@ -200,6 +200,112 @@ def test_thin_layers_take_streaming_kernels():
     assert c32.lib.gan_conv_plan_info(C.byref(d), 0, info) == 0 and info[0] > 0      # fp32 parity path: tiled kernel
 
 
+FUSE_CASES = [  # (op, N, H of dy, channels of dy, channels of the produced gradient, groups, kind, cols, with skip gradient)
+    ('conv_dgrad', 8, 32, 128, 64, 0, 'act', 64, True),          # down1 -> down0: LeakyReLU on the saved activation, 256x64 tile
+    ('conv_dgrad', 8, 16, 256, 128, 1, 'lrelu', 128, True),      # BatchNorm encoder layer, tile epilogue
+    ('conv_dgrad', 8, 16, 256, 128, 8, 'lrelu', 128, True),      # InstanceNorm: one group per image
+    ('conv_dgrad', 16, 32, 256, 128, 2, 'lrelu', 128, False),    # ping-pong 256x128 tile, D's two invocations
+    ('convT_dgrad', 16, 64, 128, 512, 1, 'relu', 256, False),    # decoder: leading half of a concat, ping-pong 256x256 tile
+    ('convT_dgrad', 4, 64, 128, 256, 1, 'relu+mask', 128, False),
+    ('convT_dgrad', 4, 8, 512, 1024, 1, 'relu+mask', 512, False),   # split-K: the slab-reduce kernel carries it
+    ('conv_dgrad', 4, 4, 512, 512, 4, 'lrelu', 512, True),          # split-K, InstanceNorm, skip gradient
+    ('conv_dgrad', 4, 4, 512, 64, 0, 'act', 64, False),             # split-K, activation only
+]
+
+
+@pytest.mark.parametrize("case", FUSE_CASES)
+def test_dgrad_fused_backward_epilogue(ctx, case):
+    """GanBwdFuse: a dgrad launch that starts the layer-below backward in its epilogue (dz + partial sums) followed by
+    gan_norm_act_bwd_fused must equal the plain dgrad followed by gan_norm_act_bwd / gan_act_bwd (themselves checked
+    against the oracle above); channels >= cols must be the plain dgrad's."""
+    from gan_amd import _lib as L
+    from gan_amd.nets import Buf
+    op, N, H, cdy, cg, G, kind, cols, skip = case
+    rng = np.random.default_rng(11)
+    Hg = 2 * H if op == 'conv_dgrad' else H // 2
+    dy = q(ctx, rng.standard_normal((N, H, H, cdy)))
+    # Conv2D master HWIO (in = cg, out = cdy) -> native NK copy; Conv2DTranspose master (kh, kw, out = cdy, in = cg) -> transposed copy
+    w = q(ctx, 0.05 * rng.standard_normal((4, 4, cg, cdy) if op == 'conv_dgrad' else (4, 4, cdy, cg)))
+    nat, tr = prep(ctx, w)
+    wt = nat if op == 'conv_dgrad' else tr
+    wrows = cg
+    dyb, dyv = dev(ctx, dy)
+    ref = q(ctx, rng.standard_normal((N, Hg, Hg, cols)) * 1.3 + 0.2)
+    refb, refv = dev(ctx, ref)
+    addv = None
+    if skip:
+        addb, addv = dev(ctx, q(ctx, rng.standard_normal((N, Hg, Hg, cols))), pitch=cols + 8)
+    f32 = torch.float32
+    norm = kind != 'act'
+    act = {'act': 'lrelu', 'lrelu': 'lrelu', 'relu': 'relu', 'relu+mask': 'relu'}[kind]
+    tm = None
+    if kind == 'relu+mask':
+        tm = torch.from_numpy((rng.random((N, Hg, Hg, cols)) > 0.5).astype(np.uint8)).to(ctx.device)
+    if norm:
+        gamma = torch.from_numpy((1 + 0.2 * rng.standard_normal(cols)).astype(np.float32)).to(ctx.device)
+        beta = torch.from_numpy((0.2 * rng.standard_normal(cols)).astype(np.float32)).to(ctx.device)
+        mean, rstd = torch.zeros(G * cols, dtype=f32, device=ctx.device), torch.zeros(G * cols, dtype=f32, device=ctx.device)
+        nd = L.GanNormDesc(ctx.dt, refv, refv, G, 1e-3, gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(), rstd.data_ptr(), None, None,
+                           0.99, None, L.ACTS[act], 0.3, ctx.ws_ptr, ctx.ws_bytes)
+        assert ctx.lib.gan_norm_stats(C.byref(nd), ctx.stream()) == 0
+    fn = ctx.lib.gan_conv2d_dgrad if op == 'conv_dgrad' else ctx.lib.gan_convT2d_dgrad
+    opi = 1 if op == 'conv_dgrad' else 3
+    z = L.GanTensor(None, 0, 0, 0, 0, 0)
+    # ---- plain: dgrad, then the stand-alone layer backward
+    da_b = Buf(ctx, N, Hg, Hg, cg)
+    d0 = L.GanConvDesc(ctx.dt, 2, dyv, da_b.view(), wt.data_ptr(), wrows, None, 0, 0.3, 0, ctx.ws_ptr, ctx.ws_bytes)
+    assert fn(C.byref(d0), ctx.stream()) == 0
+    out_a = Buf(ctx, N, Hg, Hg, cols)
+    dg_a, db_a = torch.zeros(cols, dtype=f32, device=ctx.device), torch.zeros(cols, dtype=f32, device=ctx.device)
+    if norm:
+        bd = L.GanNormBwdDesc(ctx.dt, refv, da_b.view(0, cols), addv if skip else z, out_a.view(), G, gamma.data_ptr(), beta.data_ptr(),
+                              mean.data_ptr(), rstd.data_ptr(), tm.data_ptr() if tm is not None else None, L.ACTS[act], 0.3,
+                              dg_a.data_ptr(), db_a.data_ptr(), 0, ctx.ws_ptr, ctx.ws_bytes)
+        assert ctx.lib.gan_norm_act_bwd(C.byref(bd), ctx.stream()) == 0
+    else:
+        ad = L.GanActBwdDesc(ctx.dt, refv, da_b.view(0, cols), addv if skip else z, out_a.view(), L.ACTS[act], 0.3, None, 0,
+                             ctx.ws_ptr, ctx.ws_bytes)
+        assert ctx.lib.gan_act_bwd(C.byref(ad), ctx.stream()) == 0
+    torch.cuda.synchronize()
+    # ---- fused
+    dz_b = Buf(ctx, N, Hg, Hg, cg)
+    part = torch.full((4 << 20,), 7.0, dtype=f32, device=ctx.device)
+    bf = L.GanBwdFuse(refv, addv if skip else z, mean.data_ptr() if norm else None, rstd.data_ptr() if norm else None,
+                      gamma.data_ptr() if norm else None, beta.data_ptr() if norm else None, tm.data_ptr() if tm is not None else None,
+                      cols, L.ACTS[act], 0.3, cols)
+    d1 = L.GanConvDesc(ctx.dt, 2, dyv, dz_b.view(), wt.data_ptr(), wrows, None, 0, 0.3, 0, ctx.ws_ptr, ctx.ws_bytes,
+                       part.data_ptr() if norm else None, G if norm else 0, C.addressof(bf))
+    info = (C.c_int32 * 5)()
+    assert ctx.lib.gan_conv_plan_info(C.byref(d1), opi, info) == 0
+    chunks = info[4]
+    assert chunks > 0, ("shape chosen to be fusable", list(info))
+    assert fn(C.byref(d1), ctx.stream()) == 0
+    tol = {'f32': 2e-5, 'bf16': 2e-2, 'f16': 3e-3}[ctx.dtype]
+    if norm:
+        out_f = Buf(ctx, N, Hg, Hg, cols)
+        dg_f, db_f = torch.zeros(cols, dtype=f32, device=ctx.device), torch.zeros(cols, dtype=f32, device=ctx.device)
+        fd = L.GanNormBwdDesc(ctx.dt, refv, dz_b.view(0, cols), z, out_f.view(), G, gamma.data_ptr(), beta.data_ptr(),
+                              mean.data_ptr(), rstd.data_ptr(), None, 0, 0.3, dg_f.data_ptr(), db_f.data_ptr(), 0,
+                              part.data_ptr(), part.numel() * 4)
+        assert ctx.lib.gan_norm_act_bwd_fused(C.byref(fd), chunks, ctx.stream()) == 0
+        torch.cuda.synchronize()
+        assert rel(host(out_f), host(out_a)) < tol
+        assert rel(dg_f.cpu().numpy(), dg_a.cpu().numpy().astype(np.float64)) < max(tol, 1e-4)
+        assert rel(db_f.cpu().numpy(), db_a.cpu().numpy().astype(np.float64)) < max(tol, 1e-4)
+    else:
+        torch.cuda.synchronize()
+        assert rel(host(dz_b, 0, cols), host(out_a)) < tol
+    if cols < cg:            # the skip half of a decoder concat is the plain gradient
+        assert np.array_equal(host(dz_b, cols), host(da_b, cols))
+    # a launch shape that cannot carry the epilogue refuses it instead of silently dropping it
+    if norm and G == 1:
+        d2 = L.GanConvDesc(ctx.dt, 2, dyv, dz_b.view(), wt.data_ptr(), wrows, None, 0, 0.3, 0, ctx.ws_ptr, ctx.ws_bytes,
+                           part.data_ptr(), 3, C.addressof(bf))      # 3 groups do not divide the batch
+        assert ctx.lib.gan_conv_plan_info(C.byref(d2), opi, info) == 0 and info[4] == 0
+        assert fn(C.byref(d2), ctx.stream()) == -2            # GAN_E_SHAPE
+        torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize("case", CONVT_CASES)
 def test_convT2d_fwd_dgrad_wgrad(ctx, case):
     from gan_amd import _lib as L
