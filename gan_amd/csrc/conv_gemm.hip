@@ -975,9 +975,10 @@ static int plan_gemm(const GanConvDesc* d, int op, GemmPlan* pl) {
   const long long target = BM == 256 ? (p.kchunks >= 48 && blocks <= 160 ? t_big : 128) : (BN == 16 ? t_skinny : t_small);   // BN=16: streaming layers want more, shorter blocks
   if (blocks < target) {
     splits = (int)((target + blocks - 1) / blocks);
-    int maxs = p.kchunks / 4; if (maxs < 1) maxs = 1;
+    static const int mink = tune("MINK", 4), maxsp = tune("MAXSPLIT", 64);
+    int maxs = p.kchunks / mink; if (maxs < 1) maxs = 1;
     if (splits > maxs) splits = maxs;
-    if (splits > 64) splits = 64;
+    if (splits > maxsp) splits = maxsp;
   }
   p.splits = splits;
   p.stats = nullptr; p.stats_tpg = 0; p.stats_C = y.c;
