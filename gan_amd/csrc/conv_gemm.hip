@@ -1030,10 +1030,12 @@ static int plan_gemm(const GanConvDesc* d, int op, GemmPlan* pl) {
   }
   if (bf_mode) {
     // the slab-reduce kernel of a split-K launch carries it at no cost (streaming kernel, the slabs are read anyway); a tile
-    // epilogue re-reads the reference tensor at the tile's strided pixel order (break-even per launch, +0.8 % on the captured step): GAN_AMD_BF_TILE = 0 never, 1 always, 2 not
-    // on the 64-column tiles
-    static const int bf_tile = tune("BF_TILE", 1);
-    const bool carrier = p.vec_store && (splits == 1 ? (bf_tile == 1 || (bf_tile == 2 && BN != 64)) : reduce4_ok);
+    // epilogue re-reads the reference tensor at the tile's strided pixel order - break-even per launch on the 128/256-column
+    // tiles, a gain on the 64-column ones (their act_bwd pass streamed 4 tensors): GAN_AMD_BF_TILE = 0 never, 1 always,
+    // 2 not on the 64-column tiles, 3 only on them
+    const int bf_tile = tune("BF_TILE", 3);            // read per plan: the op tests exercise every carrier
+    const bool tile_ok = bf_tile == 1 || (bf_tile == 2 && BN != 64) || (bf_tile == 3 && BN == 64);
+    const bool carrier = p.vec_store && (splits == 1 ? tile_ok : reduce4_ok);
     if (carrier && (bf_mode == 4 || p.stats)) {
       p.bf_mode = bf_mode; p.bf_cols = bf->cols; p.bf_slope = bf->slope;
       p.bf_ref = bf->ref.ptr; p.bf_refpitch = bf->ref.pitch;
