@@ -250,7 +250,10 @@ def main():
                            "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                            "flops_per_launch": round(kfl / kn),
                            "launches_per_step": kn, "avg_launch_us": round(kms / kn * 1e3, 2),
-                           "gemm_share_of_eager_gemm_time": round(kms / tot_ms, 3)}
+                           "gemm_share_of_eager_gemm_time": round(kms / tot_ms, 3),
+                           "timing": "HIP events around each launch of the class on its stream, eager single-stream passes after the timed "
+                                     "region (inside the captured step the lanes' kernels share the chip: per-kernel durations of "
+                                     "profiles/*_kernel_stats.csv are longer, *_kernel_stats_single_stream.csv has them without)"}
         out["kernels"] = {k: {"ms_per_step": round(v[0], 4), "tflops": round(v[1] / (v[0] * 1e-3) / 1e12, 1), "launches": v[2]}
                           for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}
         out["losses"] = [round(float(x), 5) for x in losses[:4]]

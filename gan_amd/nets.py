@@ -401,6 +401,8 @@ class _Builder:
         flops = 2.0 * M * info[3] * T * y.c * creal
         kname = (f"conv_gemm<{self.ctx.dtype},{info[0]},{info[1]}>" if info[0] else
                  f"conv_thin_{'n' if info[1] == 1 else 'k'}<{self.ctx.dtype}>")        # csrc/thin.hip streaming kernels
+        if info[0] and info[2] > 1:
+            kname += "+splitK"          # two kernels per call (GEMM into fp32 slabs + the slab-reduce kernel): timed as their own class
         meta = dict(kind='gemm', kernel=kname, flops=flops, splits=info[2],
                     shape=f"{op} M{M}{'x4' if info[3] == 4 else ''} N{y.c} K{T * x.c} s{info[2]}")
         return (fn, (self._desc(d),), op, meta)
