@@ -298,16 +298,20 @@ static int plan_wgrad(const GanWgradDesc* d, WgradPlan* pl, bool allow_swap = tr
     if (use_pp < 0) { const char* e = getenv("GAN_AMD_WGRAD_PP"); use_pp = e ? atoi(e) : 1; }
     static int min_rows = -1;
     if (min_rows < 0) { const char* e = getenv("GAN_AMD_WGRAD_PP_MINROWS"); min_rows = e ? atoi(e) : 1024; }
+    static int pp128 = -1, mingf = -1;
+    if (pp128 < 0) { const char* e = getenv("GAN_AMD_WGRAD_PP128"); pp128 = e ? atoi(e) : 0; }
+    if (mingf < 0) { const char* e = getenv("GAN_AMD_WGRAD_PP_MINGF"); mingf = e ? atoi(e) : 30; }
+    // (GAN_AMD_WGRAD_PP128: a 128-channel SMALL tensor on the 256-column tile - half the columns are computed and dropped)
     if (use_pp && allow_swap && !p.fold && !p.swap && d->dtype != GAN_F32 && (b.c == 64 || b.c == 128 || b.c % 256 == 0) &&
-        s.c % 256 == 0 && M >= 2 * min_rows &&
-        2.0 * (double)M * 16.0 * b.c * s.c >= 3.0e10) {      // every block writes a 256 KB fp32 slab tile (64 MB per launch with the
+        (s.c % 256 == 0 || (pp128 && s.c == 128)) && M >= 2 * min_rows &&
+        2.0 * (double)M * 16.0 * b.c * s.c >= 1.0e9 * mingf) {      // every block writes a 256 KB fp32 slab tile (64 MB per launch with the
                                                             // reduce pass): pays from ~30 GFLOP up (measured against the 128x128 kernel)
-      const long long tiles = (long long)(16 * b.c / 256) * (s.c / 256);
+      const long long tiles = (long long)(16 * b.c / 256) * ((s.c + 255) / 256);
       long long sp = (256 + tiles - 1) / tiles;
       if (sp > M / min_rows) sp = M / min_rows;
       if (sp < 1) sp = 1;
       if (sp > 1024) sp = 1024;
-      p.tilesB = s.c / 256;
+      p.tilesB = (s.c + 255) / 256;
       p.kchunks = (int)((M + 63) / 64);
       if (sp >= 8) sp &= ~7LL;
       p.splits = (int)sp;
