@@ -114,7 +114,7 @@ SYMBOLS = {
     "gan_pack": (C.c_int, [C.c_int32, C.c_void_p, C.POINTER(GanTensor), C.c_void_p]),
     "gan_pack_multi": (C.c_int, [C.c_int32, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(GanTensor), C.c_void_p]),
     "gan_dropout_mask_multi": (C.c_int, [C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_uint64, C.c_void_p,
-                                         C.POINTER(C.c_uint32), C.c_void_p]),
+                                         C.POINTER(C.c_uint32), C.c_void_p, C.c_void_p]),
     "gan_unpack": (C.c_int, [C.c_int32, C.POINTER(GanTensor), C.c_void_p, C.c_void_p]),
     "gan_copy_view": (C.c_int, [C.c_int32, C.POINTER(GanTensor), C.POINTER(GanTensor), C.c_void_p]),
     "gan_bias_grad": (C.c_int, [C.c_int32, C.POINTER(GanTensor), C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p]),

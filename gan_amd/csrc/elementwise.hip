@@ -331,14 +331,26 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const PackMulti pm, int
   st_f((T*)pm.dst[k] + (i / C) * pm.pitch[k] + (i % C), pm.src[k][i]);
 }
 struct DropMulti { uint8_t* mask[4]; long long count[4]; uint32_t sid[4]; };
-__global__ __launch_bounds__(256) void dropout_multi_kernel(const DropMulti dm, uint64_t seed, const int32_t* step) {
+// `draws` (optional): {number of launches so far, block ticket}: every block reads the count before it takes a ticket, the
+// last ticket holder advances it - successive calls draw new masks even while *step stands still (validation passes).
+__global__ __launch_bounds__(256) void dropout_multi_kernel(const DropMulti dm, uint64_t seed, const int32_t* step, int32_t* draws) {
   const int k = blockIdx.y;
-  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  long long w = i * 8;
-  if (w >= dm.count[k]) return;
-  uint64_t key = mix64(seed ^ ((uint64_t)(uint32_t)(*step) << 32) ^ dm.sid[k]);
-  uint64_t h = mix64(key ^ (uint64_t)i);
-  for (int e = 0; e < 8 && w + e < dm.count[k]; ++e) dm.mask[k][w + e] = (uint8_t)((h >> (e * 8 + 7)) & 1);
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long w = i * 8;
+  const uint32_t draw = draws ? (uint32_t)draws[0] : 0u;
+  if (w < dm.count[k]) {
+    uint64_t key = mix64(seed ^ ((uint64_t)(uint32_t)(*step) << 32) ^ dm.sid[k]);
+    if (draw) key = mix64(key + draw);
+    uint64_t h = mix64(key ^ (uint64_t)i);
+    for (int e = 0; e < 8 && w + e < dm.count[k]; ++e) dm.mask[k][w + e] = (uint8_t)((h >> (e * 8 + 7)) & 1);
+  }
+  if (draws) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const int t = atomicAdd(&draws[1], 1);
+      if (t == (int)(gridDim.x * gridDim.y) - 1) { draws[1] = 0; draws[0] = (int32_t)(draw + 1u); }
+    }
+  }
 }
 template <typename T>
 __global__ __launch_bounds__(256) void unpack_kernel(const T* src, float* dst, int C, int pitch, long long total) {
@@ -573,7 +585,7 @@ int gan_pack_multi(int32_t dtype, int32_t n, const float* const* srcs, const Gan
 }
 
 int gan_dropout_mask_multi(int32_t n, uint8_t* const* masks, const int64_t* counts, uint64_t seed, const int32_t* step,
-                           const uint32_t* stream_ids, gan_stream_t stream) {
+                           const uint32_t* stream_ids, int32_t* draws, gan_stream_t stream) {
   if (!masks || !counts || !stream_ids || !step || n <= 0 || n > 4) return GAN_E_ARG;
   DropMulti dm;
   long long maxw = 0;
@@ -584,7 +596,7 @@ int gan_dropout_mask_multi(int32_t n, uint8_t* const* masks, const int64_t* coun
     if (w > maxw) maxw = w;
   }
   hipLaunchKernelGGL(dropout_multi_kernel, dim3((unsigned)((maxw + 255) / 256), (unsigned)n), dim3(256), 0, (hipStream_t)stream, dm,
-                     seed, step);
+                     seed, step, draws);
   GAN_CHECK_LAUNCH();
   return 0;
 }

@@ -526,8 +526,10 @@ class GenCall:
         if dropout:          # the three Dropout(0.5) masks of this call in one launch
             self._mask_args = ((C.c_void_p * 3)(*[m.data_ptr() for m in self.masks]), (C.c_int64 * 3)(*[m.numel() for m in self.masks]),
                                (C.c_uint32 * 3)(*[stream_id * 8 + j for j in range(3)]))
+            # per-call launch counter (advanced by the kernel): validation passes draw new masks although the Adam step stands still
+            self.mask_draws = torch.zeros(2, dtype=torch.int32, device=dev)
             self.mask_ops.append((ctx.lib.gan_dropout_mask_multi, (3, self._mask_args[0], self._mask_args[1], seed, P.step.data_ptr(),
-                                                                   self._mask_args[2]), "dropout_mask_multi"))
+                                                                   self._mask_args[2], self.mask_draws.data_ptr()), "dropout_mask_multi"))
         self.auto_masks = dropout
 
         def a_down(i):      # activation view of down i

@@ -261,9 +261,12 @@ int gan_loss_scale_update(float* scale_state, int32_t growth_interval, float max
 /* Bernoulli(0.5) keep-mask from a counter hash of (seed, *step, stream_id, index). */
 int gan_dropout_mask(uint8_t* mask, int64_t count, uint64_t seed, const int32_t* step, uint32_t stream_id,
                      gan_stream_t stream);
-/* the same for n <= 4 masks (the three Dropout layers of a generator call) in a single launch; host arrays */
+/* the same for n <= 4 masks (the three Dropout layers of a generator call) in a single launch; host arrays.  draws: optional
+ * device int32[2], zero-initialised by the caller: a per-call-site launch counter mixed into the hash and advanced by the
+ * launch itself, so that successive calls draw new masks while *step stands still (training=True forward passes of the
+ * validation loop, pix2pix.py:228 / :338: Keras draws a fresh mask per call).  NULL = the single-mask hash above. */
 int gan_dropout_mask_multi(int32_t n, uint8_t* const* masks, const int64_t* counts, uint64_t seed, const int32_t* step,
-                           const uint32_t* stream_ids, gan_stream_t stream);
+                           const uint32_t* stream_ids, int32_t* draws, gan_stream_t stream);
 /* dst(dtype, pitch view) <- src fp32 dense [n,h,w,c]  /  dst fp32 dense <- src(dtype, pitch view) */
 int gan_pack(int32_t dtype, const float* src, const GanTensor* dst, gan_stream_t stream);
 /* n <= 4 (source, destination) pairs of one shape in a single launch (host arrays, read at call time) */

@@ -684,9 +684,21 @@ def test_multi_launch_pack_and_dropout_equal_single_calls(ctx):
     ptrs = (C.c_void_p * 3)(*[m.data_ptr() for m in m1])
     cnts = (C.c_int64 * 3)(*sizes)
     sids = (C.c_uint32 * 3)(8, 9, 10)
-    assert ctx.lib.gan_dropout_mask_multi(3, ptrs, cnts, 1234, step.data_ptr(), sids, ctx.stream()) == 0
+    assert ctx.lib.gan_dropout_mask_multi(3, ptrs, cnts, 1234, step.data_ptr(), sids, None, ctx.stream()) == 0
     for m, sid in zip(m2, (8, 9, 10)):
         assert ctx.lib.gan_dropout_mask(m.data_ptr(), m.numel(), 1234, step.data_ptr(), sid, ctx.stream()) == 0
     torch.cuda.synchronize()
     for x, y in zip(m1, m2):
         assert torch.equal(x, y) and 0.3 < x.float().mean().item() < 0.7
+    # with a launch counter: the first launch equals the plain hash, each later launch draws new masks (the step stands still,
+    # as in a validation loop), and the counter is advanced exactly once per launch by the kernel itself
+    draws = torch.zeros(2, dtype=torch.int32, device=ctx.device)
+    seen = []
+    for it in range(3):
+        assert ctx.lib.gan_dropout_mask_multi(3, ptrs, cnts, 1234, step.data_ptr(), sids, draws.data_ptr(), ctx.stream()) == 0
+        torch.cuda.synchronize()
+        assert draws.tolist() == [it + 1, 0]
+        seen.append([m.clone() for m in m1])
+    assert all(torch.equal(a_, b_) for a_, b_ in zip(seen[0], m2))
+    assert not torch.equal(seen[0][1], seen[1][1]) and not torch.equal(seen[1][1], seen[2][1])
+    assert 0.4 < (seen[1][1] == seen[2][1]).float().mean().item() < 0.6          # independent draws
