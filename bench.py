@@ -160,6 +160,14 @@ def main():
             dist.init_process_group('nccl', device_id=torch.device(f'cuda:{local}'))
         else:
             dist.init_process_group(backend)
+    # GAN_AMD_DDP_REHEARSE=1 on ONE GPU: a one-rank RCCL group with the collectives forced on - the complete data-parallel
+    # schedule (bucket graphs, wire-format kernels, asynchronous all-reduces, Adam per bucket) and its cost at N = 1
+    rehearse = world == 1 and os.environ.get('GAN_AMD_DDP_REHEARSE') == '1'
+    if rehearse:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29611')
+        torch.cuda.set_device(local)
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device(f'cuda:{local}'))
     if args.gpus != world:
         if rank == 0:
             print(f"bench.py: --gpus {args.gpus} but {world} rank(s) joined", file=sys.stderr)
@@ -176,8 +184,9 @@ def main():
         step = Pix2PixStep(ctx, B, S, 1, lam=100.0, seed=123)
     else:
         step = CycleGANStep(ctx, B, S, 1, lam=10.0, seed=123)
-    if world > 1:
-        step.sync = GradSync([n.params.grad for n in step.nets()], compress_bf16=(args.dtype != "f32" and not args.fp32_allreduce), lib=ctx.lib)
+    if world > 1 or rehearse:
+        step.sync = GradSync([n.params.grad for n in step.nets()], compress_bf16=(args.dtype != "f32" and not args.fp32_allreduce), lib=ctx.lib,
+                             rehearse=rehearse)
     # synthetic inputs on the normalize() lattice u/127.5-1 (base_gan.py:56-61), different per rank
     g = torch.Generator(device='cpu').manual_seed(123 + rank)
     mk = lambda: (torch.randint(0, 256, (B, S, S, 1), generator=g).float() / 127.5 - 1.0).to(dev)
@@ -220,7 +229,7 @@ def main():
         out = {"metric": f"Pix2Pix train_step images/sec at {S}x{S}" if args.model == 'pix2pix' else f"CycleGAN train_step pairs/sec at {S}x{S}",
                "value": round(value, 2), "unit": unit, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": args.dtype, "data": "synthetic", "repeats": len(times),
+               "dtype": args.dtype, "data": "synthetic", "repeats": len(times), **({"ddp_rehearsal_one_rank": True} if rehearse else {}),
                "ms_per_step_all_repeats": [round(t_ / args.steps * 1e3, 4) for t_ in times],
                "config": {"workload": f"{'Pix2Pix' if args.model == 'pix2pix' else 'CycleGAN'} {S}x{S} {args.dtype} "
                                       f"batch={B}/GPU train_step (G fwd, D fwd real+fake, losses, dgrad+wgrad, Adam"
@@ -260,7 +269,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or rehearse:
         dist.destroy_process_group()
 
 

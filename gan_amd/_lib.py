@@ -90,7 +90,7 @@ SYMBOLS = {
     "gan_weights_prepare": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gan_weights_prepare_multi": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "gan_adam_prepare_multi": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
-                                         C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
+                                         C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_int32, C.c_void_p]),
     "gan_norm_stats": (C.c_int, [C.POINTER(GanNormDesc), C.c_void_p]),
     "gan_norm_stats_finalize": (C.c_int, [C.POINTER(GanNormDesc), C.c_int32, C.c_void_p]),
     "gan_norm_act_fwd": (C.c_int, [C.POINTER(GanNormDesc), C.c_void_p]),
@@ -106,7 +106,7 @@ SYMBOLS = {
                          C.c_float, C.POINTER(GanTensor), C.c_void_p, C.c_void_p, C.c_void_p]),
     "gan_adam_begin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
     "gan_adam_tf": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_float,
-                              C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
+                              C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_int32, C.c_void_p]),
     "gan_sum3": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "gan_grads_check": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "gan_loss_scale_update": (C.c_int, [C.c_void_p, C.c_int32, C.c_float, C.c_void_p]),

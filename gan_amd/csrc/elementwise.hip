@@ -141,13 +141,21 @@ __global__ void adam_begin_kernel(int32_t* step, float* lr_t, float lr, float b1
   double v = (double)lr * sqrt(1.0 - pow((double)b2, (double)t)) / (1.0 - pow((double)b1, (double)t));
   *lr_t = (float)v;
 }
+// GW: the gradient is read from the data-parallel wire buffer (bf16, summed over ranks) instead of the fp32 gradient buffer
+__device__ __forceinline__ float4 ld_grad4(const void* g, size_t i4, bool wire) {
+  if (!wire) return ((const float4*)g)[i4];
+  const uint2 q = ((const uint2*)g)[i4];
+  return make_float4(__uint_as_float(q.x << 16), __uint_as_float(q.x & 0xffff0000u), __uint_as_float(q.y << 16), __uint_as_float(q.y & 0xffff0000u));
+}
+template <bool GW>
 __global__ __launch_bounds__(256) void adam_kernel(float4* __restrict__ p, float4* __restrict__ m, float4* __restrict__ v,
-                                                   const float4* __restrict__ g, long long nvec, const float* lr_t,
+                                                   const void* __restrict__ g, long long nvec, const float* lr_t,
                                                    float omb1, float omb2, float eps, float gscale, const float* ls) {
   const float lr = *lr_t;
   if (ls) { if (ls[3] != 0.f) return; gscale *= ls[1]; }
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long long)gridDim.x * 256) {
-    float4 pp = p[i], mm = m[i], vv = v[i], gg = g[i];
+    float4 pp = p[i], mm = m[i], vv = v[i];
+    const float4 gg = ld_grad4(g, (size_t)i, GW);
 #define ADAM1(f)                                     \
   {                                                  \
     float gr = gg.f * gscale;                        \
@@ -225,8 +233,8 @@ __global__ __launch_bounds__(256) void wprep_multi_kernel(const PrepEntry* ents,
 // once with its gradient and moments, updated, and leaves as fp32 master + moments and as the two typed copies the
 // GEMMs consume (the transposed one through the LDS tile), instead of Adam (28 B/param) followed by a prep pass that
 // re-reads the master (8 B/param more).  16-byte accesses along the contiguous axis when the tensor allows.
-struct AdamBases { float* master; float* m; float* v; const float* grad; };
-template <typename T>
+struct AdamBases { float* master; float* m; float* v; const void* grad; };
+template <typename T, bool GW>
 __global__ __launch_bounds__(256) void adam_prep_multi_kernel(const PrepEntry* ents, int n, AdamBases ab, const float* lr_t,
                                                               float omb1, float omb2, float eps, float gscale, const float* ls) {
   __shared__ float tile[64][65];
@@ -261,14 +269,14 @@ __global__ __launch_bounds__(256) void adam_prep_multi_kernel(const PrepEntry* e
       const size_t o = base + ((size_t)tap * A + a) * B + b;
       if (vecB) {
         float4 pp = *(const float4*)(ab.master + o), mm = *(const float4*)(ab.m + o), vv = *(const float4*)(ab.v + o);
-        const float4 gg = *(const float4*)(ab.grad + o);
+        const float4 gg = ld_grad4(ab.grad, o >> 2, GW);          // o % 4 == 0 here (B % 4 == 0, 64-element aligned tensors)
         adam1(pp.x, mm.x, vv.x, gg.x); adam1(pp.y, mm.y, vv.y, gg.y); adam1(pp.z, mm.z, vv.z, gg.z); adam1(pp.w, mm.w, vv.w, gg.w);
         *(float4*)(ab.master + o) = pp; *(float4*)(ab.m + o) = mm; *(float4*)(ab.v + o) = vv;
         w[0] = pp.x; w[1] = pp.y; w[2] = pp.z; w[3] = pp.w;
       } else {
         for (int k = 0; k < 4 && b + k < B; ++k) {
           float pp = ab.master[o + k], mm = ab.m[o + k], vv = ab.v[o + k];
-          adam1(pp, mm, vv, ab.grad[o + k]);
+          adam1(pp, mm, vv, GW ? __uint_as_float((uint32_t)((const uint16_t*)ab.grad)[o + k] << 16) : ((const float*)ab.grad)[o + k]);
           ab.master[o + k] = pp; ab.m[o + k] = mm; ab.v[o + k] = vv;
           w[k] = pp;
         }
@@ -473,14 +481,19 @@ int gan_adam_begin(int32_t* step, float* lr_t, float lr, float beta1, float beta
   return 0;
 }
 
-int gan_adam_tf(float* param, float* m, float* v, const float* grad, int64_t count, const float* lr_t, float beta1,
-                float beta2, float eps, float grad_scale, const float* scale_state, gan_stream_t stream) {
+int gan_adam_tf(float* param, float* m, float* v, const void* grad, int64_t count, const float* lr_t, float beta1,
+                float beta2, float eps, float grad_scale, const float* scale_state, int32_t grad_bf16, gan_stream_t stream) {
   if (!param || !m || !v || !grad || !lr_t || count <= 0 || count % 4) return GAN_E_ARG;
+  if (((uintptr_t)grad & (grad_bf16 ? 7 : 15))) return GAN_E_ARG;
   long long nvec = count / 4;
   long long blocks = (nvec + 255) / 256;
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (float4*)param, (float4*)m,
-                     (float4*)v, (const float4*)grad, nvec, lr_t, 1.f - beta1, 1.f - beta2, eps, grad_scale, scale_state);
+  if (grad_bf16)
+    hipLaunchKernelGGL(adam_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (float4*)param, (float4*)m,
+                       (float4*)v, grad, nvec, lr_t, 1.f - beta1, 1.f - beta2, eps, grad_scale, scale_state);
+  else
+    hipLaunchKernelGGL(adam_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (float4*)param, (float4*)m,
+                       (float4*)v, grad, nvec, lr_t, 1.f - beta1, 1.f - beta2, eps, grad_scale, scale_state);
   GAN_CHECK_LAUNCH();
   return 0;
 }
@@ -528,16 +541,20 @@ int gan_weights_prepare_multi(const void* entries_dev, int32_t n, int32_t total_
 }
 
 int gan_adam_prepare_multi(const void* entries_dev, int32_t n, int32_t total_tiles, int32_t dtype, float* master, float* m,
-                           float* v, const float* grad, const float* lr_t, float beta1, float beta2, float eps,
-                           float grad_scale, const float* scale_state, gan_stream_t stream) {
+                           float* v, const void* grad, const float* lr_t, float beta1, float beta2, float eps,
+                           float grad_scale, const float* scale_state, int32_t grad_bf16, gan_stream_t stream) {
   if (!entries_dev || n <= 0 || total_tiles <= 0 || !master || !m || !v || !grad || !lr_t) return GAN_E_ARG;
-  if (((uintptr_t)master | (uintptr_t)m | (uintptr_t)v | (uintptr_t)grad) & 15) return GAN_E_ARG;
+  if (((uintptr_t)master | (uintptr_t)m | (uintptr_t)v) & 15 || ((uintptr_t)grad & (grad_bf16 ? 7 : 15))) return GAN_E_ARG;
   const AdamBases ab = {master, m, v, grad};
   hipStream_t st = (hipStream_t)stream;
   return with_dtype(dtype, [&](auto* tag) {
     typedef GAN_TAG_T(tag) T;
-    hipLaunchKernelGGL(adam_prep_multi_kernel<T>, dim3((unsigned)total_tiles), dim3(256), 0, st, (const PrepEntry*)entries_dev, n, ab,
-                       lr_t, 1.f - beta1, 1.f - beta2, eps, grad_scale, scale_state);
+    if (grad_bf16)
+      hipLaunchKernelGGL((adam_prep_multi_kernel<T, true>), dim3((unsigned)total_tiles), dim3(256), 0, st, (const PrepEntry*)entries_dev, n, ab,
+                         lr_t, 1.f - beta1, 1.f - beta2, eps, grad_scale, scale_state);
+    else
+      hipLaunchKernelGGL((adam_prep_multi_kernel<T, false>), dim3((unsigned)total_tiles), dim3(256), 0, st, (const PrepEntry*)entries_dev, n, ab,
+                         lr_t, 1.f - beta1, 1.f - beta2, eps, grad_scale, scale_state);
     GAN_CHECK_LAUNCH();
     return 0;
   });

@@ -21,12 +21,14 @@ import torch.distributed as dist
 
 
 class GradSync:
-    def __init__(self, grad_buffers, group=None, compress_bf16=False, lib=None):
+    def __init__(self, grad_buffers, group=None, compress_bf16=False, lib=None, rehearse=False):
         """grad_buffers: list of flat fp32 tensors (ParamSet.grad of each network).  lib: the loaded C-ABI library
-        (needed for the bf16 wire format on the GPU; CPU/gloo tests pass None and get a torch cast)."""
+        (needed for the bf16 wire format on the GPU; CPU/gloo tests pass None and get a torch cast).  rehearse: issue the
+        collectives even in a group of ONE rank (a one-GPU box can then run the whole data-parallel schedule over RCCL)."""
         self.bufs = list(grad_buffers)
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.active = self.world > 1 or (bool(rehearse) and dist.is_initialized())
         self.compress = bool(compress_bf16)
         self.lib = lib
         self.wire = [torch.zeros_like(b, dtype=torch.bfloat16) for b in self.bufs] if self.compress else None
@@ -70,7 +72,7 @@ class GradSync:
     # ---- collectives -----------------------------------------------------------------------------------
     def start(self, i, lo=0, hi=None):
         """Begin the all-reduce (SUM) of elements [lo, hi) of buffer i in its wire format; returns a handle."""
-        if self.world == 1:
+        if not self.active:
             return None
         t = self.wire[i] if self.compress else self.bufs[i]
         hi = t.numel() if hi is None else hi

@@ -215,17 +215,21 @@ class ParamSet:
     def adam_begin_ops(self, lr, b1, b2):
         return [(self.ctx.lib.gan_adam_begin, (self.step.data_ptr(), self.lr_t.data_ptr(), lr, b1, b2, self.ctx.ls_ptr), "adam_begin")]
 
-    def adam_segment_ops(self, seg, b1, b2, eps=1e-7, grad_scale=1.0, vectors=False):
+    def adam_segment_ops(self, seg, b1, b2, eps=1e-7, grad_scale=1.0, vectors=False, kernels=True, wire_ptr=None):
         """Fused Adam + NK refresh of kernel segment `seg` (split_kernels_at), optionally followed by the vectors'
-        plain Adam.  gan_adam_begin must already have run this step."""
+        plain Adam.  gan_adam_begin must already have run this step.  wire_ptr: read the gradient from the bf16 wire
+        buffer of the data-parallel exchange (same element offsets as the flat fp32 gradient buffer) instead."""
         lib = self.ctx.lib
-        ptrs = (self.master.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), self.grad.data_ptr())
-        ops = [(lib.gan_adam_prepare_multi, self._segments[seg][1] + ptrs + (self.lr_t.data_ptr(), b1, b2, eps, grad_scale, self.ctx.ls_ptr),
-                "adam_prepare_multi")]
+        gw = 1 if wire_ptr else 0
+        ptrs = (self.master.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), wire_ptr or self.grad.data_ptr())
+        ops = []
+        if kernels:
+            ops.append((lib.gan_adam_prepare_multi, self._segments[seg][1] + ptrs + (self.lr_t.data_ptr(), b1, b2, eps, grad_scale, self.ctx.ls_ptr, gw),
+                        "adam_prepare_multi"))
         nvec = self.total - self.vec_start
         if vectors and nvec > 0:
-            ops.append((lib.gan_adam_tf, tuple(p_ + 4 * self.vec_start for p_ in ptrs) + (nvec, self.lr_t.data_ptr(), b1, b2, eps, grad_scale, self.ctx.ls_ptr),
-                        "adam_tf"))
+            vptrs = tuple(p_ + 4 * self.vec_start for p_ in ptrs[:3]) + (ptrs[3] + (2 if gw else 4) * self.vec_start,)
+            ops.append((lib.gan_adam_tf, vptrs + (nvec, self.lr_t.data_ptr(), b1, b2, eps, grad_scale, self.ctx.ls_ptr, gw), "adam_tf"))
         return ops
 
     def ptr(self, name, which='master'):
@@ -260,19 +264,21 @@ class ParamSet:
         """(Re)build the typed NK weight copies from the fp32 master."""
         self.ctx.run(self._prep_ops)
 
-    def adam(self, lr, b1, b2, eps=1e-7, grad_scale=1.0, stream=None):
+    def adam(self, lr, b1, b2, eps=1e-7, grad_scale=1.0, stream=None, wire_ptr=None):
         """Keras Adam (base_gan.py:247-252): the kernels in one launch fused with the refresh of their NK copies, the
-        vectors (norm parameters, biases) in a second, small one.  `stream`: that lane instead of the current stream."""
+        vectors (norm parameters, biases) in a second, small one.  `stream`: that lane instead of the current stream.
+        wire_ptr: as adam_segment_ops."""
         lib = self.ctx.lib
         table_ptr, n_ents, tiles, dt = self._prep_args
-        ptrs = (self.master.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), self.grad.data_ptr())
+        gw = 1 if wire_ptr else 0
+        ptrs = (self.master.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), wire_ptr or self.grad.data_ptr())
         ops = [(lib.gan_adam_begin, (self.step.data_ptr(), self.lr_t.data_ptr(), lr, b1, b2, self.ctx.ls_ptr), "adam_begin"),
-               (lib.gan_adam_prepare_multi, (table_ptr, n_ents, tiles, dt) + ptrs + (self.lr_t.data_ptr(), b1, b2, eps, grad_scale, self.ctx.ls_ptr),
+               (lib.gan_adam_prepare_multi, (table_ptr, n_ents, tiles, dt) + ptrs + (self.lr_t.data_ptr(), b1, b2, eps, grad_scale, self.ctx.ls_ptr, gw),
                 "adam_prepare_multi")]
         nvec = self.total - self.vec_start
         if nvec > 0:
-            ops.append((lib.gan_adam_tf, tuple(p_ + 4 * self.vec_start for p_ in ptrs) + (nvec, self.lr_t.data_ptr(), b1, b2, eps, grad_scale, self.ctx.ls_ptr),
-                        "adam_tf"))
+            vptrs = tuple(p_ + 4 * self.vec_start for p_ in ptrs[:3]) + (ptrs[3] + (2 if gw else 4) * self.vec_start,)
+            ops.append((lib.gan_adam_tf, vptrs + (nvec, self.lr_t.data_ptr(), b1, b2, eps, grad_scale, self.ctx.ls_ptr, gw), "adam_tf"))
         if stream is not None:
             self.ctx.run_on(ops, stream)
         else:

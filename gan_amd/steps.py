@@ -18,6 +18,11 @@ from . import _lib as L
 from .nets import Ctx, DiscriminatorNet, GeneratorNet
 
 
+# Other threads of the process may call into the runtime while a step is being captured (the RCCL watchdog of
+# torch.distributed polls its events): only calls of the CAPTURING thread may invalidate the capture.
+CAPTURE_MODE = "thread_local"
+
+
 class _StepBase:
     def _bce(self, logits_ptr, count, target, loss_idx, loss_scale, acc, grad_scale, dx_ptr):
         lib, ctx = self.ctx.lib, self.ctx
@@ -89,29 +94,29 @@ class _StepBase:
             self._run(*self._static_in, training=training)
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
-        split = training and self.sync is not None and self.sync.world > 1
+        split = training and self.sync is not None and getattr(self.sync, 'active', self.sync.world > 1)
         if (split and hasattr(self, '_capture_bucketed') and self.ctx.ms_mode == 4 and self.ctx.ls is None      # (fp16: the whole-step
                 and os.environ.get('GAN_AMD_DDP_BUCKETS', '1') == '1'):                                   # inf/nan check precedes every Adam)
             return self._capture_bucketed()
         g1 = torch.cuda.CUDAGraph()
         g2 = g3 = None
         if not split:
-            with torch.cuda.graph(g1):
+            with torch.cuda.graph(g1, capture_error_mode=CAPTURE_MODE):
                 self._run(*self._static_in, training=training)
                 self.ctx.assert_lanes_joined()
         else:
             # graph 1: forward, losses, generator-side backward  -> start the generators' (large) exchange
             # graph 2: discriminator parameter pass (overlaps it) -> start the discriminators' exchange
             # graph 3: Adam, after both exchanges have landed
-            with torch.cuda.graph(g1):
+            with torch.cuda.graph(g1, capture_error_mode=CAPTURE_MODE):
                 self._forward_backward(*self._static_in, training, phase=1)
                 self.ctx.assert_lanes_joined()
             g2 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g2):
+            with torch.cuda.graph(g2, capture_error_mode=CAPTURE_MODE):
                 self._forward_backward(*self._static_in, training, phase=2)
                 self.ctx.assert_lanes_joined()
             g3 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g3):
+            with torch.cuda.graph(g3, capture_error_mode=CAPTURE_MODE):
                 self._update()
                 self.ctx.assert_lanes_joined()
         self._graphs = (g1, g2, g3)
@@ -294,10 +299,10 @@ class Pix2PixStep(_StepBase):
         schedule:
 
           G1  forward, losses, D's input-gradient pass, G backward stage 0 chain (decoder)
+                                        ||  D's parameter-gradient pass -> bucket 4 = D (whole network)
           G2  stage 1 chain (down7..4)  ||  stage 0 wgrads              -> bucket 0 = decoder kernels
           G3  stage 2 chain (down3..0)  ||  stage 1 wgrads              -> bucket 1 = down7..4 kernels
-          G4  stage 2 wgrads            ||  D's parameter-gradient pass -> bucket 2 = down3..0 kernels + G's vectors,
-                                                                           bucket 3 = D (whole network)
+          G4  stage 2 wgrads                                            -> bucket 2 = down3..0 kernels, 3 = G's vectors
         Weights are only rewritten by an Adam graph after every kernel that reads them in this step has been
         enqueued: a segment's NK copies feed the dgrads of its own stage, which precede its bucket."""
         ctx, g, d, sync = self.ctx, self.g, self.d, self.sync
@@ -317,64 +322,80 @@ class Pix2PixStep(_StepBase):
             self._forward_backward(*self._static_in, True, phase=1)
             self._forward_backward(*self._static_in, True, phase=2)
             for b in range(len(self.buckets)):
-                sync.pack(*self.buckets[b]); sync.unpack(*self.buckets[b])
+                sync.pack(*self.buckets[b])
         main.wait_stream(s)
         torch.cuda.synchronize()
 
         def graph(fn):
             gr = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gr):
+            with torch.cuda.graph(gr, capture_error_mode=CAPTURE_MODE):
                 fn()
                 ctx.assert_lanes_joined()
             return gr
 
-        def fork_join(side_ops, side_stream, main_fn):
+        def fork_join(side_ops, side_stream, main_fn, bucket=None):
+            """side_ops (a stage's wgrad GEMMs) and then the cast of `bucket` to the wire format on the side stream,
+            beside main_fn on the current one."""
             cur = torch.cuda.current_stream(ctx.device)
             side_stream.wait_stream(cur)
             ctx.run_on(side_ops, side_stream)
+            if bucket is not None:
+                with torch.cuda.stream(side_stream):
+                    sync.pack(*self.buckets[bucket])
             main_fn()
             ctx.join(cur, side_stream)
 
         def g1():
             self._forward_backward(*self._static_in, True, phase=3)          # everything up to G's backward
+            # D's parameter-gradient pass runs on lane 2 beside the decoder chain, as in the one-GPU schedule; nothing
+            # reads D's weights after this graph, so D's bucket is the first to leave
+            cur = torch.cuda.current_stream(ctx.device)
+            lane2.wait_stream(cur)
+            ctx.run_on(d.params_ops(), lane2)
+            with torch.cuda.stream(lane2):
+                sync.pack(*self.buckets[4])
             ctx.run(stages[0][0])
+            ctx.join(cur, lane2)
 
         def g2():
-            fork_join(stages[0][1], lane3, lambda: ctx.run(stages[1][0]))
-            sync.pack(*self.buckets[0])
+            fork_join(stages[0][1], lane3, lambda: ctx.run(stages[1][0]), bucket=0)
 
         def g3():
-            fork_join(stages[1][1], lane3, lambda: ctx.run(stages[2][0]))
-            sync.pack(*self.buckets[1])
+            fork_join(stages[1][1], lane3, lambda: ctx.run(stages[2][0]), bucket=1)
 
         def g4():
-            fork_join(stages[2][1], lane3, lambda: ctx.run(d.params_ops()))
-            for b in (2, 3, 4):
+            ctx.run(stages[2][1])
+            for b in (2, 3):
                 sync.pack(*self.buckets[b])
 
-        gs = sync.grad_scale
+        # Adam per bucket.  bf16 wire: Adam reads the exchanged gradient straight from the wire buffer (x 1/world) - no
+        # unpack pass, and the fp32 gradient buffer keeps this rank's own gradient; fp32 wire: reduced in place, x 1/world
+        gs = 1.0 / sync.world if sync.compress else sync.grad_scale
+        wp = [w.data_ptr() for w in sync.wire] if sync.compress else [None, None]
 
         def a0():
-            sync.unpack(*self.buckets[0])
-            ctx.run(P.adam_begin_ops(self.lr, self.b1, self.b2) + P.adam_segment_ops(2, self.b1, self.b2, grad_scale=gs))
+            ctx.run(P.adam_begin_ops(self.lr, self.b1, self.b2) + P.adam_segment_ops(2, self.b1, self.b2, grad_scale=gs, wire_ptr=wp[0]))
 
         def a1():
-            sync.unpack(*self.buckets[1])
-            ctx.run(P.adam_segment_ops(1, self.b1, self.b2, grad_scale=gs))
+            ctx.run(P.adam_segment_ops(1, self.b1, self.b2, grad_scale=gs, wire_ptr=wp[0]))
 
         def a2():
-            sync.unpack(*self.buckets[2]); sync.unpack(*self.buckets[3])
-            ctx.run(P.adam_segment_ops(0, self.b1, self.b2, grad_scale=gs, vectors=True))
+            ctx.run(P.adam_segment_ops(0, self.b1, self.b2, grad_scale=gs, vectors=True, wire_ptr=wp[0]))
 
         def a3():
-            sync.unpack(*self.buckets[4])
-            PD.adam(self.lr, self.b1, self.b2, grad_scale=gs)
+            PD.adam(self.lr, self.b1, self.b2, grad_scale=gs, wire_ptr=wp[1])
 
-        G = [graph(f) for f in (g1, g2, g3, g4)]
+        merge34 = os.environ.get('GAN_AMD_DDP_MERGE34', '0') == '1'      # one graph boundary less, bucket 1 leaves later
+
+        def g34():
+            g3(); g4()
+
+        G = [graph(f) for f in ((g1, g2, g34) if merge34 else (g1, g2, g3, g4))]
         A = [graph(f) for f in (a0, a1, a2, a3)]
         self._graphs = tuple(G + A)
         # after G_k: which buckets leave, and which Adam graph follows each of them
-        plan = {1: [(0, 0)], 2: [(1, 1)], 3: [(2, None), (3, 2), (4, 3)]}
+        plan = ({0: [(4, 3)], 1: [(0, 0)], 2: [(1, 1), (2, None), (3, 2)]} if merge34 else
+                {0: [(4, 3)], 1: [(0, 0)], 2: [(1, 1)], 3: [(2, None), (3, 2)]})
 
         def replay(*inputs):
             for dst, src in zip(self._static_in, inputs):

@@ -136,8 +136,8 @@ int gan_weights_prepare_multi(const void* entries_dev, int32_t n, int32_t total_
  * TF form and its NK copies rewritten in the same pass.  gan_adam_begin must have run this step; non-kernel parameters
  * (norm scales/offsets, biases) are updated with gan_adam_tf.  All four buffers 16-byte aligned. */
 int gan_adam_prepare_multi(const void* entries_dev, int32_t n, int32_t total_tiles, int32_t dtype, float* master, float* m,
-                           float* v, const float* grad, const float* lr_t, float beta1, float beta2, float eps,
-                           float grad_scale, const float* scale_state, gan_stream_t stream);
+                           float* v, const void* grad, const float* lr_t, float beta1, float beta2, float eps,
+                           float grad_scale, const float* scale_state, int32_t grad_bf16, gan_stream_t stream);
 
 /* ---- normalisation + activation ------------------------------------------------------------- */
 typedef struct GanNormDesc {
@@ -243,8 +243,11 @@ int gan_sum3(const float* a, const float* b, const float* c, float* out, int32_t
  * m += (g-m)(1-b1); v += (g*g-v)(1-b2); p -= lr_t*m/(sqrt(v)+eps).  `step` is a device counter:
  * gan_adam_begin increments it and writes lr_t, so a captured graph advances correctly on replay. */
 int gan_adam_begin(int32_t* step, float* lr_t, float lr, float beta1, float beta2, const float* scale_state, gan_stream_t stream);
-int gan_adam_tf(float* param, float* m, float* v, const float* grad, int64_t count, const float* lr_t,
-                float beta1, float beta2, float eps, float grad_scale, const float* scale_state, gan_stream_t stream);
+/* grad: fp32 [count], or with grad_bf16 != 0 the bfloat16 wire buffer of the data-parallel exchange (gan_grad_pack, summed
+ * over ranks): Adam then reads the exchanged gradient where it landed, grad_scale = 1/world (8-byte aligned). */
+int gan_adam_tf(float* param, float* m, float* v, const void* grad, int64_t count, const float* lr_t,
+                float beta1, float beta2, float eps, float grad_scale, const float* scale_state, int32_t grad_bf16,
+                gan_stream_t stream);
 
 /* Dynamic loss scaling for the fp16 path (GAN_F16; the reference trains in fp32 and has none - this is what
  * tf.keras.mixed_precision.LossScaleOptimizer would add around base_gan.py:247-252).  scale_state: 4 floats on the

@@ -196,7 +196,7 @@ def test_loss_scale_state_machine():
         assert lib.gan_grads_check(grad.data_ptr(), n, ls.data_ptr(), st) == 0
         assert lib.gan_adam_begin(step.data_ptr(), lr_t.data_ptr(), 2e-4, 0.5, 0.999, ls.data_ptr(), st) == 0
         assert lib.gan_adam_tf(p.data_ptr(), m.data_ptr(), v.data_ptr(), grad.data_ptr(), n, lr_t.data_ptr(), 0.5, 0.999, 1e-7, 1.0,
-                               ls.data_ptr(), st) == 0
+                               ls.data_ptr(), 0, st) == 0
         assert lib.gan_loss_scale_update(ls.data_ptr(), 2, 65536.0, st) == 0
         torch.cuda.synchronize()
 

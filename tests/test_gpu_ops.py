@@ -507,7 +507,7 @@ def test_adam_tf_and_weight_prep(ctx):
         gt = torch.from_numpy(g).to(ctx.device)
         assert ctx.lib.gan_adam_begin(step.data_ptr(), lr_t.data_ptr(), 2e-4, 0.5, 0.999, None, ctx.stream()) == 0
         assert ctx.lib.gan_adam_tf(p.data_ptr(), m.data_ptr(), v.data_ptr(), gt.data_ptr(), n, lr_t.data_ptr(), 0.5, 0.999,
-                                   1e-7, 1.0, None, ctx.stream()) == 0
+                                   1e-7, 1.0, None, 0, ctx.stream()) == 0
         opt.apply(P, {'w': g.astype(np.float64)})
     torch.cuda.synchronize()
     assert step.item() == 3
@@ -611,11 +611,34 @@ def test_fused_adam_prepare_equals_adam_then_prepare(ctx):
     arr = (L.GanPrepEntry * len(ents))(*ents)
     table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(ctx.device)
     assert ctx.lib.gan_adam_prepare_multi(table.data_ptr(), len(ents), tiles, ctx.dt, master.data_ptr(), m.data_ptr(), v.data_ptr(),
-                                          g.data_ptr(), lr_t.data_ptr(), 0.5, 0.999, 1e-7, 0.5, None, ctx.stream()) == 0
+                                          g.data_ptr(), lr_t.data_ptr(), 0.5, 0.999, 1e-7, 0.5, None, 0, ctx.stream()) == 0
     # reference: plain Adam over the flat buffer, then the stand-alone prep of every tensor
     assert ctx.lib.gan_adam_tf(ref[0].data_ptr(), ref[1].data_ptr(), ref[2].data_ptr(), g.data_ptr(), total, lr_t.data_ptr(),
-                               0.5, 0.999, 1e-7, 0.5, None, ctx.stream()) == 0
+                               0.5, 0.999, 1e-7, 0.5, None, 0, ctx.stream()) == 0
     torch.cuda.synchronize()
+    # the same two entry points reading the gradient from a bf16 wire buffer (data-parallel exchange) = fp32 Adam on the
+    # bf16-rounded gradient, bit for bit
+    gw = g.to(torch.bfloat16)
+    gr = gw.float()
+    a1 = [t.clone() for t in ref]
+    a2 = [t.clone() for t in ref]
+    a3 = [t.clone() for t in ref]
+    assert ctx.lib.gan_adam_tf(a1[0].data_ptr(), a1[1].data_ptr(), a1[2].data_ptr(), gw.data_ptr(), total, lr_t.data_ptr(),
+                               0.5, 0.999, 1e-7, 0.5, None, 1, ctx.stream()) == 0
+    assert ctx.lib.gan_adam_tf(a2[0].data_ptr(), a2[1].data_ptr(), a2[2].data_ptr(), gr.data_ptr(), total, lr_t.data_ptr(),
+                               0.5, 0.999, 1e-7, 0.5, None, 0, ctx.stream()) == 0
+    ents3 = [L.GanPrepEntry(a3[0].data_ptr() + 4 * o, None, None, A, B, e.tile_start, e.tiles_b)      # (no NK copies here)
+             for (A, B), o, e in zip(shapes, offs, ents)]
+    table3 = torch.frombuffer(bytearray(bytes((L.GanPrepEntry * len(ents3))(*ents3))), dtype=torch.uint8).to(ctx.device)
+    assert ctx.lib.gan_adam_prepare_multi(table3.data_ptr(), len(ents3), tiles, ctx.dt, a3[0].data_ptr(), a3[1].data_ptr(), a3[2].data_ptr(),
+                                          gw.data_ptr(), lr_t.data_ptr(), 0.5, 0.999, 1e-7, 0.5, None, 1, ctx.stream()) == 0
+    torch.cuda.synchronize()
+    for x, y in zip(a1, a2):
+        assert torch.equal(x, y)
+    for (A, B), o in zip(shapes, offs):
+        sl = slice(o, o + 16 * A * B)
+        for x, y in zip(a3, a2):
+            assert torch.equal(x[sl], y[sl]), (A, B)
     for (A, B), o, nat, tr in zip(shapes, offs, nats, trs):
         sl = slice(o, o + 16 * A * B)
         for got, want in zip((master, m, v), ref):

@@ -286,9 +286,9 @@ def test_ddp_schedules_match_single_graph(buckets, monkeypatch):
     if buckets == '1':
         P = st2.G.params
         o4, ou = P.entries['down4.kernel'][0], P.entries['up0.kernel'][0]
-        # decoder | down7..4 | down3..0 | G vectors | D, every element of both networks exactly once
-        assert starts == [('start', 0, ou, P.vec_start), ('start', 0, o4, ou), ('start', 0, 0, o4),
-                          ('start', 0, P.vec_start, P.total), ('start', 1, 0, st2.D.params.total)]
+        # D | decoder | down7..4 | down3..0 | G vectors, every element of both networks exactly once
+        assert starts == [('start', 1, 0, st2.D.params.total), ('start', 0, ou, P.vec_start), ('start', 0, o4, ou), ('start', 0, 0, o4),
+                          ('start', 0, P.vec_start, P.total)]
         assert [c for c in st2.sync.calls if c[0] == 'wait'] != []
     else:
         assert starts == [('start_all', 0), ('start_all', 1)]            # G's exchange starts before D's pass
@@ -314,7 +314,9 @@ def _ddp_gpu_worker(rank, world, port, q, bf16_wire=False):
         ps.m.zero_(); ps.v.zero_(); ps.step.zero_()
     replay(torch.from_numpy(inp[sl]).to(ctx.device), torch.from_numpy(tar[sl]).to(ctx.device))
     torch.cuda.synchronize()
-    q.put((rank, st.G.params.grad.cpu().numpy() * st.sync.grad_scale, st.G.params.master.cpu().numpy(), st.D.params.master.cpu().numpy()))
+    # the exchanged mean gradient: in place (fp32 wire, x 1/world by Adam) or in the bf16 wire buffer Adam reads from
+    gmean = (st.sync.wire[0].float() / world) if bf16_wire else st.G.params.grad / world
+    q.put((rank, gmean.cpu().numpy(), st.G.params.master.cpu().numpy(), st.D.params.master.cpu().numpy()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -353,6 +355,83 @@ def test_ddp_two_ranks_equal_sharded_single_process(bf16_wire):
         acc = g if acc is None else acc + g
     ref = acc / 2
     assert np.abs(res[0][1] - ref).max() <= (1e-2 if bf16_wire else 1e-5) * np.abs(ref).max()
+
+
+def _rccl_one_rank_worker(port, q, model):
+    import os
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1')
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda:0'))
+    from gan_amd.ddp import GradSync
+    from gan_amd.nets import Ctx
+    from gan_amd.steps import CycleGANStep, Pix2PixStep
+    out = {}
+    for wire in ('f32', 'bf16'):
+        res = []
+        for ddp in (False, True):
+            ctx = Ctx('cuda:0', 'bf16')
+            st = Pix2PixStep(ctx, 2, 256, 1, lam=100.0, seed=123) if model == 'pix2pix' else CycleGANStep(ctx, 1, 256, 1, lam=10.0, seed=123)
+            if ddp:
+                st.sync = GradSync([n.params.grad for n in st.nets()], compress_bf16=(wire == 'bf16'), lib=ctx.lib, rehearse=True)
+                assert st.sync.active and st.sync.world == 1
+            g = torch.Generator(device='cpu').manual_seed(5)
+            x = [(torch.rand(st.B, 256, 256, 1, generator=g) * 2 - 1).to(ctx.device) for _ in range(2)]
+            w0 = [n.params.master.clone() for n in st.nets()]
+            replay = st.capture(training=True)
+            for n_, w_ in zip(st.nets(), w0):          # capture ran warm-up steps: same start for both schedules
+                n_.params.master.copy_(w_); n_.params.prepare()
+                n_.params.m.zero_(); n_.params.v.zero_(); n_.params.step.zero_()
+            for call in vars(st).values():             # ... and the same dropout draws
+                if hasattr(call, 'mask_draws'):
+                    call.mask_draws.zero_()
+            replay(*x)
+            torch.cuda.synchronize()
+            bucketed_wire = ddp and st.sync.compress and model == 'pix2pix'      # Adam read the exchanged gradient from the wire buffer
+            first = ([(st.sync.wire[i].float().cpu().numpy() if bucketed_wire else n.params.grad.cpu().numpy() * (st.sync.grad_scale if ddp else 1.0))
+                      for i, n in enumerate(st.nets())],
+                     [n.params.master.cpu().numpy() for n in st.nets()])
+            for _ in range(2):
+                replay(*x)
+            torch.cuda.synchronize()
+            res.append(([n.params.master.cpu().numpy() for n in st.nets()], st.losses.cpu().numpy().copy(),
+                        len(getattr(st, '_graphs', ())), first))
+        out[wire] = res
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put(out)
+
+
+@pytest.mark.parametrize("model", ['pix2pix', 'cyclegan'])
+def test_ddp_schedule_over_rccl_with_one_rank(model):
+    """The whole data-parallel path over the real backend on the one GPU of the test box: RCCL communicator of ONE rank
+    (all-reduce = identity), graphs captured while its watchdog thread is alive, asynchronous bucket collectives on the
+    communicator's stream between graph replays, Adam graphs behind `work.wait()` on a side stream, both wire formats.
+    fp32 wire: three steps end in the weights of the one-GPU graph.  bf16 wire: after the first step the gradients agree to
+    bf16 rounding and the weights to 1e-6 (Adam's first update is lr * sign(g)); later steps drift apart legitimately - at
+    batch 2 the BatchNorm bottleneck layers amplify a 2e-7 weight difference into sign flips of noise-level gradients."""
+    import os
+    import torch.multiprocessing as mp
+    mpc = mp.get_context('spawn')
+    q = mpc.Queue()
+    p = mpc.Process(target=_rccl_one_rank_worker, args=(29900 + os.getpid() % 1000 + (7 if model == 'cyclegan' else 0), q, model))
+    p.start()
+    out = q.get(timeout=900)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    for wire in ('f32', 'bf16'):
+        (w_one, l_one, n_one, f_one), (w_ddp, l_ddp, n_ddp, f_ddp) = out[wire]
+        assert n_one == 3 and n_ddp == (8 if model == 'pix2pix' else 3)       # bucketed: 4 compute + 4 Adam graphs
+        assert np.allclose(l_one, l_ddp, rtol=2e-2 if wire == "bf16" else 1e-5), (wire, l_one, l_ddp)      # (third step)
+        for ga, gb in zip(f_one[0], f_ddp[0]):            # gradients of the first step, every network
+            rel = np.linalg.norm(ga - gb) / np.linalg.norm(ga)
+            assert rel <= (4e-3 if wire == 'bf16' else 1e-6), (wire, float(rel))
+        for a, b in zip(f_one[1], f_ddp[1]):              # weights after the first step
+            assert np.abs(a - b).max() <= 1e-6, (wire, float(np.abs(a - b).max()))
+        for a, b in zip(w_one, w_ddp):                    # after three steps
+            assert np.isfinite(b).all()
+            if wire == 'f32':
+                assert np.abs(a - b).max() <= 1e-6, float(np.abs(a - b).max())
 
 
 @pytest.mark.parametrize("size,channels,batch", [(256, 3, 2), (512, 1, 1)])
