@@ -88,16 +88,19 @@ class GradSync:
         self.pack(i)
         self._pending.append((i, self.start(i)))
 
-    def finish(self):
+    def finish(self, unpack=True):
+        """Wait for the pending whole-buffer exchanges; unpack=False leaves the result in the wire buffers (Adam reads it
+        there, gan_amd/steps.py) instead of casting it back into the fp32 gradient buffers."""
         for i, h in self._pending:
             self.wait(h)
-            self.unpack(i)
+            if unpack:
+                self.unpack(i)
         self._pending = []
 
-    def __call__(self):
+    def __call__(self, unpack=True):
         for i in range(len(self.bufs)):
             self.start_all(i)
-        self.finish()
+        self.finish(unpack)
 
 
 def shard_batch(global_batch, rank, world):

@@ -56,12 +56,23 @@ class _StepBase:
         self._updating = False
         if training:
             if self.sync is not None:
-                self.sync()                       # data-parallel gradient exchange (RCCL)
+                self.sync(unpack=not self._wire_adam())    # data-parallel gradient exchange (RCCL)
             self._update()
         return self.losses
 
+    def _wire_adam(self):
+        """Data-parallel, bf16 wire: Adam reads the exchanged gradient from the wire buffers (no unpack pass).  Not with fp16
+        loss scaling: its inf/nan check must see the EXCHANGED gradients (every rank takes the same skip decision), which
+        the unpacked fp32 buffers hold."""
+        s_ = self.sync
+        return s_ is not None and getattr(s_, 'compress', False) and getattr(s_, 'wire', None) is not None and self.ctx.ls is None
+
     def _update(self):
         gs = self.sync.grad_scale if self.sync is not None else 1.0
+        wire = self._wire_adam()
+        if wire:
+            gs = 1.0 / self.sync.world
+        wp = lambda net: (self.sync.wire[self.nets().index(net)].data_ptr() if wire else None)
         early, done = getattr(self, '_early_adam', None), getattr(self, '_adam_done', ())
         ctx = self.ctx
         if ctx.ls is not None:        # fp16: a non-finite gradient anywhere skips the whole step (every network), then the scale adapts
@@ -73,11 +84,11 @@ class _StepBase:
             if net is early:       # some kernel segments were updated beside the backward pass: the rest + the vectors
                 rest = [k for k in range(len(net.params._segments)) if k not in self._early_segs]
                 for j, k in enumerate(rest):
-                    self.ctx.run(net.params.adam_segment_ops(k, self.b1, self.b2, grad_scale=gs, vectors=(j == len(rest) - 1)))
+                    self.ctx.run(net.params.adam_segment_ops(k, self.b1, self.b2, grad_scale=gs, vectors=(j == len(rest) - 1), wire_ptr=wp(net)))
                 if not rest:
-                    self.ctx.run(net.params.adam_segment_ops(0, self.b1, self.b2, grad_scale=gs, vectors=True)[1:])
+                    self.ctx.run(net.params.adam_segment_ops(0, self.b1, self.b2, grad_scale=gs, vectors=True, kernels=False, wire_ptr=wp(net)))
             else:
-                net.params.adam(self.lr, self.b1, self.b2, grad_scale=gs)
+                net.params.adam(self.lr, self.b1, self.b2, grad_scale=gs, wire_ptr=wp(net))
         if ctx.ls is not None:
             L.check(ctx.lib.gan_loss_scale_update(ctx.ls_ptr, ctx.ls_growth_interval, ctx.ls_max, ctx.stream()), "loss_scale_update")
         self._early_adam, self._adam_done = None, ()
@@ -133,7 +144,7 @@ class _StepBase:
                 g2.replay()
                 for i in late:
                     self.sync.start_all(i)
-                self.sync.finish()
+                self.sync.finish(unpack=not self._wire_adam())
                 g3.replay()
             return self.losses
         return replay

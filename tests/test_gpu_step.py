@@ -255,10 +255,10 @@ class _FakeSync:
     def start_all(self, i):
         self.calls.append(('start_all', i))
 
-    def finish(self):
+    def finish(self, unpack=True):
         self.calls.append(('finish',))
 
-    def __call__(self):
+    def __call__(self, unpack=True):
         pass
 
 
