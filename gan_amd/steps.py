@@ -396,17 +396,45 @@ class Pix2PixStep(_StepBase):
         def a3():
             PD.adam(self.lr, self.b1, self.b2, grad_scale=gs, wire_ptr=wp[1])
 
-        merge34 = os.environ.get('GAN_AMD_DDP_MERGE34', '0') == '1'      # one graph boundary less, bucket 1 leaves later
+        # The four logical stages can be captured as fewer graphs: GAN_AMD_DDP_GRAPHS = 4 (one per stage; default: every
+        # bucket leaves as early as it can), 3 (stages 3+4 together) or 2 (1+2 | 3+4).  On the one-rank rehearsal the three
+        # are within noise of each other (3.57-3.65 ms): the boundaries (~50 us of drained lanes each) are not what the
+        # schedule costs.  A bucket leaves at the end of the graph that holds its stage.
+        stages_fn = (g1, g2, g3, g4)
+        base_plan = {0: [(4, 3)], 1: [(0, 0)], 2: [(1, 1)], 3: [(2, None), (3, 2)]}
+        grouping = {'4': [[0], [1], [2], [3]], '3': [[0], [1], [2, 3]], '2': [[0, 1], [2, 3]]}[os.environ.get('GAN_AMD_DDP_GRAPHS', '4')]
 
-        def g34():
-            g3(); g4()
+        def group_fn(idx):
+            def f():
+                for k in idx:
+                    stages_fn[k]()
+            return f
 
-        G = [graph(f) for f in ((g1, g2, g34) if merge34 else (g1, g2, g3, g4))]
+        G = [graph(group_fn(idx)) for idx in grouping]
         A = [graph(f) for f in (a0, a1, a2, a3)]
         self._graphs = tuple(G + A)
-        # after G_k: which buckets leave, and which Adam graph follows each of them
-        plan = ({0: [(4, 3)], 1: [(0, 0)], 2: [(1, 1), (2, None), (3, 2)]} if merge34 else
-                {0: [(4, 3)], 1: [(0, 0)], 2: [(1, 1)], 3: [(2, None), (3, 2)]})
+        # after G_j: which buckets leave, and which Adam graph follows each of them
+        plan = {j: [x for k in idx for x in base_plan[k]] for j, idx in enumerate(grouping)}
+        # Host order matters: a compute graph is enqueued BEFORE the collectives / Adam graphs of the boundary behind it are
+        # issued (they hang off an event recorded at that boundary, on their own launcher stream), so the GPU never waits
+        # for the host's communicator calls between two compute graphs (that was ~50 us of idle chip per boundary).
+        evs = [torch.cuda.Event() for _ in G]
+        comm = torch.cuda.Stream(device=ctx.device)
+        late = os.environ.get('GAN_AMD_DDP_LATE_COMM', '1') == '1'
+
+        def boundary(k):
+            todo = plan.get(k, ())
+            if not todo:
+                return
+            comm.wait_event(evs[k])
+            with torch.cuda.stream(comm):
+                started = [(sync.start(*self.buckets[b]), ai) for b, ai in todo]
+            lane4.wait_event(evs[k])                       # (the Adam graphs also read what the compute graphs wrote)
+            with torch.cuda.stream(lane4):
+                for h, ai in started:
+                    sync.wait(h)                           # lane 4 waits for the collective; the host does not
+                    if ai is not None:
+                        A[ai].replay()
 
         def replay(*inputs):
             for dst, src in zip(self._static_in, inputs):
@@ -415,14 +443,13 @@ class Pix2PixStep(_StepBase):
             cur = torch.cuda.current_stream(ctx.device)
             for k, gr in enumerate(G):
                 gr.replay()
-                started = [(sync.start(*self.buckets[b]), ai) for b, ai in plan.get(k, ())]
-                if started:
-                    lane4.wait_stream(cur)                 # (the Adam graphs also read what the compute graphs wrote)
-                    with torch.cuda.stream(lane4):
-                        for h, ai in started:
-                            sync.wait(h)                   # lane 4 waits for the collective; the host does not
-                            if ai is not None:
-                                A[ai].replay()
+                evs[k].record(cur)
+                if not late:
+                    boundary(k)
+                elif k > 0:
+                    boundary(k - 1)
+            if late:
+                boundary(len(G) - 1)
             ctx.join(cur, lane4)
             return self.losses
         return replay

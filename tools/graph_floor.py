@@ -46,3 +46,19 @@ for lanes in (1, 2, 4):
 st = torch.cuda.current_stream().cuda_stream
 t = timed(lambda: chain(N, st, 0), reps=5)
 print(f"stream launches from python/ctypes: {t/N*1e6:.2f} us per kernel")
+
+# cost of a graph boundary: K graphs of N/K dependent tiny kernels replayed back to back on one stream
+for parts in (1, 2, 4, 8):
+    gs = []
+    for _ in range(parts):
+        g = torch.cuda.CUDAGraph()
+        cap = torch.cuda.Stream()
+        with torch.cuda.stream(cap):
+            with torch.cuda.graph(g, stream=cap):
+                chain(N // parts, cap.cuda_stream, 0)
+        gs.append(g)
+    def run():
+        for g in gs:
+            g.replay()
+    t = timed(run)
+    print(f"{parts} graph(s) of {N // parts} kernels back to back: {t*1e3:.3f} ms")
