@@ -45,7 +45,7 @@ class GanConvDesc(_Desc):
     _fields_ = [("struct_size", C.c_uint32), ("dtype", C.c_int32), ("stride", C.c_int32), ("x", GanTensor), ("y", GanTensor), ("w", C.c_void_p),
                 ("w_rows", C.c_int32), ("bias", C.c_void_p), ("act", C.c_int32), ("slope", C.c_float),
                 ("y_f32", C.c_int32), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
-                ("stats_partial", C.c_void_p), ("stats_groups", C.c_int32), ("bwd_fuse", C.c_void_p)]
+                ("stats_partial", C.c_void_p), ("stats_groups", C.c_int32), ("stats_partial_bytes", C.c_size_t), ("bwd_fuse", C.c_void_p)]
 
 
 class GanWgradDesc(_Desc):

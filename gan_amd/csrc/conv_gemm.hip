@@ -1133,6 +1133,8 @@ static int run_gemm(const GanConvDesc* d, int op, gan_stream_t stream) {
   hipStream_t st = (hipStream_t)stream;
   const int fam = thin_family(d, op, pl.p);
   if (pl.bf_requested && (fam || !pl.p.bf_mode)) return GAN_E_SHAPE;   // the caller must consult gan_conv_plan_info()[4] first
+  if (!fam && pl.p.stats && (size_t)d->stats_groups * pl.stats_chunks * pl.p.stats_C * 2 * sizeof(float) > d->stats_partial_bytes)
+    return GAN_E_WORKSPACE;                                            // the caller's partial-sums region is too small for this plan
   if (fam) return thin_launch(fam, d, pl.p, st);   // <= 8-channel streaming layers
   if (pl.slab_bytes > d->workspace_bytes || (pl.slab_bytes && !d->workspace)) return GAN_E_WORKSPACE;
   return d->dtype == GAN_F32 ? launch_gemm<float>(pl, st) : d->dtype == GAN_F16 ? launch_gemm<f16_t>(pl, st) : launch_gemm<bf16_t>(pl, st);

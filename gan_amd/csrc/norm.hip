@@ -470,6 +470,7 @@ int gan_norm_stats_finalize(const GanNormDesc* d, int32_t chunks, gan_stream_t s
   RedGeom g;
   int rc = red_geom(d->y, d->groups, d->dtype, &g);
   if (rc) return rc;
+  if ((size_t)d->groups * chunks * g.C * 2 * sizeof(float) > d->workspace_bytes) return GAN_E_WORKSPACE;   // the producer's partials
   hipLaunchKernelGGL(stats_finalize_kernel, dim3((g.C + FC - 1) / FC, d->moving_mean ? 1 : d->groups), dim3(256), 0, (hipStream_t)stream,
                      (const float*)d->workspace, d->groups, chunks, g.C, g.rows_per_group, d->eps, d->mean, d->rstd,
                      d->moving_mean, d->moving_var, d->momentum);

@@ -376,7 +376,7 @@ class _Builder:
             self.keep.append(bwd_fuse[0])
             stats_groups = bwd_fuse[1]
         d = L.GanConvDesc(self.ctx.dt, stride, x, y, w, w_rows, bias, L.ACTS[act], LEAKY_ALPHA, y_f32,
-                          self.ws_ptr, self.ws_bytes, self.ws_ptr if stats_groups else None, stats_groups,
+                          self.ws_ptr, self.ws_bytes, self.ws_ptr if stats_groups else None, stats_groups, 0,
                           C.addressof(bwd_fuse[0]) if bwd_fuse is not None else None)
         opi = {'conv_fwd': 0, 'conv_dgrad': 1, 'convT_fwd': 2, 'convT_dgrad': 3}[op]
         fn = [self.lib.gan_conv2d_fwd, self.lib.gan_conv2d_dgrad, self.lib.gan_convT2d_fwd, self.lib.gan_convT2d_dgrad][opi]
@@ -387,6 +387,7 @@ class _Builder:
         self.last_stats_ptr = self.ws_ptr + (need + 255) // 256 * 256
         if stats_groups:
             d.stats_partial = self.last_stats_ptr
+            d.stats_partial_bytes = self.ws_bytes - (self.last_stats_ptr - self.ws_ptr)
         info = (C.c_int32 * 5)()
         self.lib.gan_conv_plan_info(C.byref(d), opi, info)
         self.last_bwd_fused = 0

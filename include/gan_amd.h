@@ -82,6 +82,7 @@ typedef struct GanConvDesc {
   size_t workspace_bytes;
   float* stats_partial;  /* optional: fused normalisation statistics — per-tile (sum, sum^2) partials of y,   */
   int32_t stats_groups;  /* laid out [group][chunk][y.c][2]; emitted only if gan_conv_plan_info()[4] > 0     */
+  size_t stats_partial_bytes; /* size of that region: groups * chunks * channels * 8 bytes are written (GAN_E_WORKSPACE if short) */
   const GanBwdFuse* bwd_fuse; /* optional (dgrad entry points only), see above */
 } GanConvDesc;
 

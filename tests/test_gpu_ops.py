@@ -166,7 +166,7 @@ def test_conv_epilogue_statistics_partials(ctx, case):
     yb = Buf(ctx, N, Ho, Ho, co)
     part = torch.full((4 << 20,), 9.0, dtype=torch.float32, device=ctx.device)
     d = L.GanConvDesc(ctx.dt, 2, xv, yb.view(), (tr if op == 'conv_fwd' else nat).data_ptr(), co, None, 0, 0.3, 0,
-                      ctx.ws_ptr, ctx.ws_bytes, part.data_ptr(), groups)
+                      ctx.ws_ptr, ctx.ws_bytes, part.data_ptr(), groups, part.numel() * 4)
     opi = 0 if op == 'conv_fwd' else 2
     info = (C.c_int32 * 5)()
     assert ctx.lib.gan_conv_plan_info(C.byref(d), opi, info) == 0
@@ -178,6 +178,9 @@ def test_conv_epilogue_statistics_partials(ctx, case):
     got = part[:groups * chunks * co * 2].cpu().numpy().reshape(groups, chunks, co, 2).astype(np.float64).sum(1)
     y = host(yb).reshape(groups, -1, co)
     assert rel(got[..., 0], y.sum(1)) < 1e-4 and rel(got[..., 1], (y * y).sum(1)) < 1e-4
+    # a partial-sums region that is too small for the plan is refused, not overrun
+    d.stats_partial_bytes = groups * chunks * co * 8 - 4
+    assert fn(C.byref(d), ctx.stream()) == -3                 # GAN_E_WORKSPACE
 
 
 def test_thin_layers_take_streaming_kernels():
@@ -276,7 +279,7 @@ def test_dgrad_fused_backward_epilogue(ctx, case, monkeypatch):
                       gamma.data_ptr() if norm else None, beta.data_ptr() if norm else None, tm.data_ptr() if tm is not None else None,
                       cols, L.ACTS[act], 0.3, cols)
     d1 = L.GanConvDesc(ctx.dt, 2, dyv, dz_b.view(), wt.data_ptr(), wrows, None, 0, 0.3, 0, ctx.ws_ptr, ctx.ws_bytes,
-                       part.data_ptr() if norm else None, G if norm else 0, C.addressof(bf))
+                       part.data_ptr() if norm else None, G if norm else 0, part.numel() * 4, C.addressof(bf))
     info = (C.c_int32 * 5)()
     assert ctx.lib.gan_conv_plan_info(C.byref(d1), opi, info) == 0
     chunks = info[4]
@@ -302,7 +305,7 @@ def test_dgrad_fused_backward_epilogue(ctx, case, monkeypatch):
     # a launch shape that cannot carry the epilogue refuses it instead of silently dropping it
     if norm and G == 1:
         d2 = L.GanConvDesc(ctx.dt, 2, dyv, dz_b.view(), wt.data_ptr(), wrows, None, 0, 0.3, 0, ctx.ws_ptr, ctx.ws_bytes,
-                           part.data_ptr(), 3, C.addressof(bf))      # 3 groups do not divide the batch
+                           part.data_ptr(), 3, part.numel() * 4, C.addressof(bf))      # 3 groups do not divide the batch
         assert ctx.lib.gan_conv_plan_info(C.byref(d2), opi, info) == 0 and info[4] == 0
         assert fn(C.byref(d2), ctx.stream()) == -2            # GAN_E_SHAPE
         torch.cuda.synchronize()

@@ -24,7 +24,7 @@ w = (torch.randn(16, co, ci, device='cuda') * 0.05).to(ctx.tdtype)
 x.t.copy_(torch.randn_like(x.t.float()).to(ctx.tdtype))
 stats = int(os.environ.get('STATS', '0'))
 d = L.GanConvDesc(ctx.dt, s, x.view(), y.view(), w.data_ptr(), co, None, 0, 0.3, 0, ctx.ws_ptr, ctx.ws_bytes,
-                  ctx.ws_lanes[1].data_ptr() if stats else None, stats)
+                  ctx.ws_lanes[1].data_ptr() if stats else None, stats, ctx.ws_lanes[1].numel())
 fn = [lib.gan_conv2d_fwd, lib.gan_conv2d_dgrad, lib.gan_convT2d_fwd, lib.gan_convT2d_dgrad][opi]
 info = (C.c_int32 * 5)(); lib.gan_conv_plan_info(C.byref(d), opi, info)
 diag = torch.zeros(1 << 16, 16, dtype=torch.int64, device='cuda')
