@@ -51,7 +51,7 @@ class GanConvDesc(_Desc):
 class GanWgradDesc(_Desc):
     _fields_ = [("struct_size", C.c_uint32), ("dtype", C.c_int32), ("stride", C.c_int32), ("big", GanTensor), ("small", GanTensor),
                 ("dw", C.c_void_p), ("big_c", C.c_int32), ("small_c", C.c_int32), ("accumulate", C.c_int32),
-                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("concurrent", C.c_int32)]
 
 
 class GanNormDesc(_Desc):

@@ -296,8 +296,11 @@ static int plan_wgrad(const GanWgradDesc* d, WgradPlan* pl, bool allow_swap = tr
     // big reductions on 16-bit storage: the 256 x 256 ping-pong kernel (rows = (tap, channel) pairs in units of 64)
     static int use_pp = -1;
     if (use_pp < 0) { const char* e = getenv("GAN_AMD_WGRAD_PP"); use_pp = e ? atoi(e) : 1; }
-    static int min_rows = -1;
-    if (min_rows < 0) { const char* e = getenv("GAN_AMD_WGRAD_PP_MINROWS"); min_rows = e ? atoi(e) : 1024; }
+    // reduction rows per split at least: 1024 alone on the chip; 2048 when the launch shares it with other lanes (~128 blocks with
+    // longer K loops and half the slab traffic: slower alone, +1.3 % in the captured Pix2Pix step; GAN_AMD_WGRAD_PP_MINROWS overrides)
+    static int min_rows_env = -1;
+    if (min_rows_env < 0) { const char* e = getenv("GAN_AMD_WGRAD_PP_MINROWS"); min_rows_env = e ? atoi(e) : 0; }
+    const int min_rows = min_rows_env > 0 ? min_rows_env : (d->concurrent ? 2048 : 1024);
     static int pp128 = -1, mingf = -1;
     if (pp128 < 0) { const char* e = getenv("GAN_AMD_WGRAD_PP128"); pp128 = e ? atoi(e) : 0; }
     if (mingf < 0) { const char* e = getenv("GAN_AMD_WGRAD_PP_MINGF"); mingf = e ? atoi(e) : 30; }
@@ -328,7 +331,9 @@ static int plan_wgrad(const GanWgradDesc* d, WgradPlan* pl, bool allow_swap = tr
   p.kchunks = (int)((M + bkm - 1) / bkm);
   long long blocks = (long long)tilesA * tilesB * taps;
   int splits = 1;
-  const long long target = p.fold ? 1024 : 512;     // fold mode streams the SMALL tensor once: HBM-bound, wants many blocks
+  static int wtarget = -1;
+  if (wtarget < 0) { const char* e = getenv("GAN_AMD_WGRAD_TARGET"); wtarget = e ? atoi(e) : 512; }
+  const long long target = p.fold ? 1024 : wtarget;     // fold mode streams the SMALL tensor once: HBM-bound, wants many blocks
   if (blocks < target) {
     splits = (int)((target + blocks - 1) / blocks);
     int maxs = p.kchunks / 4; if (maxs < 1) maxs = 1;

@@ -416,7 +416,7 @@ class _Builder:
 
     def wgrad(self, big, small, dw_ptr, big_c, small_c, stride, accumulate):
         d = L.GanWgradDesc(self.ctx.dt, stride, big, small, dw_ptr, big_c, small_c, int(accumulate),
-                           self.ws_side_ptr, self.ws_bytes)
+                           self.ws_side_ptr, self.ws_bytes, int(getattr(self.ctx, 'wgrad_concurrent', False)))
         need = self.lib.gan_wgrad_workspace_bytes(C.byref(d))
         if need > self.ws_bytes:
             raise L.GanAmdError(f"workspace too small for wgrad: need {need}")

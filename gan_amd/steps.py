@@ -155,6 +155,7 @@ class Pix2PixStep(_StepBase):
                  seed=123, dropout=True, nets=None, mask_stream=0):
         self.ctx, self.B, self.S, self.C = ctx, batch, size, channels
         self.lam, self.lr, self.b1, self.b2 = float(lam), lr, beta_1, beta_2
+        ctx.wgrad_concurrent = ctx.ms_mode == 4      # G's wgrad GEMMs run on a side lane beside the main chain: planner hint
         if nets is not None:          # share weights with an existing step / model objects
             self.G, self.D = nets
         else:

@@ -113,6 +113,8 @@ typedef struct GanWgradDesc {
   int32_t accumulate;    /* 1: dw += result (a net called several times per step, cycle_gan.py:252-255) */
   void* workspace;
   size_t workspace_bytes;
+  int32_t concurrent;    /* scheduling hint: nonzero = this launch shares the GPU with other streams' kernels (a side lane of a
+                            captured step); the planner then prefers half-chip grids with longer reductions (less slab traffic) */
 } GanWgradDesc;
 /* Kernel gradient of Conv2D / Conv2DTranspose (GradientTape.gradient w.r.t. trainable_variables,
  * pix2pix.py:210-211, cycle_gan.py:252-260). */
