@@ -272,6 +272,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if world > 1 or rehearse:
+        dist.barrier()                     # rank 0 has been profiling alone: every rank leaves the group together
         dist.destroy_process_group()
 
 
