@@ -1152,7 +1152,8 @@ int gan_conv2d_dgrad(const GanConvDesc* d, gan_stream_t s) { return run_gemm(d, 
 int gan_convT2d_fwd(const GanConvDesc* d, gan_stream_t s) { return run_gemm(d, 2, s); }
 int gan_convT2d_dgrad(const GanConvDesc* d, gan_stream_t s) { return run_gemm(d, 3, s); }
 int gan_conv_plan_info(const GanConvDesc* d, int op, int32_t* info /*[5]: BM, BN, splits, parities, stats chunks*/) {
-  GemmPlan pl;
+  if (!d || !info || d->struct_size != sizeof(GanConvDesc)) return GAN_E_ARG;    // before the copy: a caller built against a
+  GemmPlan pl;                                                                    // smaller struct must not be read past its end
   GanConvDesc t = *d;
   plan_only_desc(&t);
   int rc = plan_gemm(&t, op, &pl);
@@ -1163,6 +1164,7 @@ int gan_conv_plan_info(const GanConvDesc* d, int op, int32_t* info /*[5]: BM, BN
   return 0;
 }
 size_t gan_conv_workspace_bytes(const GanConvDesc* d, int op) {
+  if (!d || d->struct_size != sizeof(GanConvDesc)) return 0;
   GemmPlan pl;
   GanConvDesc t = *d;
   plan_only_desc(&t);
