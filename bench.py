@@ -133,6 +133,8 @@ def main():
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--fp32-allreduce', action='store_true', help='exchange gradients as fp32 instead of bf16')
     ap.add_argument('--repeats', type=int, default=5, help='the K-step timed region is run this many times; the median is reported')
+    ap.add_argument('--opt', action='append', default=[], metavar='KEY=VALUE',
+                    help='planner option of the kernel library (gan_set_option, include/gan_amd.h); for A/B runs')
     args = ap.parse_args()
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -178,6 +180,10 @@ def main():
     from gan_amd.ddp import GradSync
     from gan_amd.nets import Ctx, workspace_mb_for
     from gan_amd.steps import CycleGANStep, Pix2PixStep
+    from gan_amd import _lib as _L
+    for kv in args.opt:
+        k, v = kv.split('=', 1)
+        _L.set_option(k, int(v))
     dev = f'cuda:{local}'
     torch.cuda.set_device(local)
     B, S = args.batch, args.img_size

@@ -122,6 +122,8 @@ SYMBOLS = {
     "gan_grad_unpack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p]),
     "gan_crc32c": (C.c_uint32, [C.c_uint32, C.c_void_p, C.c_size_t]),
     "gan_version": (C.c_char_p, []),
+    "gan_set_option": (C.c_int, [C.c_char_p, C.c_int32]),
+    "gan_get_option": (C.c_int, [C.c_char_p, C.POINTER(C.c_int32)]),
 }
 
 _lib = None
@@ -146,6 +148,15 @@ def load():
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+def set_option(key, value):
+    """Planner option of the library (include/gan_amd.h, gan_set_option); returns the previous value."""
+    lib = load()
+    old = C.c_int32()
+    check(lib.gan_get_option(key.encode(), C.byref(old)), f"gan_get_option({key})")
+    check(lib.gan_set_option(key.encode(), int(value)), f"gan_set_option({key})")
+    return old.value
 
 
 def check(rc, what):

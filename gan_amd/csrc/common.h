@@ -79,6 +79,7 @@ template <> __device__ __forceinline__ f32x4 mma16<bf16_t>(const uint4& a, const
 template <> __device__ __forceinline__ f32x4 mma16<f16_t>(const uint4& a, const uint4& b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(*(const f16x8*)&a, *(const f16x8*)&b, c, 0, 0, 0);
 }
+int gan_opt(const char* key);      // planner options (host_util.cpp; changed only by gan_set_option)
 static inline bool gan_dtype_ok(int dtype) { return dtype == GAN_F32 || dtype == GAN_BF16 || dtype == GAN_F16; }
 
 __device__ __forceinline__ float apply_act(float v, int act, float slope) {

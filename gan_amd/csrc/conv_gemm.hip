@@ -131,10 +131,14 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 // the transposed tile: acc[i][j][e] = Y[pixel row i*16 + (lane & 15)][channel j*16 + (lane >> 4)*4 + e] - four
 // consecutive channels of one pixel per lane, which pack into one 8-byte (bf16) / 16-byte (fp32) write.  SMEMB bytes of
 // LDS at `smem` are free for staging (the caller has passed a block barrier after its last LDS read).
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int SMEMB>
+// PARCOLS (conv_par_kernel): the tile's BN = 4 x PCOLS columns are (output parity, channel) pairs - column block v / PCOLS
+// goes to the output pixel of parity v / PCOLS, channel bn0 + v % PCOLS; statistics partials come out as one chunk per parity.
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int SMEMB, bool PARCOLS = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[BM / WAVES_M / 16][BN / WAVES_N / 16],
                                               unsigned char* smem, int bm0, int bn0, int par, int P, int split) {
   constexpr int VEC = VecOf<T>::N;
+  constexpr int PCOLS = PARCOLS ? BN / 4 : BN;               // channels per parity block of columns
+  constexpr int PVECS = PCOLS / VEC;
   constexpr int NW = WAVES_M * WAVES_N, NTHREADS = 64 * NW;
   constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N, MT = WTM / 16, NT = WTN / 16;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -168,7 +172,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
     for (int j = 0; j < NT; ++j)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const int n = bn0 + wn * WTN + j * 16 + q * 4 + e;
+        const int n = bn0 + (wn * WTN + j * 16 + q * 4 + e) % PCOLS;
         bv[j][e] = (p.bias && n < p.Cout) ? p.bias[n] : 0.f;
       }
     // fused normalisation statistics: per-column (sum, sum of squares) of the STORED values of this tile
@@ -180,8 +184,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
 #pragma unroll
     for (int e = 0; e < VEC; ++e) ssum[e] = ssq[e] = 0.f;
     float cmu[VEC], crs[VEC], cga[VEC], cbe[VEC];              // fused backward epilogue: this thread's per-channel constants
-    if (p.bf_mode >= 1 && p.bf_mode <= 3 && bn0 + scg * VEC < p.bf_cols) {
-      const int grp = p.stats_tpg ? (bm0 / BM) / p.stats_tpg : 0, c0 = bn0 + scg * VEC;
+    if (p.bf_mode >= 1 && p.bf_mode <= 3 && bn0 + (scg % PVECS) * VEC < p.bf_cols) {
+      const int grp = p.stats_tpg ? (bm0 / BM) / p.stats_tpg : 0, c0 = bn0 + (scg % PVECS) * VEC;
 #pragma unroll
       for (int e = 0; e < VEC; ++e) {
         cmu[e] = p.bf_mean[grp * p.bf_cols + c0 + e]; crs[e] = p.bf_rstd[grp * p.bf_cols + c0 + e];
@@ -219,10 +223,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
           for (int idx = tid; idx < TOTAL; idx += NTHREADS) {
             const int sr = idx / VPR, v = idx % VPR;             // v == scg for every idx of a thread (NTHREADS % VPR == 0)
             const int g16 = sr >> 4;
-            const int m = bm0 + (g16 / IPP) * WTM + (ip * IPP + g16 % IPP) * 16 + (sr & 15), n = bn0 + v * VEC;
+            const int m = bm0 + (g16 / IPP) * WTM + (ip * IPP + g16 % IPP) * 16 + (sr & 15), n = bn0 + (v % PVECS) * VEC;
             if (m < p.M && n < p.Cout) {
               uint4 raw = *(const uint4*)(Cs + sr * CS + v * 16);
-              const size_t pix = out_pixel_index(p, m, py, px);
+              const size_t pix = PARCOLS ? out_pixel_index(p, m, (v / PVECS) >> 1, (v / PVECS) & 1) : out_pixel_index(p, m, py, px);
               if constexpr (MODE != 0) {
                 if (n < p.bf_cols) {
                   const uint4 rv = *(const uint4*)((const T*)p.bf_ref + pix * (size_t)p.bf_refpitch + n);
@@ -242,7 +246,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
           // fused backward epilogue: the reference / skip / mask vectors of U rows are requested together before any of them
           // is used (one dependent global load per iteration made this loop pure latency: +9..+40 us per launch)
           constexpr int ITERS = TOTAL / NTHREADS, U = ITERS % 4 == 0 ? 4 : (ITERS % 2 == 0 ? 2 : 1);
-          const int n = bn0 + scg * VEC;
+          const int n = bn0 + (scg % PVECS) * VEC;
+          const int cpy = PARCOLS ? (scg / PVECS) >> 1 : py, cpx = PARCOLS ? (scg / PVECS) & 1 : px;
           const bool colok = n < p.Cout, fuse = n < p.bf_cols;
           for (int it0 = 0; it0 < ITERS; it0 += U) {
             uint4 rv[U], av[U]; uint2 mv[U]; size_t pix[U]; bool ok[U];
@@ -251,7 +256,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
               const int sr = (tid + (it0 + u) * NTHREADS) / VPR, g16 = sr >> 4;
               const int m = bm0 + (g16 / IPP) * WTM + (ip * IPP + g16 % IPP) * 16 + (sr & 15);
               ok[u] = m < p.M && colok;
-              pix[u] = ok[u] ? out_pixel_index(p, m, py, px) : 0;
+              pix[u] = ok[u] ? out_pixel_index(p, m, cpy, cpx) : 0;
               rv[u] = av[u] = make_uint4(0, 0, 0, 0); mv[u] = make_uint2(0, 0);
               if (ok[u] && fuse) {
                 rv[u] = *(const uint4*)((const T*)p.bf_ref + pix[u] * (size_t)p.bf_refpitch + n);
@@ -301,13 +306,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
         red[(sslice * BN + scg * VEC + e) * 2] = ssum[e]; red[(sslice * BN + scg * VEC + e) * 2 + 1] = ssq[e];
       }
       __syncthreads();
-      if (tid < BN && bn0 + tid < p.stats_C) {
+      if (tid < BN && bn0 + tid % PCOLS < p.stats_C) {
         float a = 0.f, b = 0.f;
 #pragma unroll
         for (int k = 0; k < SL; ++k) { a += red[(k * BN + tid) * 2]; b += red[(k * BN + tid) * 2 + 1]; }
         // chunk index: (tile within its group) * P + parity; groups are whole numbers of M tiles
-        const int tm = bm0 / BM, grp = tm / p.stats_tpg, chunk = (tm % p.stats_tpg) * P + par;
-        float* dst = p.stats + (((size_t)grp * p.stats_tpg * P + chunk) * p.stats_C + bn0 + tid) * 2;
+        const int tm = bm0 / BM, grp = tm / p.stats_tpg, chunk = (tm % p.stats_tpg) * P + (PARCOLS ? tid / PCOLS : par);
+        float* dst = p.stats + (((size_t)grp * p.stats_tpg * P + chunk) * p.stats_C + bn0 + tid % PCOLS) * 2;
         dst[0] = a; dst[1] = b;
       }
     }
@@ -756,6 +761,186 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(const GemmParams p) {
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------
+// "Parity-patch" kernel for the stride-2 transposed convolutions / stride-2 conv input gradients with few output channels
+// (generator up6 forward, down1 dgrad, PatchGAN down1 dgrad: 64 output channels, K = 4 taps x Cin per output parity).
+//
+// As four separate parity sub-GEMMs these layers stage every input pixel 16 times (4 parities x 4 taps) for 64 columns of
+// output: 51 FLOP per staged byte, a third of what the LDS-DMA path needs to keep the matrix pipe busy.
+// Here ONE block computes all four parities of 256 input-grid positions (R whole image rows) x 64 channels, i.e. 1024 output
+// pixels, from an input PATCH that is staged once per channel chunk: (R+2) x (Wg+2) pixels (a one-pixel halo, zeros outside the
+// map) x 32 channels (64-byte LDS rows).  The 16 (parity, tap) products of a chunk read it at nine different shifts
+//     output (2gy+py, 2gx+px) += x[gy + py - ty, gx + px - tx] . W[1-py+2ty][1-px+2tx],   ty, tx in {0, 1}
+// so an A fragment is an ordinary ds_read_b128 at (pixel + shift) * 64 bytes.  Per chunk 32-40 KB of patch + 64 KB of weights
+// are staged for 16.8 MFLOP: ~170 FLOP per staged byte.
+//
+// Waves: 8 = 2 (row halves of 128) x 4 (parities); a wave's accumulators are 128 rows x 64 channels of ONE parity, the same
+// register tile as the 256x256 ping-pong kernel (8 x 4 MFMA tiles), whose phase structure is kept: a K step = one tap of one
+// chunk = 32 MFMAs per wave; LOAD segment (LDS-DMA issue + 12 fragment reads + counted vmcnt) | barrier | MATH segment |
+// barrier, waves 4..7 one barrier behind waves 0..3.
+//
+// LDS: [B ring: 4 slots (= the 4 taps of a chunk) x 4 parities x 64 columns x 64 B = 64 KB][patch buffer 0][patch buffer 1],
+// a patch buffer = NPW * 8 pieces of 1 KB (16 pixels each).  16-byte slots of a 64-byte row are XOR-swizzled with
+// ((row >> 2) & 1) << 1, which makes the 16-row fragment reads conflict-free at EVERY pixel offset (the shifts move the base).
+// Ordering (s = K step; group 0 runs LOAD(s) in barrier interval 2s, group 1 in 2s+1):
+//   B tiles of step s+2 are issued in LOAD(s) (2 pieces per wave) into ring slot (s+2) % 4, last read in LOAD(s-2): WAR needs
+//     the issue >= 2 phases after the last reading LOAD segment (its reads are only known complete at the reader's lgkmcnt(0));
+//   patch pieces of chunk c+1 are issued in LOAD(4c+1) and LOAD(4c+2) into buffer (c+1) & 1, last read in LOAD(4c-1);
+//   RAW: everything first read in LOAD(s+1) is covered by the vmcnt at the end of LOAD(s) of every wave: at that point only
+//     the pieces issued in LOAD(s) itself may be outstanding (2 B pieces + the patch pieces of that step).
+template <typename T, int NPW>
+__global__ __launch_bounds__(512) void conv_par_kernel(const GemmParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int BM = 256, PC = 64, BN = 4 * PC, CKB = 64;    // rows, channels per parity, virtual columns, bytes of K per LDS row
+  constexpr int BSTEP = 4 * PC * CKB;                        // B tiles of one K step (4 parities): 16 KB
+  constexpr int BRING = 4 * BSTEP;
+  constexpr int PATCH = NPW * 8 * 1024;
+  constexpr int P1 = (NPW + 1) / 2, P2 = NPW / 2;            // patch pieces per wave issued in steps 4c+1 / 4c+2
+  constexpr int ES = sizeof(T);
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  DIAG_STAMP(0);
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, par = wave & 3, py = par >> 1, px = par & 1;
+  const int r = lane & 15, q = lane >> 4;
+
+  int bid = blockIdx.x;
+  const int nb = p.tilesM * p.tilesN;
+  if ((nb & 7) == 0) bid = (bid & 7) * (nb >> 3) + (bid >> 3);
+  const int bm0 = (bid / p.tilesN) * BM, bn0 = (bid % p.tilesN) * PC;
+  const int Wg = p.Wg, PW = Wg + 2;
+  const int lw = 31 - __builtin_clz((unsigned)Wg);           // Wg is a power of two (16..128)
+  const int Rrows = BM >> lw;
+  // tile origin (R whole rows of one image)
+  const int img = bm0 / (p.Hg * Wg), gy0 = (bm0 - img * p.Hg * Wg) >> lw;
+
+  // ---- staging state ---------------------------------------------------------------------------------------------------
+  const int spix = lane >> 2, sslot = lane & 3;              // this lane's pixel / 16-byte slot inside a 1-KB piece
+  int a_src[NPW];                                            // patch pieces wave + 8j: source byte offset of chunk 0, or out of range
+#pragma unroll
+  for (int j = 0; j < NPW; ++j) {
+    const int pp = (wave + 8 * j) * 16 + spix;
+    const int prow = pp / PW, pcol = pp - prow * PW;
+    const int y = gy0 - 1 + prow, x = pcol - 1;
+    int off = (int)0x80000000;
+    if (prow < Rrows + 2 && (unsigned)y < (unsigned)p.Hs && (unsigned)x < (unsigned)p.Ws)
+      off = (int)((((long long)(img * p.Hs + y) * p.Ws + x) * (long long)p.xpitch) * ES) + ((sslot ^ (((pp >> 2) & 1) << 1)) << 4);
+    a_src[j] = off;
+  }
+  int b_src;                                                 // B pieces wave and wave + 8: columns (wave & 3) * 16 + spix of parities (wave >> 2), +2
+  {
+    const int col = (wave & 3) * 16 + spix, n = bn0 + col;
+    b_src = n < p.Wrows ? (int)((size_t)n * p.Cin * ES) + ((sslot ^ (((col >> 2) & 1) << 1)) << 4) : (int)0x80000000;
+  }
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.xbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.wbytes, 0x00020000);
+  const int wtapbytes = p.Wrows * p.Cin * ES;
+  const int nchunks = p.kchunks;                             // channel chunks of CKB bytes
+
+  auto issue_b = [&](auto Tc, int cc) {                      // weights of (chunk cc, tap T) for the 4 parities -> ring slot T
+    constexpr int t = decltype(Tc)::value, ty = t >> 1, tx = t & 1;
+    const bool live = cc < nchunks;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int pb = (wave >> 2) + 2 * h, pyb = pb >> 1, pxb = pb & 1;
+      const int wtap = (1 - pyb + 2 * ty) * 4 + (1 - pxb + 2 * tx);
+      const int off = live ? b_src + wtap * wtapbytes + cc * CKB : (int)0x80000000;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(smem + t * BSTEP + (wave + 8 * h) * 1024), 16, off, 0, 0, 0);
+    }
+  };
+  auto issue_patch = [&](auto J0c, auto CNTc, int cc) {      // pieces wave + 8j, j in [J0, J0 + CNT), of chunk cc
+    constexpr int J0 = decltype(J0c)::value, CNT = decltype(CNTc)::value;
+    const bool live = cc < nchunks;
+    unsigned char* dst = smem + BRING + (cc & 1) * PATCH;
+    static_for<CNT>([&](auto Jc) {
+      constexpr int j = J0 + decltype(Jc)::value;
+      const int off = live ? a_src[j] + cc * CKB : (int)0x80000000;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(dst + (wave + 8 * j) * 1024), 16, off, 0, 0, 0);
+    });
+  };
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // ---- fragment addressing -----------------------------------------------------------------------------------------------
+  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  // B: column j*16 + r of this wave's parity, slot q (swizzle term depends on r only)
+  const unsigned b_row = lds_base + par * (PC * CKB) + r * CKB + (((unsigned)q ^ ((((unsigned)r >> 2) & 1) << 1)) << 4);
+  // A: patch pixel of tile row wr*128 + i*16 + r at shift (0, 0); the 16 rows of a fragment lie in one image row (Wg >= 16)
+  int pixbase[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int ml = wr * 128 + i * 16 + r;
+    pixbase[i] = ((ml >> lw) + 1) * PW + (ml & (Wg - 1)) + 1;
+  }
+
+  DIAG_STAMP(1);
+  // prologue: patch of chunk 0, weights of steps 0 and 1
+  issue_patch(std::integral_constant<int, 0>{}, std::integral_constant<int, NPW>{}, 0);
+  issue_b(std::integral_constant<int, 0>{}, 0);
+  issue_b(std::integral_constant<int, 1>{}, 0);
+  wait_vmcnt<2>();
+  __builtin_amdgcn_s_barrier();
+  DIAG_STAMP(2);
+  if (wr == 1) __builtin_amdgcn_s_barrier();                 // waves 4..7 run one barrier behind
+
+  uint4 af[8], bfr[4];
+  SEG_DECL;
+  SEG_T0;
+  for (int c = 0; c < nchunks; ++c) {
+    const unsigned pbuf = lds_base + BRING + (unsigned)(c & 1) * PATCH;
+    static_for<4>([&](auto Tc) {
+      constexpr int t = decltype(Tc)::value, ty = t >> 1, tx = t & 1;
+      // ---- LOAD segment ----
+      if constexpr (t < 2) issue_b(std::integral_constant<int, t + 2>{}, c);
+      else issue_b(std::integral_constant<int, t - 2>{}, c + 1);
+      if constexpr (t == 1) issue_patch(std::integral_constant<int, 0>{}, std::integral_constant<int, P1>{}, c + 1);
+      if constexpr (t == 2) issue_patch(std::integral_constant<int, P1>{}, std::integral_constant<int, P2>{}, c + 1);
+      SEG_ADD(5);                                            // LDS-DMA issue
+      static_for<4>([&](auto Jc) {
+        constexpr int j = decltype(Jc)::value;
+        lds_read128<t * BSTEP + j * 16 * CKB>(bfr[j], b_row);
+      });
+      int shift = (py - ty) * PW + (px - tx);                // wave-uniform pixel shift of this (parity, tap)
+      asm volatile("" : "+s"(shift));                        // (recomputed per step: hoisted out of the chunk loop, the 32 (tap, fragment) addresses spill)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const unsigned pix = (unsigned)(pixbase[i] + shift);
+        const unsigned addr = pbuf + (pix << 6) + ((((unsigned)q) ^ (((pix >> 2) & 1) << 1)) << 4);
+        lds_read128<0>(af[i], addr);
+      }
+      SEG_ADD(0);                                            // fragment read issue
+      wait_vmcnt<2 + (t == 1 ? P1 : (t == 2 ? P2 : 0))>();
+      SEG_ADD(1);                                            // waiting for older pieces
+      __builtin_amdgcn_s_barrier();
+      SEG_ADD(2);                                            // waiting for the partner group's MATH segment
+      // ---- MATH segment ----
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) Mma<T>::run(acc[i][j], bfr[j], af[i]);
+      __builtin_amdgcn_s_setprio(0);
+      SEG_ADD(3);                                            // fragment wait + MFMAs
+      __builtin_amdgcn_s_barrier();
+      SEG_ADD(4);                                            // waiting for the partner group's LOAD segment
+    });
+  }
+  SEG_STORE;
+  if (wr == 0) __builtin_amdgcn_s_barrier();
+  wait_vmcnt<0>();
+  __syncthreads();
+  DIAG_STAMP(3);
+  gemm_epilogue<T, BM, BN, 2, 4, BRING + 2 * PATCH, true>(p, acc, smem, bm0, bn0, 0, 4, 0);
+  DIAG_STAMP(4);
+#endif
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p, int P) {
   long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -883,17 +1068,11 @@ static constexpr int cfg_ns(int BM, int BN) {
   return BM == 256 ? 2 : (BM == 128 && BN == 128) ? 2 : ((BM == 128 && BN >= 64) || (BM == 64 && BN == 128)) ? 3 : 2;
 }
 
-static int tune(const char* name, int dflt) {   // GAN_AMD_<name> overrides a planner constant (tuning experiments)
-  char key[64];
-  snprintf(key, sizeof key, "GAN_AMD_%s", name);
-  const char* e = getenv(key);
-  return e ? atoi(e) : dflt;
-}
-
 struct GemmPlan {
   GemmParams p;
   int BM, BN, P, stats_chunks;
   bool pp;                 // 256-row tile on the ping-pong kernel
+  int par_npw;             // > 0: parity-patch kernel (all four parities of 256 grid positions per block), patch pieces per wave
   bool bf_requested;       // the caller asked for a fused backward epilogue (carried iff p.bf_mode != 0)
   dim3 grid;
   size_t slab_bytes;
@@ -951,31 +1130,44 @@ static int plan_gemm(const GanConvDesc* d, int op, GemmPlan* pl) {
   int BM = 128;
   if (((M + 127) / 128) * ((y.c + BN - 1) / BN) * P < 192) BM = 64;
   if (BM == 64 && M <= 32 && BN != 16) BM = 16;
-  if (y.c >= 128 && M >= 256 && !getenv("GAN_AMD_NO_BIG_TILES")) {
+  if (y.c >= 128 && M >= 256 && gan_opt("conv.big_tiles")) {
     auto fill = [](long long blocks, long long slots) { return (double)blocks / (double)(((blocks + slots - 1) / slots) * slots); };
     const long long b128 = ((M + 127) / 128) * ((y.c + 127) / 128) * P;
     const long long b256n = ((M + 255) / 256) * ((y.c + 127) / 128) * P;
     const long long b256 = ((M + 255) / 256) * ((y.c + 255) / 256) * P;
-    static const int q128 = tune("Q128", 55), q256n = tune("Q256N", 80), minb = tune("BIGMIN", 128);
+    const int q128 = gan_opt("conv.q128"), q256n = gan_opt("conv.q256n"), minb = gan_opt("conv.big_min_blocks");
     double best = 0.01 * q128 * fill(b128, 512);
     if (b256n >= minb && 0.01 * q256n * fill(b256n, 256) > best) { best = 0.01 * q256n * fill(b256n, 256); BM = 256; BN = 128; }
     if (y.c >= 256 && b256 >= minb && 1.0 * fill(b256, 256) > best) { BM = 256; BN = 256; }
   }
   // 64-channel outputs on big maps: 256x64 tiles stage 17 % fewer bytes per FLOP than 128x64 and halve the tile count
-  static const int tall64 = tune("TALL64", 1);
+  const int tall64 = gan_opt("conv.tall64");
   if (tall64 && BN == 64 && BM == 128 && ((M + 255) / 256) * P >= 1024) BM = 256;
-  p.kchunks = (int)(Kbytes / cfg_bkb(BM, BN));
+  // Parity-patch kernel (conv_par_kernel): stride-2 transposed conv / stride-2 conv dgrad with 64 output channels per block,
+  // all four parities from one staged input patch.  Needs tiles of whole image rows and enough of them to fill the chip.
+  pl->par_npw = 0;
+  {
+    const int use_par = gan_opt("conv.parity_patch"), par_maxn = gan_opt("conv.parity_patch_max_n"), par_minb = gan_opt("conv.parity_patch_min_blocks");
+    const int Wg = p.Wg;
+    if (use_par && parity && d->dtype != GAN_F32 && y.c % 64 == 0 && y.c <= par_maxn && x.c % 32 == 0 && p.vec_store &&
+        Wg >= 16 && Wg <= 128 && (Wg & (Wg - 1)) == 0 && p.Hg % (256 / Wg) == 0 && M % 256 == 0 &&
+        (M / 256) * (y.c / 64) >= par_minb) {
+      pl->par_npw = (((256 / Wg + 2) * (Wg + 2) + 15) / 16 + 7) / 8;      // ceil(patch pixels / 16) pieces over 8 waves
+      BM = 256; BN = 64;
+    }
+  }
+  p.kchunks = pl->par_npw ? (int)(((long long)x.c * 2) / 64) : (int)(Kbytes / cfg_bkb(BM, BN));
   int tilesN = (y.c + BN - 1) / BN;
   long long tilesM = (M + BM - 1) / BM;
   long long blocks = tilesM * tilesN * P;
   int splits = 1;
-  static const int t_small = tune("CONV_TARGET", 512), t_skinny = tune("SKINNY_TARGET", 1024), t_big = tune("BIG_TARGET", 256);
+  const int t_small = gan_opt("conv.split_target"), t_skinny = gan_opt("conv.split_target_skinny"), t_big = gan_opt("conv.split_target_big");
   // 256-row tiles: a half-full chip (128..160 blocks) is worth a 2-way K split only when K is long enough
   // to amortise the fp32 slab round trip (measured: K>=4096 +25..40 %, K=2048 neutral)
   const long long target = BM == 256 ? (p.kchunks >= 48 && blocks <= 160 ? t_big : 128) : (BN == 16 ? t_skinny : t_small);   // BN=16: streaming layers want more, shorter blocks
-  if (blocks < target) {
+  if (blocks < target && !pl->par_npw) {
     splits = (int)((target + blocks - 1) / blocks);
-    static const int mink = tune("MINK", 4), maxsp = tune("MAXSPLIT", 64);
+    const int mink = gan_opt("conv.split_min_ktiles"), maxsp = gan_opt("conv.split_max");
     int maxs = p.kchunks / mink; if (maxs < 1) maxs = 1;
     if (splits > maxs) splits = maxs;
     if (splits > maxsp) splits = maxsp;
@@ -1031,9 +1223,9 @@ static int plan_gemm(const GanConvDesc* d, int op, GemmPlan* pl) {
   if (bf_mode) {
     // the slab-reduce kernel of a split-K launch carries it at no cost (streaming kernel, the slabs are read anyway); a tile
     // epilogue re-reads the reference tensor at the tile's strided pixel order - break-even per launch on the 128/256-column
-    // tiles, a gain on the 64-column ones (their act_bwd pass streamed 4 tensors): GAN_AMD_BF_TILE = 0 never, 1 always,
+    // tiles, a gain on the 64-column ones (their act_bwd pass streamed 4 tensors): option conv.bwd_fuse_tile = 0 never, 1 always,
     // 2 not on the 64-column tiles, 3 only on them
-    const int bf_tile = tune("BF_TILE", 3);            // read per plan: the op tests exercise every carrier
+    const int bf_tile = gan_opt("conv.bwd_fuse_tile");   // (the op tests exercise every carrier)
     const bool tile_ok = bf_tile == 1 || (bf_tile == 2 && BN != 64) || (bf_tile == 3 && BN == 64);
     const bool carrier = p.vec_store && (splits == 1 ? tile_ok : reduce4_ok);
     if (carrier && (bf_mode == 4 || p.stats)) {
@@ -1052,10 +1244,10 @@ static int plan_gemm(const GanConvDesc* d, int op, GemmPlan* pl) {
 #ifdef GAN_DIAG
   p.diag = g_diag;
 #endif
-  static const int use_pp = tune("PP", 1);
+  const int use_pp = gan_opt("conv.pingpong");
   pl->pp = use_pp && BM == 256 && (BN == 256 || BN == 128) && ((long long)x.c * (d->dtype == GAN_F32 ? 4 : 2)) % 128 == 0;
   pl->BM = BM; pl->BN = BN;
-  pl->grid = dim3((unsigned)(tilesM * tilesN * P), 1, (unsigned)splits);
+  pl->grid = dim3((unsigned)(tilesM * tilesN * (pl->par_npw ? 1 : P)), 1, (unsigned)splits);
   pl->slab_bytes = splits > 1 ? (size_t)P * splits * (size_t)M * p.NslabPitch * sizeof(float) : 0;
   return 0;
 }
@@ -1092,9 +1284,36 @@ static int launch_pp(const GemmPlan& pl, hipStream_t st) {
   return 0;
 }
 
+template <typename T, int NPW>
+static int launch_par(const GemmPlan& pl, hipStream_t st) {
+  static bool attr_set = false;
+  constexpr size_t smem = (size_t)4 * 4 * 64 * 64 + 2 * (size_t)NPW * 8 * 1024;
+  if constexpr (sizeof(T) == 2) {
+    auto kern = conv_par_kernel<T, NPW>;
+    if (!attr_set) {
+      hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      if (e != hipSuccess) return (int)e;
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, pl.grid, dim3(512), smem, st, pl.p);
+    GAN_CHECK_LAUNCH();
+    return 0;
+  } else {
+    return GAN_E_SHAPE;       // (the planner never sends the fp32 parity path here)
+  }
+}
+
 template <typename T>
 static int launch_gemm(const GemmPlan& pl, hipStream_t st) {
   int rc;
+  if (pl.par_npw) {
+    switch (pl.par_npw) {
+      case 3: return launch_par<T, 3>(pl, st);
+      case 4: return launch_par<T, 4>(pl, st);
+      case 5: return launch_par<T, 5>(pl, st);
+      default: return GAN_E_SHAPE;
+    }
+  }
   const int key = pl.pp ? pl.BN : pl.BM * 1000 + pl.BN;
   switch (key) {
     case 256: rc = launch_pp<T, 256>(pl, st); break;
@@ -1158,7 +1377,8 @@ int gan_conv_plan_info(const GanConvDesc* d, int op, int32_t* info /*[5]: BM, BN
   plan_only_desc(&t);
   int rc = plan_gemm(&t, op, &pl);
   if (rc) return rc;
-  info[0] = pl.BM; info[1] = pl.BN; info[2] = pl.p.splits; info[3] = pl.P;
+  info[0] = pl.par_npw ? 4 * pl.BM : pl.BM;      // parity-patch kernel: 1024 output pixels (4 parities x 256 positions) per block
+  info[1] = pl.BN; info[2] = pl.p.splits; info[3] = pl.P;
   info[4] = pl.stats_chunks;          // > 0: this launch can emit normalisation-statistics partials (chunks per group)
   if (const int fam = thin_family(&t, op, pl.p)) { info[0] = 0; info[1] = fam; info[2] = 1; info[4] = 0; }   // thin.hip kernels
   return 0;

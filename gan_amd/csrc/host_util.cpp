@@ -15,3 +15,59 @@ extern "C" uint32_t gan_crc32c(uint32_t crc, const void* data, size_t n) {
   while (n) { c = _mm_crc32_u8((uint32_t)c, *p++); --n; }
   return (uint32_t)c ^ 0xffffffffu;
 }
+
+// ---- planner options -------------------------------------------------------------------------------------------------
+// The launch planners (conv_gemm.hip, wgrad.hip, thin.hip) take their tunable constants from this table, which only
+// gan_set_option() changes: the library reads no environment variable.  Values are read at PLAN time (every entry point plans
+// per call), so a change applies to the calls that follow it.  Keys and defaults: include/gan_amd.h.
+#include <atomic>
+namespace {
+struct Opt { const char* key; std::atomic<int> value; };
+Opt g_opts[] = {
+    {"conv.big_tiles", {1}},        // 256-row tiles for layers with >= 128 output channels
+    {"conv.q128", {55}},            // relative quality (percent) of the 128x128 tile in the tile choice
+    {"conv.q256n", {80}},           //   ... of the 256x128 tile (256x256 = 100)
+    {"conv.big_min_blocks", {128}}, // a 256-row tile needs at least this many blocks
+    {"conv.tall64", {1}},           // 256x64 tiles for 64-channel outputs on big maps
+    {"conv.pingpong", {1}},         // 256-row tiles on the ping-pong kernel
+    {"conv.parity_patch", {1}},     // parity-patch kernel for stride-2 transposed convs with 64 output channels
+    {"conv.parity_patch_max_n", {64}},
+    {"conv.parity_patch_min_blocks", {192}},
+    {"conv.split_target", {512}},   // split K until this many blocks (128-row tiles and smaller)
+    {"conv.split_target_skinny", {1024}},
+    {"conv.split_target_big", {256}},
+    {"conv.split_min_ktiles", {4}},
+    {"conv.split_max", {64}},
+    {"conv.bwd_fuse_tile", {3}},    // fused backward epilogue on tile epilogues: 0 never, 1 always, 2 not on 64-column tiles, 3 only on them
+    {"conv.thin", {7}},             // bit 0: streaming kernels at all, bit 1: thin-N, bit 2: thin-K
+    {"wgrad.tile256", {0}},         // 256-row tiles in the 128x128 kernel family
+    {"wgrad.pingpong", {1}},
+    {"wgrad.pingpong_min_rows", {0}},   // 0: 1024 rows per split (2048 when the launch shares the chip)
+    {"wgrad.pingpong_128", {0}},
+    {"wgrad.pingpong_min_gflop", {30}},
+    {"wgrad.split_target", {512}},
+};
+Opt* find_opt(const char* key) {
+  if (!key) return nullptr;
+  for (Opt& o : g_opts)
+    if (!strcmp(o.key, key)) return &o;
+  return nullptr;
+}
+}  // namespace
+
+int gan_opt(const char* key) {              // internal: a key the table does not hold is a programming error
+  Opt* o = find_opt(key);
+  return o ? o->value.load(std::memory_order_relaxed) : 0;
+}
+extern "C" int gan_set_option(const char* key, int32_t value) {
+  Opt* o = find_opt(key);
+  if (!o) return GAN_E_ARG;
+  o->value.store(value, std::memory_order_relaxed);
+  return 0;
+}
+extern "C" int gan_get_option(const char* key, int32_t* value) {
+  Opt* o = find_opt(key);
+  if (!o || !value) return GAN_E_ARG;
+  *value = o->value.load(std::memory_order_relaxed);
+  return 0;
+}

@@ -185,8 +185,7 @@ __global__ __launch_bounds__(256) void conv_thin_col2im_kernel(const Col2imParam
 
 // ------------------------------------------------------------------------------------------------
 int thin_family(const GanConvDesc* d, int op, const GemmParams& p) {
-  static int off = -1;
-  if (off < 0) { const char* e = getenv("GAN_AMD_NO_THIN"); off = e ? atoi(e) : 0; }
+  const int on = gan_opt("conv.thin"), off = (on & 1) ? (~on & 6) : 1;      // off: 1 = none, bit 1 = no thin-N, bit 2 = no thin-K
   if (off == 1 || d->dtype == GAN_F32) return 0;
   const GanTensor &x = d->x, &y = d->y;
   // thin-N: few output channels.  Z needs one MFMA tile per output channel; weights CO*KS KiB of LDS.

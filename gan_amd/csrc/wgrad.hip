@@ -27,7 +27,6 @@ struct WgradParams {
   int splits, kchunks;
   int accumulate, fold;
   int swap, shift;  // swap: roles exchanged (thin SMALL tensor folded, thick BIG tensor streamed), taps flipped, rows shifted
-  int debug;     // timing experiments (GAN_AMD_WGRAD_DEBUG): 1 skip the MFMA phase, 2 skip global loads + LDS stores
 };
 
 template <typename T, int TA, int TB, int WAVES_A, int WAVES_B, bool TR>
@@ -118,9 +117,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
   if (kc_begin < kc_end) { gload(kc_begin); lstore(0); }
   __syncthreads();
   for (int kc = kc_begin; kc < kc_end; ++kc) {
-    const bool more = kc + 1 < kc_end && !(p.debug & 2);
+    const bool more = kc + 1 < kc_end;
     if (more) gload(kc + 1);
-    if (!(p.debug & 1)) {
+    {
     const unsigned char* Ab = As + buf * BKM * RSA + (wa * WTA) * ES;
     const unsigned char* Bb = Bs + buf * BKM * RSB + (wb * WTB) * ES;
     if constexpr (sizeof(T) == 4) {
@@ -263,7 +262,6 @@ static int plan_wgrad(const GanWgradDesc* d, WgradPlan* pl, bool allow_swap = tr
   p.Hb = b.h; p.Wb = b.w; p.bpitch = b.pitch; p.Ca = b.c; p.spitch = s.pitch; p.Cb = s.c;
   p.S = d->stride; p.M = (int)M; p.divW = make_fastdiv(s.w); p.divH = make_fastdiv(s.h);
   p.CaReal = d->big_c; p.CbReal = d->small_c; p.accumulate = d->accumulate;
-  { static int dbg = -1; if (dbg < 0) { const char* e = getenv("GAN_AMD_WGRAD_DEBUG"); dbg = e ? atoi(e) : 0; } p.debug = dbg; }
   p.fold = (b.c == 8) ? 1 : 0;
   p.swap = 0; p.shift = 0;
   int TA, TB, tilesA, taps;
@@ -284,8 +282,7 @@ static int plan_wgrad(const GanWgradDesc* d, WgradPlan* pl, bool allow_swap = tr
     taps = 16;
     TB = s.c >= 128 ? 128 : (s.c >= 64 ? 64 : 16);
     TA = b.c >= 128 ? 128 : (b.c >= 64 ? 64 : 16);
-    { static int big = -1; if (big < 0) { const char* e = getenv("GAN_AMD_WGRAD_BIG"); big = e ? atoi(e) : 0; }
-      if (big && b.c >= 256 && s.c >= 128 && d->dtype != GAN_F32) TA = 256; }
+    if (gan_opt("wgrad.tile256") && b.c >= 256 && s.c >= 128 && d->dtype != GAN_F32) TA = 256;
     if (TB == 16) TA = TA == 16 ? 64 : TA;   // supported: (128|64, 16)
     if (TA == 64 && TB == 16) {}
     if (TA == 16 && TB == 16) return GAN_E_SHAPE;
@@ -294,17 +291,13 @@ static int plan_wgrad(const GanWgradDesc* d, WgradPlan* pl, bool allow_swap = tr
   pl->pp = false;
   {
     // big reductions on 16-bit storage: the 256 x 256 ping-pong kernel (rows = (tap, channel) pairs in units of 64)
-    static int use_pp = -1;
-    if (use_pp < 0) { const char* e = getenv("GAN_AMD_WGRAD_PP"); use_pp = e ? atoi(e) : 1; }
+    const int use_pp = gan_opt("wgrad.pingpong");
     // reduction rows per split at least: 1024 alone on the chip; 2048 when the launch shares it with other lanes (~128 blocks with
-    // longer K loops and half the slab traffic: slower alone, +1.3 % in the captured Pix2Pix step; GAN_AMD_WGRAD_PP_MINROWS overrides)
-    static int min_rows_env = -1;
-    if (min_rows_env < 0) { const char* e = getenv("GAN_AMD_WGRAD_PP_MINROWS"); min_rows_env = e ? atoi(e) : 0; }
+    // longer K loops and half the slab traffic: slower alone, +1.3 % in the captured Pix2Pix step; option wgrad.pingpong_min_rows overrides)
+    const int min_rows_env = gan_opt("wgrad.pingpong_min_rows");
     const int min_rows = min_rows_env > 0 ? min_rows_env : (d->concurrent ? 2048 : 1024);
-    static int pp128 = -1, mingf = -1;
-    if (pp128 < 0) { const char* e = getenv("GAN_AMD_WGRAD_PP128"); pp128 = e ? atoi(e) : 0; }
-    if (mingf < 0) { const char* e = getenv("GAN_AMD_WGRAD_PP_MINGF"); mingf = e ? atoi(e) : 30; }
-    // (GAN_AMD_WGRAD_PP128: a 128-channel SMALL tensor on the 256-column tile - half the columns are computed and dropped)
+    const int pp128 = gan_opt("wgrad.pingpong_128"), mingf = gan_opt("wgrad.pingpong_min_gflop");
+    // (option wgrad.pingpong_128: a 128-channel SMALL tensor on the 256-column tile - half the columns are computed and dropped)
     if (use_pp && allow_swap && !p.fold && !p.swap && d->dtype != GAN_F32 && (b.c == 64 || b.c == 128 || b.c % 256 == 0) &&
         (s.c % 256 == 0 || (pp128 && s.c == 128)) && M >= 2 * min_rows &&
         2.0 * (double)M * 16.0 * b.c * s.c >= 1.0e9 * mingf) {      // every block writes a 256 KB fp32 slab tile (64 MB per launch with the
@@ -331,8 +324,7 @@ static int plan_wgrad(const GanWgradDesc* d, WgradPlan* pl, bool allow_swap = tr
   p.kchunks = (int)((M + bkm - 1) / bkm);
   long long blocks = (long long)tilesA * tilesB * taps;
   int splits = 1;
-  static int wtarget = -1;
-  if (wtarget < 0) { const char* e = getenv("GAN_AMD_WGRAD_TARGET"); wtarget = e ? atoi(e) : 512; }
+  const int wtarget = gan_opt("wgrad.split_target");
   const long long target = p.fold ? 1024 : wtarget;     // fold mode streams the SMALL tensor once: HBM-bound, wants many blocks
   if (blocks < target) {
     splits = (int)((target + blocks - 1) / blocks);
@@ -833,22 +825,15 @@ static int launch_wpp(const WgradPlan& pl, unsigned bigbytes, unsigned smallbyte
   return 0;
 }
 
-static bool wgrad_use_tr() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("GAN_AMD_WGRAD_NO_TR"); v = (e && e[0] == '1') ? 0 : 1; }
-  return v == 1;
-}
 
 extern "C" {
 int gan_conv_wgrad(const GanWgradDesc* d, gan_stream_t stream) {
   if (!d || d->struct_size != sizeof(GanWgradDesc)) return GAN_E_ARG;
   hipStream_t st = (hipStream_t)stream;
-  static int v1 = -1;
-  if (v1 < 0) { const char* e = getenv("GAN_AMD_WGRAD_V1"); v1 = (e && e[0] == '1') ? 1 : 0; }
   const size_t es = d->dtype == GAN_F32 ? 4 : 2;
   size_t bb = (((size_t)d->big.n * d->big.h * d->big.w - 1) * d->big.pitch + d->big.c) * es;
   size_t sb = (((size_t)d->small.n * d->small.h * d->small.w - 1) * d->small.pitch + d->small.c) * es;
-  const bool dma_ok = !v1 && bb < 0x7fffffffull && sb < 0x7fffffffull && !(((uintptr_t)d->big.ptr | (uintptr_t)d->small.ptr) & 15);
+  const bool dma_ok = bb < 0x7fffffffull && sb < 0x7fffffffull && !(((uintptr_t)d->big.ptr | (uintptr_t)d->small.ptr) & 15);
   WgradPlan pl;
   int rc = plan_wgrad(d, &pl, dma_ok);         // the role-swapped plan exists only in the LDS-DMA kernel
   if (rc) return rc;
@@ -859,8 +844,8 @@ int gan_conv_wgrad(const GanWgradDesc* d, gan_stream_t stream) {
                    : d->dtype == GAN_F16 ? launch_wgrad_dma<f16_t>(pl, (unsigned)bb, (unsigned)sb, st)
                                          : launch_wgrad_dma<bf16_t>(pl, (unsigned)bb, (unsigned)sb, st);
   else if (d->dtype == GAN_F32) rc = launch_wgrad<float, false>(pl, st);
-  else if (d->dtype == GAN_F16) rc = wgrad_use_tr() ? launch_wgrad<f16_t, true>(pl, st) : launch_wgrad<f16_t, false>(pl, st);
-  else rc = wgrad_use_tr() ? launch_wgrad<bf16_t, true>(pl, st) : launch_wgrad<bf16_t, false>(pl, st);
+  else if (d->dtype == GAN_F16) rc = launch_wgrad<f16_t, true>(pl, st);
+  else rc = launch_wgrad<bf16_t, true>(pl, st);
   if (rc) return rc;
   if (pl.p.splits > 1) {
     const long long count4 = (long long)4 * pl.p.CaReal * pl.p.CbReal;     // 16 taps * Ca * Cb floats, as float4

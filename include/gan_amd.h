@@ -295,6 +295,20 @@ int gan_grad_unpack(const void* src_bf16, float* dst, int64_t count, float scale
 uint32_t gan_crc32c(uint32_t crc, const void* data, size_t n);
 const char* gan_version(void);
 
+/* ---- planner options -------------------------------------------------------------------------- */
+/* The launch planners' tunable constants.  The library reads NO environment variable: these calls are the only way to
+ * change them, and a change applies to the entry-point calls that follow it (each call plans for itself).  Unknown key:
+ * GAN_E_ARG.  Keys (default): conv.big_tiles (1), conv.q128 (55), conv.q256n (80), conv.big_min_blocks (128),
+ * conv.tall64 (1), conv.pingpong (1), conv.parity_patch (1), conv.parity_patch_max_n (64),
+ * conv.parity_patch_min_blocks (192), conv.split_target (512), conv.split_target_skinny (1024),
+ * conv.split_target_big (256), conv.split_min_ktiles (4), conv.split_max (64), conv.bwd_fuse_tile (3: the fused backward
+ * epilogue rides on 64-column tile epilogues only; 0 never, 1 on every tile, 2 not on 64-column tiles), conv.thin (7: bit 0
+ * streaming kernels for the <= 8-channel layers, bit 1 thin-N, bit 2 thin-K), wgrad.tile256 (0), wgrad.pingpong (1),
+ * wgrad.pingpong_min_rows (0 = automatic), wgrad.pingpong_128 (0), wgrad.pingpong_min_gflop (30),
+ * wgrad.split_target (512). */
+int gan_set_option(const char* key, int32_t value);
+int gan_get_option(const char* key, int32_t* value);
+
 #ifdef __cplusplus
 }
 #endif

@@ -21,3 +21,16 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture
+def planner_options():
+    """set(key, value): change a planner option of the library (gan_set_option, include/gan_amd.h) for this test only."""
+    from gan_amd import _lib as L
+    saved = []
+
+    def set_(key, value):
+        saved.append((key, L.set_option(key, value)))
+    yield set_
+    for key, value in reversed(saved):
+        L.set_option(key, value)

@@ -217,14 +217,14 @@ FUSE_CASES = [  # (op, N, H of dy, channels of dy, channels of the produced grad
 
 
 @pytest.mark.parametrize("case", FUSE_CASES)
-def test_dgrad_fused_backward_epilogue(ctx, case, monkeypatch):
+def test_dgrad_fused_backward_epilogue(ctx, case, planner_options):
     """GanBwdFuse: a dgrad launch that starts the layer-below backward in its epilogue (dz + partial sums) followed by
     gan_norm_act_bwd_fused must equal the plain dgrad followed by gan_norm_act_bwd / gan_act_bwd (themselves checked
-    against the oracle above); channels >= cols must be the plain dgrad's.  GAN_AMD_BF_TILE=1 lets every tile epilogue carry
+    against the oracle above); channels >= cols must be the plain dgrad's.  option conv.bwd_fuse_tile = 1 lets every tile epilogue carry
     it (the default policy keeps it to the 64-column tiles and the slab-reduce kernels, where it pays)."""
     from gan_amd import _lib as L
     from gan_amd.nets import Buf
-    monkeypatch.setenv('GAN_AMD_BF_TILE', '1')
+    planner_options('conv.bwd_fuse_tile', 1)          # every tile epilogue carries it (planner option, include/gan_amd.h)
     op, N, H, cdy, cg, G, kind, cols, skip = case
     rng = np.random.default_rng(11)
     Hg = 2 * H if op == 'conv_dgrad' else H // 2
@@ -343,6 +343,121 @@ def test_convT2d_fwd_dgrad_wgrad(ctx, case):
     assert ctx.lib.gan_conv_wgrad(C.byref(d), ctx.stream()) == 0
     torch.cuda.synchronize()
     assert rel(dw.cpu().numpy().reshape(4, 4, co, ci), dw_ref) < TOL[ctx.dtype]
+
+
+PAR_CASES = [  # (N, h of the coarse grid, Cin, Cout): stride-2 transposed conv h -> 2h and the stride-2 conv dgrad of the same shape
+    (2, 16, 32, 64),       # Wg = 16: a tile = one whole image (16 rows), one K chunk
+    (1, 32, 64, 64),       # Wg = 32: 8 rows per tile, 4 tiles, two chunks (patch double buffer)
+    (1, 64, 128, 64),      # Wg = 64: 4 rows per tile, four chunks (ring wrap), halo rows between tiles
+    (1, 128, 32, 64),      # Wg = 128: 2 rows per tile (512^2 images), 5 patch pieces per wave
+    (2, 32, 64, 128),      # two 64-channel column blocks
+]
+
+
+@pytest.mark.parametrize("case", PAR_CASES)
+def test_parity_patch_kernel(ctx, case, planner_options):
+    """conv_par_kernel (all four output parities of 256 grid positions from one staged input patch): Conv2DTranspose forward
+    (base_gan.py:106-110) and the input gradient of a stride-2 Conv2D (base_gan.py:77-79 under the tape) against the oracle,
+    with bias + activation, fused statistics partials, and the fused backward epilogue equal to the four-sub-GEMM kernels."""
+    from gan_amd import _lib as L
+    from gan_amd.nets import Buf
+    if ctx.dtype == 'f32':
+        pytest.skip("the fp32 parity path keeps the tap-gather kernel")
+    planner_options('conv.parity_patch_min_blocks', 1)
+    planner_options('conv.parity_patch_max_n', 128)
+    N, h, ci, co = case
+    rng = np.random.default_rng(hash(case) % 2**31)
+    info = (C.c_int32 * 5)()
+    # ---- Conv2DTranspose forward: x [N,h,h,ci] -> y [N,2h,2h,co], bias + LeakyReLU, statistics partials of the stored output
+    x = q(ctx, rng.standard_normal((N, h, h, ci)))
+    w = q(ctx, 0.05 * rng.standard_normal((4, 4, co, ci)))
+    bias = (0.1 * rng.standard_normal(co)).astype(np.float32)
+    xb, _ = dev(ctx, x, pitch=ci + 8)                 # channel-slice view of a wider buffer
+    xv = xb.view(0, ci)
+    nat, tr = prep(ctx, w)
+    yb = Buf(ctx, N, 2 * h, 2 * h, co + 8)
+    bt = torch.from_numpy(bias).to(ctx.device)
+    part = torch.full((1 << 20,), 9.0, dtype=torch.float32, device=ctx.device)
+    groups = N
+    d = L.GanConvDesc(ctx.dt, 2, xv, yb.view(8, co), nat.data_ptr(), co, bt.data_ptr(), L.ACT_LRELU, 0.3, 0, ctx.ws_ptr, ctx.ws_bytes,
+                      part.data_ptr(), groups, part.numel() * 4)
+    assert ctx.lib.gan_conv_plan_info(C.byref(d), 2, info) == 0
+    assert (info[0], info[1], info[2], info[3]) == (1024, 64, 1, 4), list(info)
+    chunks = info[4]
+    assert chunks == (h * h // 256) * 4
+    assert ctx.lib.gan_convT2d_fwd(C.byref(d), ctx.stream()) == 0
+    torch.cuda.synchronize()
+    ref = O.act_fwd(O.convT2d_fwd(x, w) + bias, 'lrelu')
+    assert rel(host(yb, 8, co), ref) < TOL[ctx.dtype]
+    assert np.all(host(yb, 0, 8) == 0)
+    got = part[:groups * chunks * co * 2].cpu().numpy().reshape(groups, chunks, co, 2).astype(np.float64).sum(1)
+    ys = host(yb, 8, co).reshape(groups, -1, co)
+    assert rel(got[..., 0], ys.sum(1)) < 1e-4 and rel(got[..., 1], (ys * ys).sum(1)) < 1e-4
+    # ---- stride-2 Conv2D input gradient: dy [N,h,h,ci'] (ci' = this case's Cin) -> dx [N,2h,2h,co]
+    wc = q(ctx, 0.05 * rng.standard_normal((4, 4, co, ci)))          # HWIO: in = co (the gradient's channels), out = ci
+    dy = q(ctx, rng.standard_normal((N, h, h, ci)))
+    natc, trc = prep(ctx, wc)
+    dyb, dyv = dev(ctx, dy)
+    dxb = Buf(ctx, N, 2 * h, 2 * h, co)
+    d2 = L.GanConvDesc(ctx.dt, 2, dyv, dxb.view(), natc.data_ptr(), co, None, 0, 0.3, 0, ctx.ws_ptr, ctx.ws_bytes)
+    assert ctx.lib.gan_conv_plan_info(C.byref(d2), 1, info) == 0 and info[0] == 1024
+    assert ctx.lib.gan_conv2d_dgrad(C.byref(d2), ctx.stream()) == 0
+    torch.cuda.synchronize()
+    dx_ref, _ = O.conv2d_bwd(np.zeros((N, 2 * h, 2 * h, co)), wc, dy, 2)
+    assert rel(host(dxb), dx_ref) < TOL[ctx.dtype]
+    # ---- fused backward epilogue on this kernel == on the four-sub-GEMM kernel (every tile epilogue carries it)
+    planner_options('conv.bwd_fuse_tile', 1)
+    refy = q(ctx, rng.standard_normal((N, 2 * h, 2 * h, co)) * 1.3 + 0.2)
+    refb, refv = dev(ctx, refy)
+    addb, addv = dev(ctx, q(ctx, rng.standard_normal((N, 2 * h, 2 * h, co))), pitch=co + 8)
+    f32 = torch.float32
+    gamma = torch.from_numpy((1 + 0.2 * rng.standard_normal(co)).astype(np.float32)).to(ctx.device)
+    beta = torch.from_numpy((0.2 * rng.standard_normal(co)).astype(np.float32)).to(ctx.device)
+    mean, rstd = torch.zeros(co, dtype=f32, device=ctx.device), torch.zeros(co, dtype=f32, device=ctx.device)
+    nd = L.GanNormDesc(ctx.dt, refv, refv, 1, 1e-3, gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(), rstd.data_ptr(), None, None,
+                       0.99, None, L.ACT_LRELU, 0.3, ctx.ws_ptr, ctx.ws_bytes)
+    assert ctx.lib.gan_norm_stats(C.byref(nd), ctx.stream()) == 0
+    bf = L.GanBwdFuse(refv, addv, mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), None, 0, L.ACT_LRELU, 0.3, co)
+    outs = []
+    for use_par in (1, 0):
+        planner_options('conv.parity_patch', use_par)
+        dzb = Buf(ctx, N, 2 * h, 2 * h, co)
+        pf = torch.full((1 << 20,), 7.0, dtype=f32, device=ctx.device)
+        d3 = L.GanConvDesc(ctx.dt, 2, dyv, dzb.view(), natc.data_ptr(), co, None, 0, 0.3, 0, ctx.ws_ptr, ctx.ws_bytes,
+                           pf.data_ptr(), 1, pf.numel() * 4, C.addressof(bf))
+        assert ctx.lib.gan_conv_plan_info(C.byref(d3), 1, info) == 0 and info[4] > 0 and (info[0] == 1024) == bool(use_par)
+        assert ctx.lib.gan_conv2d_dgrad(C.byref(d3), ctx.stream()) == 0
+        torch.cuda.synchronize()
+        sums = pf[:info[4] * co * 2].cpu().numpy().reshape(info[4], co, 2).astype(np.float64).sum(0)
+        outs.append((host(dzb), sums))
+    assert rel(outs[0][0], outs[1][0]) < {'bf16': 2e-2, 'f16': 3e-3}[ctx.dtype]
+    assert rel(outs[0][1], outs[1][1]) < {'bf16': 2e-2, 'f16': 3e-3}[ctx.dtype]
+
+
+def test_parity_patch_kernel_at_baseline_shape(planner_options):
+    """Generator up6 forward at BASELINE's batch 16 (16 x 64 x 64 x 256 -> 128 x 128 x 64, bf16): the parity-patch kernel
+    against the four-sub-GEMM kernel on the same data (the oracle takes minutes at this size)."""
+    from gan_amd import _lib as L
+    from gan_amd.nets import Ctx, Buf
+    c = Ctx('cuda:0', 'bf16')
+    g = torch.Generator(device='cuda').manual_seed(3)
+    x = Buf(c, 16, 64, 64, 256)
+    x.t.copy_(torch.randn(x.t.shape, device='cuda', generator=g).to(c.tdtype))
+    w = (0.05 * torch.randn((16, 64, 256), device='cuda', generator=g)).to(c.tdtype)
+    info = (C.c_int32 * 5)()
+    res = []
+    for use_par in (1, 0):
+        planner_options('conv.parity_patch', use_par)
+        y = Buf(c, 16, 128, 128, 64)
+        d = L.GanConvDesc(c.dt, 2, x.view(), y.view(), w.data_ptr(), 64, None, 0, 0.3, 0, c.ws_ptr, c.ws_bytes)
+        assert c.lib.gan_conv_plan_info(C.byref(d), 2, info) == 0 and (info[0] == 1024) == bool(use_par), list(info)
+        assert c.lib.gan_convT2d_fwd(C.byref(d), c.stream()) == 0
+        torch.cuda.synchronize()
+        res.append(y.t.float())
+    err = float((res[0] - res[1]).abs().max() / res[1].abs().max())
+    assert err < 1e-2, err          # same products, different summation order; bf16 output rounding
+
+
 
 
 def test_wgrad_tr_read_matches_plain(ctx, monkeypatch):
