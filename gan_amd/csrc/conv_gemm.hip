@@ -768,8 +768,8 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(const GemmParams p) {
 // As four separate parity sub-GEMMs these layers stage every input pixel 16 times (4 parities x 4 taps) for 64 columns of
 // output: 51 FLOP per staged byte, a third of what the LDS-DMA path needs to keep the matrix pipe busy.
 // Here ONE block computes all four parities of 256 input-grid positions (R whole image rows) x 64 channels, i.e. 1024 output
-// pixels, from an input PATCH that is staged once per channel chunk: (R+2) x (Wg+2) pixels (a one-pixel halo, zeros outside the
-// map) x 32 channels (64-byte LDS rows).  The 16 (parity, tap) products of a chunk read it at nine different shifts
+// pixels, from an input PATCH that is staged once per channel chunk: (R+2) rows of Wg+2 pixels (a one-pixel halo, zeros outside the
+// map; row pitch Wg+8) x 32 channels (64-byte LDS rows).  The 16 (parity, tap) products of a chunk read it at nine different shifts
 //     output (2gy+py, 2gx+px) += x[gy + py - ty, gx + px - tx] . W[1-py+2ty][1-px+2tx],   ty, tx in {0, 1}
 // so an A fragment is an ordinary ds_read_b128 at (pixel + shift) * 64 bytes.  Per chunk 32-40 KB of patch + 64 KB of weights
 // are staged for 16.8 MFLOP: ~170 FLOP per staged byte.
@@ -808,7 +808,7 @@ __global__ __launch_bounds__(512) void conv_par_kernel(const GemmParams p) {
   const int nb = p.tilesM * p.tilesN;
   if ((nb & 7) == 0) bid = (bid & 7) * (nb >> 3) + (bid >> 3);
   const int bm0 = (bid / p.tilesN) * BM, bn0 = (bid % p.tilesN) * PC;
-  const int Wg = p.Wg, PW = Wg + 2;
+  const int Wg = p.Wg, PW = Wg + 8;                          // patch row: halo | Wg pixels | halo | 6 unused (PW % 8 == 0, below)
   const int lw = 31 - __builtin_clz((unsigned)Wg);           // Wg is a power of two (16..128)
   const int Rrows = BM >> lw;
   // tile origin (R whole rows of one image)
@@ -869,12 +869,20 @@ __global__ __launch_bounds__(512) void conv_par_kernel(const GemmParams p) {
   const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
   // B: column j*16 + r of this wave's parity, slot q (swizzle term depends on r only)
   const unsigned b_row = lds_base + par * (PC * CKB) + r * CKB + (((unsigned)q ^ ((((unsigned)r >> 2) & 1) << 1)) << 4);
-  // A: patch pixel of tile row wr*128 + i*16 + r at shift (0, 0); the 16 rows of a fragment lie in one image row (Wg >= 16)
-  int pixbase[8];
+  // A: fragment i = tile rows wr*128 + i*16 + (0..15): 16 consecutive pixels of one image row (Wg >= 16), patch pixel
+  // (row_i + 1 + dy) * PW + col_i + r + 1 + dx at shift (dy, dx).  PW % 8 == 0 and col_i % 16 == 0, so the swizzle term depends
+  // on r + 1 + dx only: byte address = [wave-uniform (row_i + 1 + dy) * PW + col_i] * 64 + lane_off[dx], one add per fragment.
+  unsigned lane_off[2];                                      // tx = 0, 1 -> dx = px - tx
+#pragma unroll
+  for (int tx = 0; tx < 2; ++tx) {
+    const unsigned c = (unsigned)(r + 1 + px - tx);
+    lane_off[tx] = (c << 6) + ((((unsigned)q) ^ (((c >> 2) & 1) << 1)) << 4);
+  }
+  int frag_org[8];                                           // (row_i * PW + col_i) * 64: wave-uniform
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
-    const int ml = wr * 128 + i * 16 + r;
-    pixbase[i] = ((ml >> lw) + 1) * PW + (ml & (Wg - 1)) + 1;
+    const int ml = wr * 128 + i * 16;
+    frag_org[i] = ((ml >> lw) * PW + (ml & (Wg - 1))) * CKB;
   }
 
   DIAG_STAMP(1);
@@ -895,24 +903,20 @@ __global__ __launch_bounds__(512) void conv_par_kernel(const GemmParams p) {
     static_for<4>([&](auto Tc) {
       constexpr int t = decltype(Tc)::value, ty = t >> 1, tx = t & 1;
       // ---- LOAD segment ----
+      static_for<4>([&](auto Jc) {
+        constexpr int j = decltype(Jc)::value;
+        lds_read128<t * BSTEP + j * 16 * CKB>(bfr[j], b_row);
+      });
+      int rowsh = (int)pbuf + (1 + py - ty) * PW * CKB;      // wave-uniform: buffer + the (parity, tap)'s row shift
+      asm volatile("" : "+s"(rowsh));                        // (recomputed per step: hoisted out of the chunk loop, the 32 (tap, fragment) addresses spill)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) lds_read128<0>(af[i], lane_off[tx] + (unsigned)(frag_org[i] + rowsh));
+      SEG_ADD(0);                                            // fragment read issue
       if constexpr (t < 2) issue_b(std::integral_constant<int, t + 2>{}, c);
       else issue_b(std::integral_constant<int, t - 2>{}, c + 1);
       if constexpr (t == 1) issue_patch(std::integral_constant<int, 0>{}, std::integral_constant<int, P1>{}, c + 1);
       if constexpr (t == 2) issue_patch(std::integral_constant<int, P1>{}, std::integral_constant<int, P2>{}, c + 1);
       SEG_ADD(5);                                            // LDS-DMA issue
-      static_for<4>([&](auto Jc) {
-        constexpr int j = decltype(Jc)::value;
-        lds_read128<t * BSTEP + j * 16 * CKB>(bfr[j], b_row);
-      });
-      int shift = (py - ty) * PW + (px - tx);                // wave-uniform pixel shift of this (parity, tap)
-      asm volatile("" : "+s"(shift));                        // (recomputed per step: hoisted out of the chunk loop, the 32 (tap, fragment) addresses spill)
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const unsigned pix = (unsigned)(pixbase[i] + shift);
-        const unsigned addr = pbuf + (pix << 6) + ((((unsigned)q) ^ (((pix >> 2) & 1) << 1)) << 4);
-        lds_read128<0>(af[i], addr);
-      }
-      SEG_ADD(0);                                            // fragment read issue
       wait_vmcnt<2 + (t == 1 ? P1 : (t == 2 ? P2 : 0))>();
       SEG_ADD(1);                                            // waiting for older pieces
       __builtin_amdgcn_s_barrier();
@@ -1152,7 +1156,7 @@ static int plan_gemm(const GanConvDesc* d, int op, GemmPlan* pl) {
     if (use_par && parity && d->dtype != GAN_F32 && y.c % 64 == 0 && y.c <= par_maxn && x.c % 32 == 0 && p.vec_store &&
         Wg >= 16 && Wg <= 128 && (Wg & (Wg - 1)) == 0 && p.Hg % (256 / Wg) == 0 && M % 256 == 0 &&
         (M / 256) * (y.c / 64) >= par_minb) {
-      pl->par_npw = (((256 / Wg + 2) * (Wg + 2) + 15) / 16 + 7) / 8;      // ceil(patch pixels / 16) pieces over 8 waves
+      pl->par_npw = (((256 / Wg + 2) * (Wg + 8) + 15) / 16 + 7) / 8;      // ceil(patch pixels / 16) pieces over 8 waves (rows of Wg + 8)
       BM = 256; BN = 64;
     }
   }
@@ -1308,7 +1312,6 @@ static int launch_gemm(const GemmPlan& pl, hipStream_t st) {
   int rc;
   if (pl.par_npw) {
     switch (pl.par_npw) {
-      case 3: return launch_par<T, 3>(pl, st);
       case 4: return launch_par<T, 4>(pl, st);
       case 5: return launch_par<T, 5>(pl, st);
       default: return GAN_E_SHAPE;
