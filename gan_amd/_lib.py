@@ -41,11 +41,19 @@ class GanBwdFuse(C.Structure):
                 ("cols", C.c_int32)]
 
 
+class GanNormFuse(C.Structure):
+    _fields_ = [("out", GanTensor), ("gamma", C.c_void_p), ("beta", C.c_void_p), ("mean", C.c_void_p), ("rstd", C.c_void_p),
+                ("moving_mean", C.c_void_p), ("moving_var", C.c_void_p), ("eps", C.c_float), ("momentum", C.c_float),
+                ("dropmask", C.c_void_p), ("act", C.c_int32), ("slope", C.c_float), ("dgamma", C.c_void_p), ("dbeta", C.c_void_p),
+                ("accumulate", C.c_int32)]
+
+
 class GanConvDesc(_Desc):
     _fields_ = [("struct_size", C.c_uint32), ("dtype", C.c_int32), ("stride", C.c_int32), ("x", GanTensor), ("y", GanTensor), ("w", C.c_void_p),
                 ("w_rows", C.c_int32), ("bias", C.c_void_p), ("act", C.c_int32), ("slope", C.c_float),
                 ("y_f32", C.c_int32), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
-                ("stats_partial", C.c_void_p), ("stats_groups", C.c_int32), ("stats_partial_bytes", C.c_size_t), ("bwd_fuse", C.c_void_p)]
+                ("stats_partial", C.c_void_p), ("stats_groups", C.c_int32), ("stats_partial_bytes", C.c_size_t), ("bwd_fuse", C.c_void_p),
+                ("norm_fuse", C.c_void_p)]
 
 
 class GanWgradDesc(_Desc):

@@ -153,8 +153,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
       const int m = bm0 + wm * WTM + i * 16 + r;
       if (m < p.M) {
 #pragma unroll
-        for (int j = 0; j < NT; ++j)
-          *(f32x4*)(slab + (size_t)m * p.NslabPitch + bn0 + wn * WTN + j * 16 + q * 4) = acc[i][j];
+        for (int j = 0; j < NT; ++j) {
+          const int col = bn0 + wn * WTN + j * 16 + q * 4;
+          // (splitk_norm_kernel reads 8-channel slices of all rows: its slabs are laid out [slice][row][8] so that a slice is contiguous)
+          if (p.skn) *(f32x4*)(slab + ((size_t)(col >> 3) * p.M + m) * 8 + (col & 7)) = acc[i][j];
+          else *(f32x4*)(slab + (size_t)m * p.NslabPitch + col) = acc[i][j];
+        }
       }
     }
   } else if (p.vec_store) {
@@ -1064,6 +1068,227 @@ __global__ __launch_bounds__(256) void splitk_reduce4_kernel(const GemmParams p,
 }
 
 // ------------------------------------------------------------------------------------------------
+// Slab reduce of a SMALL split-K layer that also finishes the layer (GanNormFuse): a workgroup owns 8 channels of every row of
+// a statistics group (<= 1024 rows: 128 row slots x <= 8 rows per thread, kept in registers), so summing the K slabs, the
+// normalisation statistics and the apply pass need no second launch and no second read.
+//   MODE 1 (forward):  y = sum of slabs (stored); mean, rstd (+ moving averages); out = act(dropout(gamma*(y-mean)*rstd+beta))
+//   MODE 2 (backward): da = sum of slabs (+ add); dz = da * act'(z) * mask with z from the saved y (bf_ref);
+//                      out = gamma*rstd*(dz - sum(dz)/R - xhat*sum(dz*xhat)/R); dgamma, dbeta; channels >= bf_cols: y = da
+// Arithmetic per element = splitk_reduce4_kernel + stats_finalize / bwd_finalize + norm_act_fwd / norm_act_bwd (norm.hip); the
+// per-channel sums are taken in a different (fixed) order.  gridDim.y == groups: one group per workgroup; gridDim.y == 1: the
+// workgroup walks the groups in order (moving averages of successive BatchNormalization calls; dgamma / dbeta over the groups).
+template <typename T, int MODE, int KR>       // KR: rows per thread (1, 2, 4, 8): 128 * KR >= rows per group
+__global__ __launch_bounds__(256) void splitk_norm_kernel(const GemmParams p, int P) {
+  constexpr int RS = 128, UNR = 16 / KR;         // 16 slab loads in flight per thread (a row at a time the kernel is latency-bound)
+  __shared__ double red[4][8][2];
+  __shared__ float bc[8][4];
+  const int tid = threadIdx.x, cv = tid & 1, rs = tid >> 1, lane = tid & 63, wave = tid >> 6;
+  const int n = blockIdx.x * 8 + cv * 4;
+  const int groups = p.skn_groups, Mg = p.M / groups, Rg = P * Mg;
+  const size_t sstride = (size_t)p.M * p.NslabPitch;
+  const int g0 = gridDim.y > 1 ? blockIdx.y : 0, g1 = gridDim.y > 1 ? g0 + 1 : groups;
+  auto ld4 = [](const void* base, size_t off, float* out) {
+    if constexpr (sizeof(T) == 4) { const f32x4 q = *(const f32x4*)((const float*)base + off); out[0] = q[0]; out[1] = q[1]; out[2] = q[2]; out[3] = q[3]; }
+    else { float t8[8]; const uint2 q = *(const uint2*)((const T*)base + off); unpack16<T>(make_uint4(q.x, q.y, 0u, 0u), t8); out[0] = t8[0]; out[1] = t8[1]; out[2] = t8[2]; out[3] = t8[3]; }
+  };
+  auto st4 = [](void* base, size_t off, const float* v, bool f32) {
+    if (f32 || sizeof(T) == 4) *(f32x4*)((float*)base + off) = f32x4{v[0], v[1], v[2], v[3]};
+    else *(uint2*)((T*)base + off) = make_uint2(pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]));
+  };
+  // slabs of this kernel's launches: [parity * splits + split][8-channel slice][row][8] (gemm_epilogue, p.skn)
+  auto slab_sum = [&](int par, int m, float* v) {
+    const float* src = p.slab + (size_t)par * p.splits * sstride + ((size_t)blockIdx.x * p.M + m) * 8 + cv * 4;
+    f32x4 sacc = f32x4{0.f, 0.f, 0.f, 0.f};
+    int k = 0;
+    for (; k + 4 <= p.splits; k += 4) {
+      const f32x4 a = *(const f32x4*)(src + (size_t)k * sstride), b = *(const f32x4*)(src + (size_t)(k + 1) * sstride);
+      const f32x4 c = *(const f32x4*)(src + (size_t)(k + 2) * sstride), d = *(const f32x4*)(src + (size_t)(k + 3) * sstride);
+      sacc += a; sacc += b; sacc += c; sacc += d;
+    }
+    for (; k < p.splits; ++k) sacc += *(const f32x4*)(src + (size_t)k * sstride);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = (p.out_f32 || sizeof(T) == 4) ? sacc[e] : (float)(T)sacc[e];      // as stored
+  };
+  // sum of two values per channel over the workgroup's row slots: lanes of equal cv inside a wave, then the 4 waves
+  // (a thread's <= 8 rows are summed in fp32, everything across threads in double, like the finalize kernels of norm.hip)
+  auto block_sums = [&](const float (&f1)[4], const float (&f2)[4], double* t1, double* t2) {     // t1/t2: totals of channel (tid & 7), all threads
+    double s1[4], s2[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      s1[e] = (double)f1[e]; s2[e] = (double)f2[e];
+#pragma unroll
+      for (int o = 2; o < 64; o <<= 1) { s1[e] += __shfl_xor(s1[e], o, 64); s2[e] += __shfl_xor(s2[e], o, 64); }
+    }
+    __syncthreads();                                          // (red is re-used group after group)
+    if (lane < 2) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { red[wave][lane * 4 + e][0] = s1[e]; red[wave][lane * 4 + e][1] = s2[e]; }
+    }
+    __syncthreads();
+    const int c = tid & 7;
+    *t1 = red[0][c][0] + red[1][c][0] + red[2][c][0] + red[3][c][0];
+    *t2 = red[0][c][1] + red[1][c][1] + red[2][c][1] + red[3][c][1];
+  };
+  if (MODE == 2 && blockIdx.x * 8 >= p.bf_cols) {             // skip half of a decoder concat: plain gradient
+    for (int row = rs; row < P * p.M; row += RS) {
+      const int par = row / p.M, m = row - par * p.M;
+      float v[4];
+      slab_sum(par, m, v);
+      st4(p.y, out_pixel_index(p, m, par >> 1, par & 1) * (size_t)p.ypitch + n, v, p.out_f32);
+    }
+    return;
+  }
+  double tg = 0, tb = 0;                                       // MODE 2: dgamma / dbeta of channel (tid & 7) over the groups
+  for (int g = g0; g < g1; ++g) {
+    float va[KR][4], vb[KR][4];                                // MODE 1: y | MODE 2: dz, xhat
+    size_t pix[KR];
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    float mu[4], rsd[4], ga[4], be[4];
+    if (MODE == 2) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        mu[e] = p.bf_mean[g * p.bf_cols + n + e]; rsd[e] = p.bf_rstd[g * p.bf_cols + n + e];
+        ga[e] = p.bf_gamma[n + e]; be[e] = p.bf_beta[n + e];
+      }
+    }
+    // slab sums of the thread's KR rows: 16 loads in flight per thread (a row at a time the kernel was latency-bound: 24 us for
+    // 256 KB per workgroup); the splits of a row are added in order, as splitk_reduce4_kernel adds them
+    {
+      const float* src[KR];
+#pragma unroll
+      for (int k = 0; k < KR; ++k) {
+        int row = rs + RS * k;
+        if (row >= Rg) row = rs < Rg ? rs : 0;                 // (clamped: loaded, never used)
+        const int par = row / Mg, m = g * Mg + (row - par * Mg);
+        pix[k] = out_pixel_index(p, m, par >> 1, par & 1);
+        src[k] = p.slab + (size_t)par * p.splits * sstride + ((size_t)blockIdx.x * p.M + m) * 8 + cv * 4;
+      }
+      f32x4 sacc[KR];
+#pragma unroll
+      for (int k = 0; k < KR; ++k) sacc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+      int sp = 0;
+      for (; sp + UNR <= p.splits; sp += UNR) {
+        f32x4 t[UNR][KR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u)
+#pragma unroll
+          for (int k = 0; k < KR; ++k) t[u][k] = *(const f32x4*)(src[k] + (size_t)(sp + u) * sstride);
+#pragma unroll
+        for (int u = 0; u < UNR; ++u)
+#pragma unroll
+          for (int k = 0; k < KR; ++k) sacc[k] += t[u][k];
+      }
+      for (; sp < p.splits; ++sp) {
+#pragma unroll
+        for (int k = 0; k < KR; ++k) sacc[k] += *(const f32x4*)(src[k] + (size_t)sp * sstride);
+      }
+#pragma unroll
+      for (int k = 0; k < KR; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) va[k][e] = (p.out_f32 || sizeof(T) == 4) ? sacc[k][e] : (float)(T)sacc[k][e];      // as stored
+    }
+#pragma unroll
+    for (int k = 0; k < KR; ++k) {
+      const int row = rs + RS * k;
+      if (row < Rg) {
+        if (MODE == 1) {
+          st4(p.y, pix[k] * (size_t)p.ypitch + n, va[k], p.out_f32);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { s1[e] += va[k][e]; s2[e] = fmaf(va[k][e], va[k][e], s2[e]); }
+        } else {
+          float rf[4], a2[4];
+          if (p.bf_add) {
+            ld4(p.bf_add, pix[k] * (size_t)p.bf_addpitch + n, a2);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) va[k][e] += a2[e];
+          }
+          ld4(p.bf_ref, pix[k] * (size_t)p.bf_refpitch + n, rf);
+          float mk[4] = {1.f, 1.f, 1.f, 1.f};
+          if (p.bf_mode == 3) {
+            const uint32_t w = *(const uint32_t*)(p.bf_mask + pix[k] * (size_t)p.bf_maskpitch + n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) mk[e] = 2.f * (float)((w >> (8 * e)) & 0xff);
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float xh = (rf[e] - mu[e]) * rsd[e];
+            const float z = fmaf(ga[e], xh, be[e]);
+            const float zd = z * mk[e];
+            float d = va[k][e] * mk[e];
+            d = zd > 0.f ? d : (p.bf_mode == 1 ? d * p.bf_slope : 0.f);
+            va[k][e] = d; vb[k][e] = xh;
+            s1[e] += d; s2[e] = fmaf(d, xh, s2[e]);
+          }
+        }
+      }
+    }
+    double t1, t2;
+    block_sums(s1, s2, &t1, &t2);
+    const int c = tid & 7, cn = blockIdx.x * 8 + c;
+    if (MODE == 1) {
+      if (tid < 8) {
+        const double rows = (double)Rg;
+        const double m = t1 / rows;
+        double var = t2 / rows - m * m;
+        if (var < 0) var = 0;
+        const float r = 1.0f / sqrtf((float)var + p.skn_eps);
+        p.skn_mean[g * p.Cout + cn] = (float)m; p.skn_rstd[g * p.Cout + cn] = r;
+        if (p.skn_mmean) {
+          const double adj = rows / (double)(Rg > 1 ? Rg - 1 : 1);
+          p.skn_mmean[cn] += ((float)m - p.skn_mmean[cn]) * (1.f - p.skn_momentum);
+          p.skn_mvar[cn] += ((float)(var * adj) - p.skn_mvar[cn]) * (1.f - p.skn_momentum);
+        }
+        bc[c][0] = (float)m; bc[c][1] = p.skn_gamma[cn] * r; bc[c][2] = p.skn_beta[cn];
+      }
+      __syncthreads();
+      float mu1[4], A[4], b1[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { mu1[e] = bc[cv * 4 + e][0]; A[e] = bc[cv * 4 + e][1]; b1[e] = bc[cv * 4 + e][2]; }
+#pragma unroll
+      for (int k = 0; k < KR; ++k) {
+        if (rs + RS * k < Rg) {
+          float o[4];
+          float mk[4] = {1.f, 1.f, 1.f, 1.f};
+          if (p.skn_mask) {
+            const uint32_t w = *(const uint32_t*)(p.skn_mask + pix[k] * (size_t)p.Cout + n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) mk[e] = 2.f * (float)((w >> (8 * e)) & 0xff);
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float z = fmaf(va[k][e] - mu1[e], A[e], b1[e]);
+            if (p.skn_mask) z *= mk[e];
+            o[e] = apply_act(z, p.skn_act, p.skn_slope);
+          }
+          st4(p.skn_out, pix[k] * (size_t)p.skn_outpitch + n, o, false);
+        }
+      }
+    } else {
+      if (tid < 8) {
+        const float A = p.bf_gamma[cn] * p.bf_rstd[g * p.bf_cols + cn], invR = 1.0f / (float)Rg;
+        bc[c][0] = A; bc[c][1] = -A * ((float)t1 * invR); bc[c][2] = -A * ((float)t2 * invR);
+        tb += t1; tg += t2;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < KR; ++k) {
+        if (rs + RS * k < Rg) {
+          float o[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = fmaf(va[k][e], bc[cv * 4 + e][0], fmaf(vb[k][e], bc[cv * 4 + e][2], bc[cv * 4 + e][1]));
+          st4(p.skn_out, pix[k] * (size_t)p.skn_outpitch + n, o, false);
+        }
+      }
+    }
+  }
+  if (MODE == 2 && tid < 8) {
+    const int cn = blockIdx.x * 8 + tid;
+    if (p.skn_dgamma) p.skn_dgamma[cn] = (p.skn_accumulate ? p.skn_dgamma[cn] : 0.f) + (float)tg;
+    if (p.skn_dbeta) p.skn_dbeta[cn] = (p.skn_accumulate ? p.skn_dbeta[cn] : 0.f) + (float)tb;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // pipeline shape per tile (measured): 128-byte K rows and 2 stages for the 8-wave 256-row tiles (one block per CU),
 // 64-byte rows for 256x64 and 2 stages for 128x128 so that two blocks share a CU, 3 stages with counted vmcnt for the
 // 4-wave 128x64 / 64x128 tiles.
@@ -1206,6 +1431,36 @@ static int plan_gemm(const GanConvDesc* d, int op, GemmPlan* pl) {
   }
   const bool reduce4_ok = p.vec_store && y.c % 4 == 0 && (p.out_f32 || d->dtype != GAN_F32);
   const bool want_stats = d->stats_groups > 0 && bf_mode != 4;
+  // GanNormFuse: a small split-K layer is finished by its slab-reduce kernel (splitk_norm_kernel): <= 1024 rows per group
+  p.skn = 0; p.skn_groups = 0;
+  if (const GanNormFuse* nf = d->norm_fuse; nf && gan_opt("conv.norm_fuse") && splits > 1 && reduce4_ok && want_stats && y.c % 8 == 0 &&
+      !d->bias && d->act == GAN_ACT_NONE && x.n % d->stats_groups == 0 && M % d->stats_groups == 0 &&
+      (long long)P * (M / d->stats_groups) <= 1024) {
+    const int G = d->stats_groups;
+    const int oc = bf_mode ? bf->cols : y.c;
+    const bool out_ok = nf->out.ptr && nf->out.n == y.n && nf->out.h == y.h && nf->out.w == y.w && nf->out.c >= oc && nf->out.pitch % 4 == 0 &&
+                        ((uintptr_t)nf->out.ptr & 7) == 0;
+    if (!bf_mode && out_ok && nf->gamma && nf->beta && nf->mean && nf->rstd && (!nf->moving_mean || nf->moving_var)) {
+      p.skn = 1;
+    } else if (bf_mode >= 1 && bf_mode <= 3 && out_ok && (G == 1 || (long long)P * M <= 4096) && bf->cols % 8 == 0) {
+      p.skn = 2;
+      p.bf_mode = bf_mode; p.bf_cols = bf->cols; p.bf_slope = bf->slope;
+      p.bf_ref = bf->ref.ptr; p.bf_refpitch = bf->ref.pitch;
+      p.bf_add = bf->add.ptr; p.bf_addpitch = bf->add.pitch;
+      p.bf_mean = bf->mean; p.bf_rstd = bf->rstd; p.bf_gamma = bf->gamma; p.bf_beta = bf->beta;
+      p.bf_mask = bf->dropmask; p.bf_maskpitch = bf->mask_pitch;
+    }
+    if (p.skn) {
+      p.skn_groups = G; p.skn_out = nf->out.ptr; p.skn_outpitch = nf->out.pitch;
+      p.skn_gamma = nf->gamma; p.skn_beta = nf->beta; p.skn_mean = nf->mean; p.skn_rstd = nf->rstd;
+      p.skn_mmean = nf->moving_mean; p.skn_mvar = nf->moving_var; p.skn_eps = nf->eps; p.skn_momentum = nf->momentum;
+      p.skn_mask = nf->dropmask; p.skn_act = nf->act; p.skn_slope = nf->slope;
+      p.skn_dgamma = nf->dgamma; p.skn_dbeta = nf->dbeta; p.skn_accumulate = nf->accumulate;
+      pl->stats_chunks = -1;                                   // plan_info()[4]: the launch finishes the layer
+    }
+  }
+  if (p.skn) {
+  } else
   if (want_stats && splits == 1 && p.vec_store && BN <= 64 * 8 && x.n % d->stats_groups == 0) {
     const long long rpg = M / d->stats_groups;            // GEMM rows per statistics group (per parity)
     if (rpg % BM == 0 && (BM == 256 ? 512 : 256) >= BN) {
@@ -1224,7 +1479,7 @@ static int plan_gemm(const GanConvDesc* d, int op, GemmPlan* pl) {
       p.stats = d->stats_partial;
     }
   }
-  if (bf_mode) {
+  if (bf_mode && !p.skn) {
     // the slab-reduce kernel of a split-K launch carries it at no cost (streaming kernel, the slabs are read anyway); a tile
     // epilogue re-reads the reference tensor at the tile's strided pixel order - break-even per launch on the 128/256-column
     // tiles, a gain on the 64-column ones (their act_bwd pass streamed 4 tensors): option conv.bwd_fuse_tile = 0 never, 1 always,
@@ -1336,7 +1591,15 @@ static int launch_gemm(const GemmPlan& pl, hipStream_t st) {
   }
   if (rc) return rc;
   if (pl.p.splits > 1) {
-    if (pl.p.vec_store && pl.p.Cout % 4 == 0 && (pl.p.out_f32 || sizeof(T) == 2)) {
+    if (pl.p.skn) {
+      const dim3 g((unsigned)(pl.p.Cout / 8), (unsigned)((pl.p.skn == 1 && !(pl.p.skn_mmean && pl.p.skn_groups > 1)) ? pl.p.skn_groups : 1));
+      const long long rg = (long long)pl.P * (pl.p.M / pl.p.skn_groups);
+      const int kr = rg <= 128 ? 1 : rg <= 256 ? 2 : rg <= 512 ? 4 : 8;
+#define SKN_LAUNCH(MODE, KRV) hipLaunchKernelGGL((splitk_norm_kernel<T, MODE, KRV>), g, dim3(256), 0, st, pl.p, pl.P)
+      if (pl.p.skn == 1) { if (kr == 1) SKN_LAUNCH(1, 1); else if (kr == 2) SKN_LAUNCH(1, 2); else if (kr == 4) SKN_LAUNCH(1, 4); else SKN_LAUNCH(1, 8); }
+      else { if (kr == 1) SKN_LAUNCH(2, 1); else if (kr == 2) SKN_LAUNCH(2, 2); else if (kr == 4) SKN_LAUNCH(2, 4); else SKN_LAUNCH(2, 8); }
+#undef SKN_LAUNCH
+    } else if (pl.p.vec_store && pl.p.Cout % 4 == 0 && (pl.p.out_f32 || sizeof(T) == 2)) {
       long long total = (long long)pl.P * pl.p.M * (pl.p.Cout / 4);
       hipLaunchKernelGGL(splitk_reduce4_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, pl.p, pl.P);
     } else {
@@ -1355,7 +1618,7 @@ static int run_gemm(const GanConvDesc* d, int op, gan_stream_t stream) {
   hipStream_t st = (hipStream_t)stream;
   const int fam = thin_family(d, op, pl.p);
   if (pl.bf_requested && (fam || !pl.p.bf_mode)) return GAN_E_SHAPE;   // the caller must consult gan_conv_plan_info()[4] first
-  if (!fam && pl.p.stats && (size_t)d->stats_groups * pl.stats_chunks * pl.p.stats_C * 2 * sizeof(float) > d->stats_partial_bytes)
+  if (!fam && pl.p.stats && pl.stats_chunks > 0 && (size_t)d->stats_groups * pl.stats_chunks * pl.p.stats_C * 2 * sizeof(float) > d->stats_partial_bytes)
     return GAN_E_WORKSPACE;                                            // the caller's partial-sums region is too small for this plan
   if (fam) return thin_launch(fam, d, pl.p, st);   // <= 8-channel streaming layers
   if (pl.slab_bytes > d->workspace_bytes || (pl.slab_bytes && !d->workspace)) return GAN_E_WORKSPACE;

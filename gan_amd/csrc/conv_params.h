@@ -23,6 +23,11 @@ struct GemmParams {
   const float* bf_mean; const float* bf_rstd; const float* bf_gamma; const float* bf_beta;
   const unsigned char* bf_mask;
   int bf_refpitch, bf_addpitch, bf_maskpitch, bf_mode, bf_cols; float bf_slope;
+  // small split-K layer finished inside its slab-reduce kernel (GanNormFuse): skn = 1 forward, 2 backward
+  int skn, skn_groups; void* skn_out; int skn_outpitch;
+  const float* skn_gamma; const float* skn_beta; float* skn_mean; float* skn_rstd; float* skn_mmean; float* skn_mvar;
+  float skn_eps, skn_momentum; const unsigned char* skn_mask; int skn_act; float skn_slope;
+  float* skn_dgamma; float* skn_dbeta; int skn_accumulate;
 #ifdef GAN_DIAG
   unsigned long long* diag;  // diagnostic build: per-block stamps
 #endif

@@ -33,12 +33,13 @@ Opt g_opts[] = {
     {"conv.parity_patch", {1}},     // parity-patch kernel for stride-2 transposed convs with 64 output channels
     {"conv.parity_patch_max_n", {64}},
     {"conv.parity_patch_min_blocks", {192}},
-    {"conv.split_target", {512}},   // split K until this many blocks (128-row tiles and smaller)
+    {"conv.split_target", {256}},   // split K until this many blocks (128-row tiles and smaller; 512 before the slab-reduce kernels took over the normalisation)
     {"conv.split_target_skinny", {1024}},
     {"conv.split_target_big", {256}},
     {"conv.split_min_ktiles", {4}},
     {"conv.split_max", {64}},
     {"conv.bwd_fuse_tile", {3}},    // fused backward epilogue on tile epilogues: 0 never, 1 always, 2 not on 64-column tiles, 3 only on them
+    {"conv.norm_fuse", {1}},        // GanNormFuse: small split-K layers finished by their slab-reduce kernel
     {"conv.thin", {7}},             // bit 0: streaming kernels at all, bit 1: thin-N, bit 2: thin-K
     {"wgrad.tile256", {0}},         // 256-row tiles in the 128x128 kernel family
     {"wgrad.pingpong", {1}},

@@ -365,7 +365,26 @@ class _Builder:
                          mask_ptr, mask_pitch, L.ACTS[act], LEAKY_ALPHA, cols if cols is not None else ref.c)
         return (f, groups if name else 0)
 
-    def conv(self, op, x, y, w, w_rows, stride=2, bias=None, act=None, y_f32=0, k_real=None, stats_groups=0, bwd_fuse=None):
+    def fwd_norm_fuse(self, name, a, groups, mean, rstd, act, mask_ptr, update_moving=True):
+        """GanNormFuse for the convolution that produces layer `name`'s pre-normalisation output: when the launch is a small
+        split-K one, its slab-reduce kernel also takes the statistics and writes the activation `a` (self.last_full)."""
+        gk, bk = self.norm_names()
+        eps = BN_EPS if self.norm == 'batchnorm' else IN_EPS
+        mm = mv = None
+        if self.norm == 'batchnorm' and update_moving:
+            mm = self.P.state[name + '.moving_mean'].data_ptr()
+            mv = self.P.state[name + '.moving_variance'].data_ptr()
+        return L.GanNormFuse(a, self.P.ptr(name + gk), self.P.ptr(name + bk), mean.data_ptr(), rstd.data_ptr(), mm, mv, eps, BN_MOMENTUM,
+                             mask_ptr, L.ACTS[act], LEAKY_ALPHA, None, None, 0)
+
+    def bwd_norm_fuse(self, name, dy, want_param_grads, accumulate):
+        """GanNormFuse for the dgrad launch whose bwd_fuse names layer `name`: dy of that layer straight from the slab reduce."""
+        gk, bk = self.norm_names()
+        return L.GanNormFuse(dy, None, None, None, None, None, None, 0.0, 0.0, None, 0, LEAKY_ALPHA,
+                             self.P.ptr(name + gk, 'grad') if want_param_grads else None,
+                             self.P.ptr(name + bk, 'grad') if want_param_grads else None, int(accumulate))
+
+    def conv(self, op, x, y, w, w_rows, stride=2, bias=None, act=None, y_f32=0, k_real=None, stats_groups=0, bwd_fuse=None, norm_fuse=None):
         """stats_groups > 0: ask the GEMM epilogue to also emit normalisation-statistics partials; the number of
         chunks it will write (0 = not fusable for this shape) is left in self.last_stats_chunks.
         bwd_fuse = fuse_spec(...): ask a dgrad launch to start the backward of the layer below in its epilogue;
@@ -375,9 +394,12 @@ class _Builder:
         if bwd_fuse is not None:
             self.keep.append(bwd_fuse[0])
             stats_groups = bwd_fuse[1]
+        if norm_fuse is not None:
+            self.keep.append(norm_fuse)
         d = L.GanConvDesc(self.ctx.dt, stride, x, y, w, w_rows, bias, L.ACTS[act], LEAKY_ALPHA, y_f32,
                           self.ws_ptr, self.ws_bytes, self.ws_ptr if stats_groups else None, stats_groups, 0,
-                          C.addressof(bwd_fuse[0]) if bwd_fuse is not None else None)
+                          C.addressof(bwd_fuse[0]) if bwd_fuse is not None else None,
+                          C.addressof(norm_fuse) if norm_fuse is not None else None)
         opi = {'conv_fwd': 0, 'conv_dgrad': 1, 'convT_fwd': 2, 'convT_dgrad': 3}[op]
         fn = [self.lib.gan_conv2d_fwd, self.lib.gan_conv2d_dgrad, self.lib.gan_convT2d_fwd, self.lib.gan_convT2d_dgrad][opi]
         need = self.lib.gan_conv_workspace_bytes(C.byref(d), opi)
@@ -391,15 +413,16 @@ class _Builder:
         info = (C.c_int32 * 5)()
         self.lib.gan_conv_plan_info(C.byref(d), opi, info)
         self.last_bwd_fused = 0
+        self.last_full = info[4] == -1       # GanNormFuse honoured: the launch finishes the layer (no norm ops follow)
         if bwd_fuse is not None:
             self.last_stats_chunks = 0
-            self.last_bwd_fused = info[4]
+            self.last_bwd_fused = max(info[4], 0)
             if not info[4]:            # this launch shape (thin kernel, odd group size ...) cannot carry it: plain dgrad
                 d.bwd_fuse = None
                 d.stats_partial, d.stats_groups = None, 0
         else:
-            self.last_stats_chunks = info[4] if (stats_groups and not os.environ.get('GAN_AMD_NO_FUSED_STATS')) else 0
-            if stats_groups and not self.last_stats_chunks:
+            self.last_stats_chunks = max(info[4], 0) if stats_groups else 0
+            if stats_groups and not info[4]:
                 d.stats_partial, d.stats_groups = None, 0
         T = 4 if info[3] == 4 else 16
         # algorithmic FLOPs, SURVEY.md 8(d) convention: real channel counts, border taps not discounted
@@ -556,20 +579,24 @@ class GenCall:
             if i == 0:      # conv -> LeakyReLU fused in the GEMM epilogue (apply_norm=False, base_gan.py:180)
                 fwd.append(bd.conv('conv_fwd', x, a_down(0), w.data_ptr(), G_DOWN[0], 2, None, 'lrelu', k_real=C_))
             else:
-                fwd.append(bd.conv('conv_fwd', x, self.y_down[i].view(), w.data_ptr(), G_DOWN[i], 2, stats_groups=groups))
                 mean, rstd = stat(name, G_DOWN[i])
-                fwd += bd.norm_fwd(name, self.y_down[i].view(), a_down(i), groups, mean, rstd, 'lrelu', None,
-                                   fused_chunks=bd.last_stats_chunks, fused_ptr=bd.last_stats_ptr)
+                fwd.append(bd.conv('conv_fwd', x, self.y_down[i].view(), w.data_ptr(), G_DOWN[i], 2, stats_groups=groups,
+                                   norm_fuse=bd.fwd_norm_fuse(name, a_down(i), groups, mean, rstd, 'lrelu', None)))
+                if not bd.last_full:
+                    fwd += bd.norm_fwd(name, self.y_down[i].view(), a_down(i), groups, mean, rstd, 'lrelu', None,
+                                       fused_chunks=bd.last_stats_chunks, fused_ptr=bd.last_stats_ptr)
             x = a_down(i)
         for j in range(7):
             name = f'up{j}'
             xin = self.a7.view() if j == 0 else self.cat[j - 1].view()
             w = P.nat[name + '.kernel']
-            fwd.append(bd.conv('convT_fwd', xin, self.y_up[j].view(), w.data_ptr(), G_UP[j], 2, stats_groups=groups))
             mean, rstd = stat(name, G_UP[j])
             mptr = self.masks[j].data_ptr() if (dropout and j < 3) else None
-            fwd += bd.norm_fwd(name, self.y_up[j].view(), self.cat[j].view(0, G_UP[j]), groups, mean, rstd, 'relu', mptr,
-                               fused_chunks=bd.last_stats_chunks, fused_ptr=bd.last_stats_ptr)
+            fwd.append(bd.conv('convT_fwd', xin, self.y_up[j].view(), w.data_ptr(), G_UP[j], 2, stats_groups=groups,
+                               norm_fuse=bd.fwd_norm_fuse(name, self.cat[j].view(0, G_UP[j]), groups, mean, rstd, 'relu', mptr)))
+            if not bd.last_full:
+                fwd += bd.norm_fwd(name, self.y_up[j].view(), self.cat[j].view(0, G_UP[j]), groups, mean, rstd, 'relu', mptr,
+                                   fused_chunks=bd.last_stats_chunks, fused_ptr=bd.last_stats_ptr)
         fwd.append(bd.conv('convT_fwd', self.cat[6].view(), self.out.view(0, C_), P.nat['last.kernel'].data_ptr(), C_, 2,
                            P.ptr('last.bias'), 'tanh'))
         self.fwd_ops = fwd
@@ -605,12 +632,14 @@ class GenCall:
 
         ops.append(bd.conv('convT_dgrad', self.dpre.view(), self.dcat[6].view(), P.tr['last.kernel'].data_ptr(), 128, 2, k_real=C_,
                            bwd_fuse=up_spec(6)))
-        fused, fptr = bd.last_bwd_fused, bd.last_stats_ptr
+        fused, fptr, full = bd.last_bwd_fused, bd.last_stats_ptr, False
         for j in range(6, -1, -1):
             name = f'up{j}'
             mean, rstd = self.stats[name]
             mptr = self.masks[j].data_ptr() if (self.masks is not None and j < 3) else None
-            if fused:
+            if full:         # the dgrad above finished this layer's backward in its slab-reduce kernel (GanNormFuse)
+                pass
+            elif fused:
                 ops.append(bd.norm_bwd_fused(name, self.y_up[j].view(), self.dcat[j].view(0, G_UP[j]), self.dy_up[j].view(), groups,
                                              mean.data_ptr(), rstd.data_ptr(), fused, fptr, True, accumulate))
             else:
@@ -621,12 +650,14 @@ class GenCall:
             cin = xin.c
             ops.append(bd.wgrad(self.dy_up[j].view(), xin.view(), P.ptr(name + '.kernel', 'grad'), G_UP[j], cin, 2, accumulate))
             if j > 0:
-                spec = up_spec(j - 1)
+                spec, nfz = up_spec(j - 1), bd.bwd_norm_fuse(f'up{j - 1}', self.dy_up[j - 1].view(), True, accumulate)
             else:               # da7: gradient w.r.t. the bottleneck activation = down7's backward
                 m7, r7 = self.stats['down7']
                 spec = bd.fuse_spec(self.y_down[7].view(), None, 'down7', groups, m7.data_ptr(), r7.data_ptr(), 'lrelu')
-            ops.append(bd.conv('convT_dgrad', self.dy_up[j].view(), dxin.view(), P.tr[name + '.kernel'].data_ptr(), cin, 2, bwd_fuse=spec))
-            fused, fptr = bd.last_bwd_fused, bd.last_stats_ptr
+                nfz = bd.bwd_norm_fuse('down7', self.dy_down[7].view(), True, accumulate)
+            ops.append(bd.conv('convT_dgrad', self.dy_up[j].view(), dxin.view(), P.tr[name + '.kernel'].data_ptr(), cin, 2, bwd_fuse=spec,
+                               norm_fuse=nfz))
+            fused, fptr, full = bd.last_bwd_fused, bd.last_stats_ptr, bd.last_full
         dy0 = self.dy_down[0]
         for i in range(7, -1, -1):
             name = f'down{i}'
@@ -642,7 +673,9 @@ class GenCall:
                     ops.append(bd.act_bwd(self.cat[6].view(G_UP[6], 64), da, da2, self.dy_down[0].view(), 'lrelu'))
             else:
                 mean, rstd = self.stats[name]
-                if fused:
+                if full:
+                    pass
+                elif fused:
                     dz = self.da7.view() if i == 7 else self.dA[i].view()
                     ops.append(bd.norm_bwd_fused(name, self.y_down[i].view(), dz, self.dy_down[i].view(), groups,
                                                  mean.data_ptr(), rstd.data_ptr(), fused, fptr, True, accumulate))
@@ -658,7 +691,7 @@ class GenCall:
                 jj = 6 - (i - 1)
                 xin, cin_real = self.cat[jj].view(G_UP[jj], G_DOWN[i - 1]), G_DOWN[i - 1]
             ops.append(bd.wgrad(xin, dyi.view(), P.ptr(name + '.kernel', 'grad'), cin_real, G_DOWN[i], 2, accumulate))
-            fused = 0
+            fused, full = 0, False
             if i > 0:
                 jb = 6 - (i - 1)                                     # layer below: down i-1, its skip gradient sits in dcat[jb]
                 skip = self.dcat[jb].view(G_UP[jb], G_DOWN[i - 1])
@@ -668,8 +701,9 @@ class GenCall:
                     mb, rb = self.stats[f'down{i - 1}']
                     spec = bd.fuse_spec(self.y_down[i - 1].view(), skip, f'down{i - 1}', groups, mb.data_ptr(), rb.data_ptr(), 'lrelu')
                 ops.append(bd.conv('conv_dgrad', dyi.view(), self.dA[i - 1].view(),
-                                   P.nat[name + '.kernel'].data_ptr(), G_DOWN[i - 1], 2, bwd_fuse=spec))
-                fused, fptr = bd.last_bwd_fused, bd.last_stats_ptr
+                                   P.nat[name + '.kernel'].data_ptr(), G_DOWN[i - 1], 2, bwd_fuse=spec,
+                                   norm_fuse=bd.bwd_norm_fuse(f'down{i - 1}', self.dy_down[i - 1].view(), True, accumulate) if i - 1 > 0 else None))
+                fused, fptr, full = bd.last_bwd_fused, bd.last_stats_ptr, bd.last_full
             elif need_dx:
                 ops.append(bd.conv('conv_dgrad', dyi.view(), self.dxin.view(0, C_),
                                    P.nat[name + '.kernel'].data_ptr(), C_, 2))
@@ -835,11 +869,12 @@ class DiscCall:
         fwd = [bd.conv('conv_fwd', self.xin.view(), self.a0.view(), P.tr['down0.kernel'].data_ptr(), 64, 2, None, 'lrelu', k_real=net.cin)]
         prev = self.a0
         for name, co, stride in self.LAYERS[1:4]:
-            fwd.append(bd.conv('conv_fwd', prev.view(), self.y[name].view(), P.tr[name + '.kernel'].data_ptr(), co, stride,
-                               stats_groups=groups))
             mean, rstd = self.stats[name]
-            fwd += bd.norm_fwd(name, self.y[name].view(), self.a[name].view(), groups, mean, rstd, 'lrelu', None,
-                               fused_chunks=bd.last_stats_chunks, fused_ptr=bd.last_stats_ptr)
+            fwd.append(bd.conv('conv_fwd', prev.view(), self.y[name].view(), P.tr[name + '.kernel'].data_ptr(), co, stride,
+                               stats_groups=groups, norm_fuse=bd.fwd_norm_fuse(name, self.a[name].view(), groups, mean, rstd, 'lrelu', None)))
+            if not bd.last_full:
+                fwd += bd.norm_fwd(name, self.y[name].view(), self.a[name].view(), groups, mean, rstd, 'lrelu', None,
+                                   fused_chunks=bd.last_stats_chunks, fused_ptr=bd.last_stats_ptr)
             prev = self.a[name]
         fwd.append(bd.conv('conv_fwd', prev.view(), self.logits.view(), P.tr['last.kernel'].data_ptr(), 1, 1,
                            P.ptr('last.bias'), None, 1))
@@ -868,12 +903,14 @@ class DiscCall:
             ops = [bd.conv('conv_fwd', sv(self.xin), sv(self.a0), P.tr['down0.kernel'].data_ptr(), 64, 2, None, 'lrelu', k_real=net.cin)]
             prev = self.a0
             for name, co, stride in self.LAYERS[1:4]:
-                ops.append(bd.conv('conv_fwd', sv(prev), sv(self.y[name]), P.tr[name + '.kernel'].data_ptr(), co, stride,
-                                   stats_groups=gper))
                 mean, rstd = self.stats[name]
                 lo, hi = call * gper * co, (call + 1) * gper * co
-                ops += bd.norm_fwd(name, sv(self.y[name]), sv(self.a[name]), gper, mean[lo:hi], rstd[lo:hi], 'lrelu', None,
-                                   fused_chunks=bd.last_stats_chunks, fused_ptr=bd.last_stats_ptr)
+                ops.append(bd.conv('conv_fwd', sv(prev), sv(self.y[name]), P.tr[name + '.kernel'].data_ptr(), co, stride,
+                                   stats_groups=gper,
+                                   norm_fuse=bd.fwd_norm_fuse(name, sv(self.a[name]), gper, mean[lo:hi], rstd[lo:hi], 'lrelu', None)))
+                if not bd.last_full:
+                    ops += bd.norm_fwd(name, sv(self.y[name]), sv(self.a[name]), gper, mean[lo:hi], rstd[lo:hi], 'lrelu', None,
+                                       fused_chunks=bd.last_stats_chunks, fused_ptr=bd.last_stats_ptr)
                 prev = self.a[name]
             ops.append(bd.conv('conv_fwd', sv(prev), sv(self.logits), P.tr['last.kernel'].data_ptr(), 1, 1,
                                P.ptr('last.bias'), None, 1))
@@ -911,12 +948,14 @@ class DiscCall:
 
         ops.append(bd.conv('conv_dgrad', dl, gv(self.dA['conv']), P.nat['last.kernel'].data_ptr(), 512, 1, k_real=1,
                            bwd_fuse=spec_for('conv')))
-        fused, fptr = bd.last_bwd_fused, bd.last_stats_ptr
+        fused, fptr, full = bd.last_bwd_fused, bd.last_stats_ptr, False
         order = [('conv', 'down2', 1, 256), ('down2', 'down1', 2, 128), ('down1', 'down0', 2, 64)]
         for name, prev, stride, cprev in order:
             mean, rstd = self.stats[name]
             c = self.y[name].c
-            if fused:
+            if full:
+                pass
+            elif fused:
                 ops.append(bd.norm_bwd_fused(name, sv(self.y[name]), gv(self.dA[name]), gv(self.dy[name]), groups,
                                              mean.data_ptr() + 4 * stat_off * c, rstd.data_ptr() + 4 * stat_off * c, fused, fptr,
                                              wgrads, accumulate))
@@ -927,8 +966,9 @@ class DiscCall:
             if wgrads:
                 ops.append(bd.wgrad(sv(self.a[prev]), gv(self.dy[name]), P.ptr(name + '.kernel', 'grad'), cprev, c, stride, accumulate))
             ops.append(bd.conv('conv_dgrad', gv(self.dy[name]), gv(self.dA[prev]), P.nat[name + '.kernel'].data_ptr(), cprev, stride,
-                               bwd_fuse=spec_for(prev)))
-            fused, fptr = bd.last_bwd_fused, bd.last_stats_ptr
+                               bwd_fuse=spec_for(prev),
+                               norm_fuse=bd.bwd_norm_fuse(prev, gv(self.dy[prev]), wgrads, accumulate) if prev != 'down0' else None))
+            fused, fptr, full = bd.last_bwd_fused, bd.last_stats_ptr, bd.last_full
         dy0 = self.dA['down0'] if fused else self.dy['down0']
         if not fused:
             ops.append(bd.act_bwd(sv(self.a0), gv(self.dA['down0']), None, gv(self.dy['down0']), 'lrelu'))

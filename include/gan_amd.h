@@ -66,6 +66,31 @@ typedef struct GanBwdFuse {
   int32_t cols;              /* multiple of 8 */
 } GanBwdFuse;
 
+/* Optional: a split-K launch of a SMALL layer finishes the whole layer in its slab-reduce kernel (one launch instead of
+ * reduce + statistics finalize + apply): a workgroup owns 8 channels of all rows of a statistics group (at most 1024 rows), so
+ * it sums the K slabs, takes the statistics and applies them without leaving the kernel.
+ * Forward entry points (with GanConvDesc.stats_groups): y = conv output as usual, out = act(dropout(gamma*(y-mean)*rstd+beta))
+ * (Conv -> BN|IN -> [Dropout] -> act of base_gan.py:77-87, :106-120); mean / rstd / moving averages are written as
+ * gan_norm_stats would.  dgrad entry points (with GanConvDesc.bwd_fuse, which names the layer below): out = dy of that layer,
+ * dgamma / dbeta accumulated; the first bwd_fuse->cols channels of GanConvDesc.y then receive dz as usual.
+ * Honoured only when gan_conv_plan_info()[4] == -1; otherwise the launch behaves as without it. */
+typedef struct GanNormFuse {
+  GanTensor out;
+  const float* gamma;
+  const float* beta;
+  float* mean;               /* forward: [groups][c] written */
+  float* rstd;
+  float* moving_mean;        /* forward, optional */
+  float* moving_var;
+  float eps, momentum;
+  const uint8_t* dropmask;   /* forward, optional: dense 0/1 bytes [n][h][w][c] */
+  int32_t act;
+  float slope;
+  float* dgamma;             /* backward, optional */
+  float* dbeta;
+  int32_t accumulate;
+} GanNormFuse;
+
 typedef struct GanConvDesc {
   uint32_t struct_size;  /* sizeof(GanConvDesc) of the caller's build */
   int32_t dtype;
@@ -84,6 +109,7 @@ typedef struct GanConvDesc {
   int32_t stats_groups;  /* laid out [group][chunk][y.c][2]; emitted only if gan_conv_plan_info()[4] > 0     */
   size_t stats_partial_bytes; /* size of that region: groups * chunks * channels * 8 bytes are written (GAN_E_WORKSPACE if short) */
   const GanBwdFuse* bwd_fuse; /* optional (dgrad entry points only), see above */
+  const GanNormFuse* norm_fuse; /* optional, see above */
 } GanConvDesc;
 
 /* Conv2D(k4, strides=s, no bias | bias) — base_gan.py:77-79 ('same', s=2), :145-148 and :157-161
@@ -99,7 +125,9 @@ int gan_convT2d_fwd(const GanConvDesc* d, gan_stream_t stream);
  * w = transposed NK copy ([tap][cin][cout]). */
 int gan_convT2d_dgrad(const GanConvDesc* d, gan_stream_t stream);
 size_t gan_conv_workspace_bytes(const GanConvDesc* d, int op /*0 conv_fwd,1 conv_dgrad,2 convT_fwd,3 convT_dgrad*/);
-/* launch plan the library picks for this problem: info[5] = {BM, BN, splitK, parities, fused-stats chunks per group} */
+/* launch plan the library picks for this problem: info[5] = {BM, BN, splitK, parities, fused-stats chunks per group}
+ * (BM = 0: streaming kernel family BN; BM = 1024: parity-patch kernel; info[4] = -1: norm_fuse is honoured, the launch
+ * finishes the layer) */
 int gan_conv_plan_info(const GanConvDesc* d, int op, int32_t* info);
 
 typedef struct GanWgradDesc {
@@ -300,10 +328,10 @@ const char* gan_version(void);
  * change them, and a change applies to the entry-point calls that follow it (each call plans for itself).  Unknown key:
  * GAN_E_ARG.  Keys (default): conv.big_tiles (1), conv.q128 (55), conv.q256n (80), conv.big_min_blocks (128),
  * conv.tall64 (1), conv.pingpong (1), conv.parity_patch (1), conv.parity_patch_max_n (64),
- * conv.parity_patch_min_blocks (192), conv.split_target (512), conv.split_target_skinny (1024),
+ * conv.parity_patch_min_blocks (192), conv.split_target (256), conv.split_target_skinny (1024),
  * conv.split_target_big (256), conv.split_min_ktiles (4), conv.split_max (64), conv.bwd_fuse_tile (3: the fused backward
  * epilogue rides on 64-column tile epilogues only; 0 never, 1 on every tile, 2 not on 64-column tiles), conv.thin (7: bit 0
- * streaming kernels for the <= 8-channel layers, bit 1 thin-N, bit 2 thin-K), wgrad.tile256 (0), wgrad.pingpong (1),
+ * streaming kernels for the <= 8-channel layers, bit 1 thin-N, bit 2 thin-K), conv.norm_fuse (1), wgrad.tile256 (0), wgrad.pingpong (1),
  * wgrad.pingpong_min_rows (0 = automatic), wgrad.pingpong_128 (0), wgrad.pingpong_min_gflop (30),
  * wgrad.split_target (512). */
 int gan_set_option(const char* key, int32_t value);

@@ -460,6 +460,131 @@ def test_parity_patch_kernel_at_baseline_shape(planner_options):
 
 
 
+NORMFUSE_CASES = [  # (op, N, H of x, Cin, Cout, groups, act, dropout)
+    ('conv_fwd', 16, 8, 512, 512, 1, 'lrelu', False),     # generator down5 at batch 16: M = 256, BatchNorm over the batch
+    ('conv_fwd', 16, 16, 512, 512, 1, 'lrelu', False),    # down4: M = 1024 (8 rows per thread)
+    ('conv_fwd', 4, 4, 512, 512, 4, 'lrelu', False),      # InstanceNorm: one group per image, 4 rows each
+    ('conv_fwd', 2, 2, 512, 512, 2, 'lrelu', False),      # 1 x 1 maps: one row per group
+    ('convT_fwd', 16, 2, 512, 512, 1, 'relu', True),      # up1: four parities, dropout
+    ('convT_fwd', 4, 8, 1024, 512, 2, 'relu', False),     # two BatchNorm calls batched (moving averages in call order)
+]
+
+
+@pytest.mark.parametrize("case", NORMFUSE_CASES)
+def test_split_k_layer_finished_by_its_slab_reduce(ctx, case, planner_options):
+    """GanNormFuse, forward: conv -> BN|IN -> [dropout] -> activation (base_gan.py:77-87, :106-120) of a small split-K layer in
+    two launches (GEMM + slab reduce that also normalises) equals the four-launch path (slab reduce, statistics finalize,
+    apply), which the tests above check against the oracle."""
+    from gan_amd import _lib as L
+    from gan_amd.nets import Buf
+    op, N, H, ci, co, G, act, drop = case
+    rng = np.random.default_rng(23)
+    x = q(ctx, rng.standard_normal((N, H, H, ci)))
+    w = q(ctx, 0.05 * rng.standard_normal((4, 4, ci, co) if op == 'conv_fwd' else (4, 4, co, ci)))
+    xb, xv = dev(ctx, x)
+    nat, tr = prep(ctx, w)
+    Ho = H // 2 if op == 'conv_fwd' else 2 * H
+    f32 = torch.float32
+    gamma = torch.from_numpy((1 + 0.2 * rng.standard_normal(co)).astype(np.float32)).to(ctx.device)
+    beta = torch.from_numpy((0.2 * rng.standard_normal(co)).astype(np.float32)).to(ctx.device)
+    tm = torch.from_numpy((rng.random((N, Ho, Ho, co)) > 0.5).astype(np.uint8)).to(ctx.device) if drop else None
+    fn = ctx.lib.gan_conv2d_fwd if op == 'conv_fwd' else ctx.lib.gan_convT2d_fwd
+    opi = 0 if op == 'conv_fwd' else 2
+    info = (C.c_int32 * 5)()
+    res = []
+    for fuse in (1, 0):
+        planner_options('conv.norm_fuse', fuse)
+        yb, ab = Buf(ctx, N, Ho, Ho, co), Buf(ctx, N, Ho, Ho, co + 8)
+        mean, rstd = torch.zeros(G * co, dtype=f32, device=ctx.device), torch.zeros(G * co, dtype=f32, device=ctx.device)
+        mm, mv = torch.zeros(co, dtype=f32, device=ctx.device), torch.ones(co, dtype=f32, device=ctx.device)
+        part = torch.zeros(1 << 20, dtype=f32, device=ctx.device)
+        nf = L.GanNormFuse(ab.view(8, co), gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(), rstd.data_ptr(), mm.data_ptr(), mv.data_ptr(),
+                           1e-3, 0.99, tm.data_ptr() if drop else None, L.ACTS[act], 0.3, None, None, 0)
+        d = L.GanConvDesc(ctx.dt, 2, xv, yb.view(), (tr if op == 'conv_fwd' else nat).data_ptr(), co, None, 0, 0.3, 0, ctx.ws_ptr, ctx.ws_bytes,
+                          part.data_ptr(), G, part.numel() * 4, None, C.addressof(nf))
+        assert ctx.lib.gan_conv_plan_info(C.byref(d), opi, info) == 0
+        assert info[2] > 1, "shape chosen to be split-K"
+        assert (info[4] == -1) == bool(fuse), list(info)
+        assert fn(C.byref(d), ctx.stream()) == 0
+        if not fuse:
+            nd = L.GanNormDesc(ctx.dt, yb.view(), ab.view(8, co), G, 1e-3, gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                               mm.data_ptr(), mv.data_ptr(), 0.99, tm.data_ptr() if drop else None, L.ACTS[act], 0.3, part.data_ptr(), part.numel() * 4)
+            if info[4] > 0:
+                assert ctx.lib.gan_norm_stats_finalize(C.byref(nd), info[4], ctx.stream()) == 0
+            else:
+                nd.workspace, nd.workspace_bytes = ctx.ws_ptr, ctx.ws_bytes
+                assert ctx.lib.gan_norm_stats(C.byref(nd), ctx.stream()) == 0
+            assert ctx.lib.gan_norm_act_fwd(C.byref(nd), ctx.stream()) == 0
+        torch.cuda.synchronize()
+        res.append((host(yb), host(ab, 8, co), mean.cpu().numpy(), rstd.cpu().numpy(), mm.cpu().numpy(), mv.cpu().numpy(), host(ab, 0, 8)))
+    a, b = res
+    assert np.array_equal(a[0], b[0])                       # y: the same slab sums
+    assert rel(a[2], b[2].astype(np.float64)) < 1e-5 and rel(a[3], b[3].astype(np.float64)) < 1e-5
+    assert rel(a[4], b[4].astype(np.float64)) < 1e-5 and rel(a[5], b[5].astype(np.float64)) < 1e-5
+    assert rel(a[1], b[1]) < {'f32': 1e-5, 'bf16': 1e-2, 'f16': 2e-3}[ctx.dtype]     # (an ulp of the storage type where rstd differs in its last bit)
+    assert np.all(a[6] == 0)
+
+
+@pytest.mark.parametrize("case", [('convT_dgrad', 16, 16, 512, 1024, 1, 'relu+mask', 512), ('convT_dgrad', 16, 4, 512, 1024, 1, 'relu', 512),
+                                  ('conv_dgrad', 16, 4, 512, 512, 1, 'lrelu', 512), ('conv_dgrad', 2, 4, 512, 512, 2, 'lrelu', 512),
+                                  ('convT_dgrad', 2, 16, 512, 512, 2, 'relu', 512)])
+def test_split_k_dgrad_finishes_the_layer_below(ctx, case, planner_options):
+    """GanNormFuse, backward: the slab reduce of a small split-K dgrad writes dy of the layer below (and dgamma, dbeta; the skip
+    half of a decoder concat unchanged) = the fused-epilogue path (dz + partial sums, finalize, apply) checked above."""
+    from gan_amd import _lib as L
+    from gan_amd.nets import Buf
+    op, N, H, cdy, cg, G, kind, cols = case
+    rng = np.random.default_rng(29)
+    Hg = 2 * H if op == 'conv_dgrad' else H // 2
+    dy = q(ctx, rng.standard_normal((N, H, H, cdy)))
+    w = q(ctx, 0.05 * rng.standard_normal((4, 4, cg, cdy) if op == 'conv_dgrad' else (4, 4, cdy, cg)))
+    nat, tr = prep(ctx, w)
+    wt = nat if op == 'conv_dgrad' else tr
+    dyb, dyv = dev(ctx, dy)
+    ref = q(ctx, rng.standard_normal((N, Hg, Hg, cols)) * 1.3 + 0.2)
+    refb, refv = dev(ctx, ref)
+    addb, addv = dev(ctx, q(ctx, rng.standard_normal((N, Hg, Hg, cols))), pitch=cols + 8)
+    f32 = torch.float32
+    act = 'lrelu' if kind == 'lrelu' else 'relu'
+    tm = torch.from_numpy((rng.random((N, Hg, Hg, cols)) > 0.5).astype(np.uint8)).to(ctx.device) if kind == 'relu+mask' else None
+    gamma = torch.from_numpy((1 + 0.2 * rng.standard_normal(cols)).astype(np.float32)).to(ctx.device)
+    beta = torch.from_numpy((0.2 * rng.standard_normal(cols)).astype(np.float32)).to(ctx.device)
+    mean, rstd = torch.zeros(G * cols, dtype=f32, device=ctx.device), torch.zeros(G * cols, dtype=f32, device=ctx.device)
+    nd = L.GanNormDesc(ctx.dt, refv, refv, G, 1e-3, gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(), rstd.data_ptr(), None, None,
+                       0.99, None, L.ACTS[act], 0.3, ctx.ws_ptr, ctx.ws_bytes)
+    assert ctx.lib.gan_norm_stats(C.byref(nd), ctx.stream()) == 0
+    fn = ctx.lib.gan_conv2d_dgrad if op == 'conv_dgrad' else ctx.lib.gan_convT2d_dgrad
+    opi = 1 if op == 'conv_dgrad' else 3
+    z = L.GanTensor(None, 0, 0, 0, 0, 0)
+    bf = L.GanBwdFuse(refv, addv, mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), tm.data_ptr() if tm is not None else None,
+                      cols, L.ACTS[act], 0.3, cols)
+    info = (C.c_int32 * 5)()
+    res = []
+    for fuse in (1, 0):
+        planner_options('conv.norm_fuse', fuse)
+        dzb, outb = Buf(ctx, N, Hg, Hg, cg), Buf(ctx, N, Hg, Hg, cols)
+        dg, db = torch.full((cols,), 0.5, dtype=f32, device=ctx.device), torch.full((cols,), -0.25, dtype=f32, device=ctx.device)
+        part = torch.zeros(4 << 20, dtype=f32, device=ctx.device)
+        nf = L.GanNormFuse(outb.view(), None, None, None, None, None, None, 0.0, 0.0, None, 0, 0.3, dg.data_ptr(), db.data_ptr(), 1)
+        d = L.GanConvDesc(ctx.dt, 2, dyv, dzb.view(), wt.data_ptr(), cg, None, 0, 0.3, 0, ctx.ws_ptr, ctx.ws_bytes,
+                          part.data_ptr(), G, part.numel() * 4, C.addressof(bf), C.addressof(nf))
+        assert ctx.lib.gan_conv_plan_info(C.byref(d), opi, info) == 0
+        assert info[2] > 1 and (info[4] == -1) == bool(fuse) and info[4] != 0, list(info)
+        assert fn(C.byref(d), ctx.stream()) == 0
+        if not fuse:
+            fd = L.GanNormBwdDesc(ctx.dt, refv, dzb.view(0, cols), z, outb.view(), G, gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(),
+                                  rstd.data_ptr(), None, 0, 0.3, dg.data_ptr(), db.data_ptr(), 1, part.data_ptr(), part.numel() * 4)
+            assert ctx.lib.gan_norm_act_bwd_fused(C.byref(fd), info[4], ctx.stream()) == 0
+        torch.cuda.synchronize()
+        res.append((host(outb), dg.cpu().numpy().astype(np.float64), db.cpu().numpy().astype(np.float64), host(dzb, cols) if cols < cg else None))
+    a, b = res
+    tol = {'f32': 2e-5, 'bf16': 2e-2, 'f16': 3e-3}[ctx.dtype]
+    assert rel(a[0], b[0]) < tol
+    assert rel(a[1], b[1]) < max(tol, 1e-4) and rel(a[2], b[2]) < max(tol, 1e-4)
+    if cols < cg:
+        assert np.array_equal(a[3], b[3])                   # skip half: the plain gradient
+
+
 def test_wgrad_tr_read_matches_plain(ctx, monkeypatch):
     """bf16 wgrad fragments come from ds_read_b64_tr_b16; fp32 from ds_read_b32.  Exact integer data with an
     asymmetric pattern catches any row/column mix-up in the transposing read."""
