@@ -926,7 +926,7 @@ class DiscCall:
         per = self.B * self.dlogits.h * self.dlogits.w * 8
         return self.dlogits.t.data_ptr() + call * per * self.dlogits.t.element_size()
 
-    def _chain(self, n0, n, groups, stat_off, wgrads, need_dx, accumulate):
+    def _chain(self, n0, n, groups, stat_off, wgrads, need_dx, accumulate, dx_dst=None, dx_c0=0):
         """Backward over samples [n0, n0+n).  Scratch gradients always live at samples [0, n) of the dA/dy
         buffers; saved forward tensors are read at [n0, n0+n)."""
         bd, P = (self._bd2 if wgrads else self._bd), self.net.params
@@ -975,8 +975,12 @@ class DiscCall:
         if wgrads:
             ops.append(bd.wgrad(sv(self.xin), gv(dy0), P.ptr('down0.kernel', 'grad'), self.net.cin, 64, 2, accumulate))
         if need_dx:
-            ops.append(bd.conv('conv_dgrad', gv(dy0), self.dxin.view(0, self.net.cin, 0, n),
-                               P.nat['down0.kernel'].data_ptr(), self.net.cin, 2))
+            if dx_dst is not None:      # only channels [dx_c0, dx_c0 + dx_dst.c) of the input gradient, written where the caller wants them
+                wk = P.nat['down0.kernel']
+                ops.append(bd.conv('conv_dgrad', gv(dy0), dx_dst, wk.data_ptr() + dx_c0 * wk.shape[2] * wk.element_size(), self.net.cin, 2))
+            else:
+                ops.append(bd.conv('conv_dgrad', gv(dy0), self.dxin.view(0, self.net.cin, 0, n),
+                                   P.nat['down0.kernel'].data_ptr(), self.net.cin, 2))
         return ops
 
     def params_ops(self, accumulate=False):
@@ -992,10 +996,11 @@ class DiscCall:
             self._cache[key] = self._chain(0, self.N, self.groups, 0, True, False, accumulate)
         self.ctx.run(self._cache[key], lane=2 if self.ctx.multistream else 0)      # (ops carry lane-2/3 workspaces either way)
 
-    def backward_input(self, call):
+    def backward_input(self, call, dst=None, c0=0):
         """Pass B: gradient w.r.t. the input of invocation `call`; its dlogits must be in self.dlogits_b.
-        Result in self.dxin (8-channel padded)."""
-        key = ('B', call)
+        Result in self.dxin (8-channel padded), or - dst: a GanTensor view - input channels [c0, c0 + dst.c) straight into
+        dst (the generator's upstream-gradient slot: no copy, and for Pix2Pix half the output channels of the layer)."""
+        key = ('B', call, dst.ptr if dst is not None else None, c0)
         if key not in self._cache:
-            self._cache[key] = self._chain(call * self.B, self.B, self.gper, call * self.gper, False, True, False)
+            self._cache[key] = self._chain(call * self.B, self.B, self.gper, call * self.gper, False, True, False, dst, c0)
         self.ctx.run(self._cache[key])

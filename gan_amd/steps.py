@@ -223,8 +223,7 @@ class Pix2PixStep(_StepBase):
                                                  d.dlogits_ptr(1), 8, self.lam, lp + 8, lp, lp + 4, lp + 12,
                                                  self.bce_ws.data_ptr(), self.ctx.ls_ptr, self.ctx.stream()), "patchgan_losses")
         if training:
-            d.backward_input(1)                                       # dL_G/d gen through D(fake), pre-update D
-            self._copy(d.dxin.view(Cc, Cc), g.dgen2.view(0, Cc))
+            d.backward_input(1, dst=g.dgen2.view(0, Cc), c0=Cc)        # dL_G/d gen through D(fake), pre-update D: the `gen` channels only
             if phase == 3:                                            # bucketed data-parallel schedule: the caller stages G's backward
                 return self.losses
             # two independent chains: D's parameter gradients (pix2pix.py:211) beside G's backward (:210)
@@ -547,11 +546,11 @@ class CycleGANStep(_StepBase):
             # gradients and the gradient w.r.t. fake_y / fake_x (computed once, used twice)
             cx.backward(need_dx=True, accumulate=False)               # G_f grads (cycle_x), d/d fake_y
             cy.backward(need_dx=True, accumulate=False)               # G_g grads (cycle_y), d/d fake_x
-            dy.backward_input(1)                                      # adversarial term through D_y(fake_y)
-            self._copy(dy.dxin.view(0, Cc), fy.dgen.view(0, Cc)); self._copy(cx.dxin.view(0, Cc), fy.dgen2.view(0, Cc))
+            dy.backward_input(1, dst=fy.dgen.view(0, Cc))             # adversarial term through D_y(fake_y)
+            self._copy(cx.dxin.view(0, Cc), fy.dgen2.view(0, Cc))
             fy.backward(use_dgen2=True, accumulate=True)              # G_g
-            dx.backward_input(1)
-            self._copy(dx.dxin.view(0, Cc), fx.dgen.view(0, Cc)); self._copy(cy.dxin.view(0, Cc), fx.dgen2.view(0, Cc))
+            dx.backward_input(1, dst=fx.dgen.view(0, Cc))
+            self._copy(cy.dxin.view(0, Cc), fx.dgen2.view(0, Cc))
             fx.backward(use_dgen2=True, accumulate=True)              # G_f
             main, lane2 = self.ctx.lane_stream(0), self.ctx.lane_stream(2)
             if phase == 0 and self.ctx.ms_mode == 2:
@@ -600,10 +599,10 @@ class CycleGANStep(_StepBase):
         if training:
             cx.backward(need_dx=True, accumulate=False)               # G_f grads (cycle_x), d/d fake_y
             cy.backward(need_dx=True, accumulate=False)               # G_g grads (cycle_y), d/d fake_x
-            dy.backward_input(1)                                      # adversarial term through D_y(fake_y)
-            self._copy(dy.dxin.view(0, Cc), fy.dgen_view()); self._copy(cx.dxin.view(0, Cc), fy.dgen_view(second=True))
-            dx.backward_input(1)
-            self._copy(dx.dxin.view(0, Cc), fx.dgen_view()); self._copy(cy.dxin.view(0, Cc), fx.dgen_view(second=True))
+            dy.backward_input(1, dst=fy.dgen_view())                  # adversarial term through D_y(fake_y)
+            self._copy(cx.dxin.view(0, Cc), fy.dgen_view(second=True))
+            dx.backward_input(1, dst=fx.dgen_view())
+            self._copy(cy.dxin.view(0, Cc), fx.dgen_view(second=True))
             # second upstream slot of the identity halves stays zero (never written); one backward per generator covers the
             # adversarial + cycle gradient of fake_* and the identity gradient of same_*
             gA.backward(use_dgen2=True, accumulate=True)              # G_g
