@@ -12,6 +12,7 @@ import numpy as np
 import torch
 
 from . import data as D
+from . import ddp
 from .base_gan import GAN
 from .checkpoint import Checkpoint, CheckpointManager, latest_checkpoint
 from .steps import CycleGANStep
@@ -34,8 +35,16 @@ class CycleGAN(GAN):
         self.generator_g_optimizer, self.generator_f_optimizer = mk(self.generator_g), mk(self.generator_f)
         self.discriminator_x_optimizer, self.discriminator_y_optimizer = mk(self.discriminator_x), mk(self.discriminator_y)
         self._steps = {}
+        self.dist = ddp.DistInfo(0, 1, self.config.get('device'))
         self._rng = np.random.default_rng(seed)
         self.sync = None
+
+    def enable_data_parallel(self, info, wire='bf16'):
+        """As Pix2Pix.enable_data_parallel: one process per GPU, gradients of the four networks averaged over the ranks."""
+        self.dist = info
+        if info.world > 1:
+            self._rng = np.random.default_rng(int(self.config.get('seed', 123)) + 7919 * info.rank)
+            self.sync = ddp.GradSync([m.net.params.grad for m in self._models()], compress_bf16=(wire == 'bf16'), lib=self.ctx.lib)
 
     def _models(self):
         return (self.generator_g, self.generator_f, self.discriminator_x, self.discriminator_y)
@@ -73,6 +82,7 @@ class CycleGAN(GAN):
         val_Y = random.sample([i for i in cy], val_obs_Y)
         train_X = [i for i in cx if i not in test and i not in val_X]
         train_Y = [i for i in cy if i not in val_Y]
+        train_X, train_Y, val_X, val_Y = (ddp.shard_files(f, self.dist.rank, self.dist.world) for f in (train_X, train_Y, val_X, val_Y))
         bs, dev, sd = self.config["batch_size"], self.ctx.device, self.config['seed']
         return (D.Batches(fx(train_X), self.process_images_train, bs, dev, shuffle_seed=sd),
                 D.Batches(fy(train_Y), self.process_images_train, bs, dev, shuffle_seed=sd + 1),
@@ -99,7 +109,10 @@ class CycleGAN(GAN):
                               seed=int(self.config.get('seed', 123)), mask_stream=0 if training else 16, nets=tuple(m.net for m in self._models()))
             st.sync = self.sync
             saved = [(ps, ps.master.clone(), ps.m.clone(), ps.v.clone(), ps.step.clone()) for ps in (m.net.params for m in self._models())]
+            from .pix2pix import _step_state, _restore_step_state
+            extra = _step_state(self.ctx, st)
             replay = st.capture(training=training)
+            _restore_step_state(extra)
             for ps, w, m, v, step in saved:          # capture() runs warm-up steps: undo them
                 ps.master.copy_(w); ps.m.copy_(m); ps.v.copy_(v); ps.step.copy_(step); ps.prepare()
             self._steps[key] = (st, replay)
@@ -137,12 +150,16 @@ class CycleGAN(GAN):
         example = next(it)[0]
         it.close()
         samples = os.path.join(output_path, 'test_images')
-        os.makedirs(samples, exist_ok=True)
+        if self.dist.is_main:
+            os.makedirs(samples, exist_ok=True)
         save = checkpoint_manager.save if checkpoint_manager is not None else (lambda: None)
         sample = lambda epoch: self.generate_images(self.generator_g, example[:1], os.path.join(samples, f"epoch_{epoch}.png"))
+        if not self.dist.is_main:
+            save = sample = (lambda *a: None)
         return run_epochs(self.config['epochs'], list(cyclegan_losses()), lambda: self._zipped(train_X, train_Y),
                           lambda: self._zipped(val_X, val_Y), self.train_step, save, sample,
-                          ('Total X->Y Generator Loss', 'Discriminator Y Loss'))
+                          ('Total X->Y Generator Loss', 'Discriminator Y Loss'),
+                          epoch_mean=lambda acc, n: ddp.mean_over_ranks(acc, n, self.dist))
 
     def predict(self, predict_ds, output_path: str):
         plot_path = os.path.join(output_path, 'prediction_images')
@@ -178,6 +195,9 @@ def parse_opt(argv=None):
     parser.add_argument('--weights', type=str, help='path to pretrained model weights for prediction', required='--predict' in argv)
     parser.add_argument('--dtype', type=str, default='bf16', choices=['bf16', 'f16', 'f32'])
     parser.add_argument('--device', type=str, default='cuda:0')
+    parser.add_argument('--dist-backend', type=str, default='nccl', choices=['nccl', 'gloo'],
+                        help='under torchrun (one process per GPU): collective backend; nccl = RCCL over xGMI')
+    parser.add_argument('--wire', type=str, default='bf16', choices=['bf16', 'f32'], help='gradient all-reduce wire format')
     args = parser.parse_args(argv)
     assert (args.img_size == 256) or (args.img_size == 512), "img-size currently only supported for 256 x 256 or 512 x 512 pixels!"
     assert (args.validation_size > 0.0 and args.validation_size <= 0.3), "validation size is a proportion and bounded between 0-0.3!"
@@ -186,32 +206,43 @@ def parse_opt(argv=None):
 
 
 def main(opt):
-    run = Run(opt.output, log_to_file=opt.logging == 'true', strict_logs=False)
+    """One GPU, or `torchrun --nproc-per-node N cycle_gan.py --train ...` (data parallel, as gan_amd.pix2pix.main)."""
+    info = ddp.init_from_env(opt.device, opt.dist_backend)
+    opt.device = info.device or opt.device
+    run = Run(opt.output, log_to_file=opt.logging == 'true' and info.is_main, strict_logs=False, writer=info.is_main)
     try:
         cgan = CycleGAN(vars(opt))
+        if opt.train:
+            cgan.enable_data_parallel(info, opt.wire)
         names = ('generator_g', 'generator_f', 'discriminator_x', 'discriminator_y')
         objects = {n: getattr(cgan, n) for n in names}
         objects.update({n + '_optimizer': getattr(cgan, n + '_optimizer') for n in names})
         checkpoint = Checkpoint(**objects)                     # object names of cycle_gan.py:437-444
         run.write_json('config.json', cgan.config)
         if opt.predict:
-            dataset = cgan.image_pipeline(predict=True)[0]
-            checkpoint.restore(latest_checkpoint(opt.weights))
-            cgan.predict(dataset, run.root)
+            if info.is_main:
+                dataset = cgan.image_pipeline(predict=True)[0]
+                checkpoint.restore(latest_checkpoint(opt.weights))
+                cgan.predict(dataset, run.root)
         else:
             train_X, train_Y, val_X, val_Y, test = cgan.image_pipeline(predict=False)
             manager = (CheckpointManager(checkpoint, os.path.join(run.root, 'training_checkpoints'), max_to_keep=3)
-                       if opt.save_weights == 'true' else None)
+                       if opt.save_weights == 'true' and info.is_main else None)
             train_metrics, val_metrics = cgan.fit(train_X, train_Y, val_X, val_Y, test, run.root, checkpoint_manager=manager)
-            final = run.dir('final_test_imgs', fresh=True)
-            for k, (img,) in enumerate(test.unbatch()):
-                cgan.generate_images(cgan.generator_g, img[None], os.path.join(final, f"img{k}.png"))
-            run.write_json('train_metrics.json', train_metrics)
-            run.write_json('val_metrics.json', val_metrics)
-            plot_loss_curves(train_metrics, val_metrics, 'CycleGAN', os.path.join(run.root, 'figs'))
+            ddp.assert_replicas_in_sync([m.net.params for m in cgan._models()], info)
+            if info.is_main:
+                final = run.dir('final_test_imgs', fresh=True)
+                for k, (img,) in enumerate(test.unbatch()):
+                    cgan.generate_images(cgan.generator_g, img[None], os.path.join(final, f"img{k}.png"))
+                run.write_json('train_metrics.json', train_metrics)
+                run.write_json('val_metrics.json', val_metrics)
+                plot_loss_curves(train_metrics, val_metrics, 'CycleGAN', os.path.join(run.root, 'figs'))
+                if info.world > 1:
+                    print(f"data-parallel run: {info.world} ranks, replicas in sync.")
         print("Done.")
     finally:
         run.close()
+        ddp.shutdown(info)
 
 
 if __name__ == '__main__':

@@ -109,3 +109,74 @@ def shard_batch(global_batch, rank, world):
         raise ValueError(f"global batch {global_batch} not divisible by world size {world}")
     per = global_batch // world
     return rank * per, per
+
+
+# ---- data-parallel runs of the CLIs (torchrun / torch.distributed.run: one process per GPU) ------------------------------
+class DistInfo:
+    """rank / world of this process and the device it owns; world == 1: a plain single-process run."""
+
+    def __init__(self, rank=0, world=1, device=None):
+        self.rank, self.world, self.device = rank, world, device
+
+    @property
+    def is_main(self):
+        return self.rank == 0
+
+
+def init_from_env(device: str = 'cuda:0', backend: str | None = None) -> DistInfo:
+    """Join the process group a launcher described in the environment (RANK, WORLD_SIZE, LOCAL_RANK, MASTER_ADDR/PORT) BEFORE
+    the first GPU call of this process; each rank owns cuda:LOCAL_RANK.  Without a launcher: DistInfo(0, 1, device).
+    backend: "nccl" (= RCCL on ROCm) unless given; CPU tests and one-GPU rehearsals pass "gloo"."""
+    import os
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world <= 1:
+        return DistInfo(0, 1, device)
+    rank, local = int(os.environ['RANK']), int(os.environ.get('LOCAL_RANK', '0'))
+    backend = backend or 'nccl'
+    ndev = torch.cuda.device_count()              # (does not create a GPU context)
+    dev = f'cuda:{local % max(ndev, 1)}'
+    kw = {}
+    if backend == 'nccl':
+        kw['device_id'] = torch.device(dev)
+    dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    if torch.cuda.is_available():
+        torch.cuda.set_device(torch.device(dev))
+    return DistInfo(rank, world, dev)
+
+
+def shard_files(files, rank, world):
+    """This rank's share of a file list (after the seeded split, which every rank computes identically): every world-th
+    file, all shards cut to the same length so that every rank runs the same number of steps (each step is a collective)."""
+    per = len(files) // world
+    return list(files[rank:per * world:world]) if world > 1 else list(files)
+
+
+def mean_over_ranks(acc, n, info: DistInfo):
+    """Epoch mean of the per-step loss vectors over all ranks' steps: (sum over ranks of acc) / (sum over ranks of n)."""
+    if info is None or info.world == 1 or acc is None:
+        return (acc / n) if n else None
+    t = torch.cat([acc.float().flatten(), torch.tensor([float(n)], device=acc.device)])
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t[:-1] / t[-1]
+
+
+def assert_replicas_in_sync(param_sets, info: DistInfo):
+    """Every rank must hold bit-identical weights after a data-parallel run (same start, same exchanged gradients): compares
+    a checksum of every network's master weights across the ranks; raises on the first difference."""
+    if info is None or info.world == 1:
+        return
+    sums = torch.stack([torch.stack([ps.master.double().sum(), ps.master.double().abs().sum()]) for ps in param_sets]).flatten()
+    lo, hi = sums.clone(), sums.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    if not torch.equal(lo, hi):
+        raise RuntimeError(f"data-parallel replicas diverged: weight checksums differ across ranks ({lo.tolist()} .. {hi.tolist()})")
+
+
+def shutdown(info: DistInfo):
+    """Leave the process group together (a rank that exits early makes its peers' pending collectives fail)."""
+    if info is not None and info.world > 1 and dist.is_initialized():
+        try:
+            dist.barrier()
+        finally:
+            dist.destroy_process_group()

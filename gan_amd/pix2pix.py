@@ -11,11 +11,28 @@ import numpy as np
 import torch
 
 from . import data as D
+from . import ddp
 from .base_gan import GAN
 from .checkpoint import Checkpoint, CheckpointManager, latest_checkpoint
 from .steps import Pix2PixStep
 from .runner import Run, plot_loss_curves, run_epochs, save_panels
 from .utils import pix2pix_losses
+
+
+def _step_state(ctx, st):
+    """Device state a warm-up pass of capture() advances besides weights and Adam moments: the fp16 loss-scale state and the
+    per-call dropout draw counters (every new batch size captures a new step: without this each capture would move them)."""
+    ts = [ctx.ls] if ctx.ls is not None else []
+    for call in vars(st).values():
+        md = getattr(call, 'mask_draws', None)
+        if isinstance(md, torch.Tensor):
+            ts.append(md)
+    return [(t, t.clone()) for t in ts]
+
+
+def _restore_step_state(saved):
+    for t, v in saved:
+        t.copy_(v)
 
 
 class Pix2Pix(GAN):
@@ -30,8 +47,19 @@ class Pix2Pix(GAN):
         self.generator_optimizer = mk().bind(self.generator.net.params)
         self.discriminator_optimizer = mk().bind(self.discriminator.net.params)
         self._steps = {}          # (batch, training) -> (Pix2PixStep, graph replay)
+        self.dist = ddp.DistInfo(0, 1, self.config.get('device'))      # main() replaces it in a data-parallel run
         self._rng = np.random.default_rng(seed)
         self.sync = None          # gan_amd.ddp.GradSync for data-parallel training
+
+    def enable_data_parallel(self, info, wire='bf16'):
+        """One process per GPU (torchrun): gradients are averaged over the ranks with RCCL all-reduces overlapped with the
+        backward pass (gan_amd/steps.py bucketed schedule); BatchNorm statistics stay per replica; the augmentation stream and
+        the dropout masks differ per rank.  The reference is single-device (base_gan.py:18-19 only prints the GPU count)."""
+        self.dist = info
+        if info.world > 1:
+            self._rng = np.random.default_rng(int(self.config.get('seed', 123)) + 7919 * info.rank)
+            self.sync = ddp.GradSync([self.generator.net.params.grad, self.discriminator.net.params.grad],
+                                     compress_bf16=(wire == 'bf16'), lib=self.ctx.lib)
 
     # ---- input pipeline (pix2pix.py:34-165) ------------------------------------------------------
     def split_img(self, image_file: str):
@@ -63,6 +91,7 @@ class Pix2Pix(GAN):
         if predict:
             return D.Batches(full(contents), self.process_images_pred, 1, None), None, None
         train, val, test = D.pix2pix_split(contents, self.config['seed'], self.config['test_img'], self.config['validation_size'])
+        train, val = (ddp.shard_files(f, self.dist.rank, self.dist.world) for f in (train, val))     # (every rank made the same split)
         bs = self.config["batch_size"]
         return (D.Batches(full(train), self.process_images_train, bs, dev),
                 D.Batches(full(val), self.process_images_pred, bs, dev),
@@ -83,8 +112,10 @@ class Pix2Pix(GAN):
                              seed=int(self.config.get('seed', 123)), mask_stream=0 if training else 16, nets=(self.generator.net, self.discriminator.net))
             st.sync = self.sync
             saved = self._snapshot()       # capture() runs warm-up passes (they also move BatchNorm's moving statistics): undo them
+            extra = _step_state(self.ctx, st)
             replay = st.capture(training=training)
             self._restore(saved)
+            _restore_step_state(extra)
             self._steps[key] = (st, replay)
         return self._steps[key]
 
@@ -121,12 +152,16 @@ class Pix2Pix(GAN):
         example_input, example_target = next(it)
         it.close()
         samples = os.path.join(output_path, 'test_images')
-        os.makedirs(samples, exist_ok=True)
+        if self.dist.is_main:
+            os.makedirs(samples, exist_ok=True)
         save = checkpoint_manager.save if checkpoint_manager is not None else (lambda: None)
         sample = lambda epoch: self.generate_images(self.generator, example_input[:1], example_target[:1],
                                                     os.path.join(samples, f"epoch_{epoch}.png"))
+        if not self.dist.is_main:           # rank 0 alone writes checkpoints and sample images
+            save = sample = (lambda *a: None)
         return run_epochs(self.config['epochs'], list(pix2pix_losses()), lambda: train_ds, lambda: val_ds, self.train_step,
-                          save, sample, ('Generator Total Loss', 'Discriminator Loss'))
+                          save, sample, ('Generator Total Loss', 'Discriminator Loss'),
+                          epoch_mean=lambda acc, n: ddp.mean_over_ranks(acc, n, self.dist))
 
     def predict(self, predict_ds, output_path: str):
         plot_path = os.path.join(output_path, 'prediction_images')
@@ -163,6 +198,9 @@ def parse_opt(argv=None):
     parser.add_argument('--weights', type=str, help='path to pretrained model weights for prediction', required='--predict' in argv)
     parser.add_argument('--dtype', type=str, default='bf16', choices=['bf16', 'f16', 'f32'], help='MI355X compute/storage dtype (f32 = exact parity path)')
     parser.add_argument('--device', type=str, default='cuda:0')
+    parser.add_argument('--dist-backend', type=str, default='nccl', choices=['nccl', 'gloo'],
+                        help='under torchrun (one process per GPU): collective backend; nccl = RCCL over xGMI')
+    parser.add_argument('--wire', type=str, default='bf16', choices=['bf16', 'f32'], help='gradient all-reduce wire format')
     args = parser.parse_args(argv)
     assert (args.img_size == 256) or (args.img_size == 512), "img-size currently only supported for 256 x 256 or 512 x 512 pixels!"
     assert (args.validation_size > 0.0 and args.validation_size <= 0.3), "validation size is a proportion and bounded between 0-0.3!"
@@ -171,30 +209,43 @@ def parse_opt(argv=None):
 
 
 def main(opt):
-    run = Run(opt.output, log_to_file=opt.logging == 'true', strict_logs=True)
+    """`python pix2pix.py --train ...` on one GPU, or `torchrun --nproc-per-node N pix2pix.py --train ...` for data-parallel
+    training: the process group is joined before the first GPU call, rank r owns cuda:r, the training / validation file lists
+    are sharded by rank after the seeded split, and rank 0 alone owns the run directory (logs, checkpoints, figures)."""
+    info = ddp.init_from_env(opt.device, opt.dist_backend)
+    opt.device = info.device or opt.device
+    run = Run(opt.output, log_to_file=opt.logging == 'true' and info.is_main, strict_logs=True, writer=info.is_main)
     try:
         p2p = Pix2Pix(vars(opt))
+        if opt.train:
+            p2p.enable_data_parallel(info, opt.wire)
         checkpoint = Checkpoint(generator_optimizer=p2p.generator_optimizer, discriminator_optimizer=p2p.discriminator_optimizer,
                                 generator=p2p.generator, discriminator=p2p.discriminator)
         run.write_json('config.json', p2p.config)
         if opt.predict:
-            dataset, _, _ = p2p.image_pipeline(predict=True)
-            checkpoint.restore(latest_checkpoint(opt.weights))
-            p2p.predict(dataset, run.root)
+            if info.is_main:
+                dataset, _, _ = p2p.image_pipeline(predict=True)
+                checkpoint.restore(latest_checkpoint(opt.weights))
+                p2p.predict(dataset, run.root)
         else:
             train, validation, test = p2p.image_pipeline(predict=False)
             manager = (CheckpointManager(checkpoint, os.path.join(run.root, 'training_checkpoints'), max_to_keep=1)
-                       if opt.save_weights == 'true' else None)
+                       if opt.save_weights == 'true' and info.is_main else None)
             train_metrics, val_metrics = p2p.fit(train, validation, test, run.root, checkpoint_manager=manager)
-            final = run.dir('final_test_imgs', fresh=True)
-            for k, (inp, tar) in enumerate(test.unbatch()):
-                p2p.generate_images(p2p.generator, inp[None], tar[None], os.path.join(final, f"img{k}.png"))
-            run.write_json('train_metrics.json', train_metrics)
-            run.write_json('val_metrics.json', val_metrics)
-            plot_loss_curves(train_metrics, val_metrics, 'Pix2Pix', os.path.join(run.root, 'figs'))
+            ddp.assert_replicas_in_sync([p2p.generator.net.params, p2p.discriminator.net.params], info)
+            if info.is_main:
+                final = run.dir('final_test_imgs', fresh=True)
+                for k, (inp, tar) in enumerate(test.unbatch()):
+                    p2p.generate_images(p2p.generator, inp[None], tar[None], os.path.join(final, f"img{k}.png"))
+                run.write_json('train_metrics.json', train_metrics)
+                run.write_json('val_metrics.json', val_metrics)
+                plot_loss_curves(train_metrics, val_metrics, 'Pix2Pix', os.path.join(run.root, 'figs'))
+                if info.world > 1:
+                    print(f"data-parallel run: {info.world} ranks, replicas in sync.")
         print("Done.")
     finally:
         run.close()
+        ddp.shutdown(info)
 
 
 if __name__ == '__main__':

@@ -23,22 +23,30 @@ class Run:
     """One timestamped run directory.  `strict_logs`: Pix2Pix refuses to reuse an existing logs/ directory
     (pix2pix.py:392), CycleGAN does not (cycle_gan.py:428)."""
 
-    def __init__(self, output_root: str, log_to_file: bool, strict_logs: bool):
+    def __init__(self, output_root: str, log_to_file: bool, strict_logs: bool, writer: bool = True):
+        """writer=False: a non-zero rank of a data-parallel run - it creates nothing on disk (rank 0 alone owns the run
+        directory, logs, checkpoints and figures) and keeps its console."""
+        self.writer = writer
         self.root = os.path.join(output_root, datetime.now().strftime("%Y-%m-%d-%Hh%M"))
         self.logs = os.path.join(self.root, 'logs')
+        self._saved = None
+        if not writer:
+            return
         os.makedirs(self.root, exist_ok=True)
         os.makedirs(self.logs, exist_ok=not strict_logs)
-        self._saved = None
         if log_to_file:
             self._saved = (sys.stdout, sys.stderr)
             sys.stdout = sys.stderr = open(os.path.join(self.logs, "Log.txt"), "w")
 
     def dir(self, name: str, fresh: bool = False) -> str:
         d = os.path.join(self.root, name)
-        os.makedirs(d, exist_ok=not fresh)
+        if self.writer:
+            os.makedirs(d, exist_ok=not fresh)
         return d
 
     def write_json(self, name: str, obj) -> None:
+        if not self.writer:
+            return
         with open(os.path.join(self.logs, name), 'w') as f:
             json.dump(obj, f)
 
@@ -84,9 +92,10 @@ def plot_loss_curves(train: dict, val: dict, model_name: str, out_dir: str) -> N
         plt.close(fig)
 
 
-def run_epochs(epochs: int, keys, train_batches, val_batches, step, on_checkpoint, on_sample, headline):
+def run_epochs(epochs: int, keys, train_batches, val_batches, step, on_checkpoint, on_sample, headline, epoch_mean=None):
     """Epoch driver.  train_batches()/val_batches() yield the positional arguments of `step(*args, training)`, which
     returns the per-step loss tensors (device); `headline` = (train key, val key) printed per epoch.
+    epoch_mean(acc, n) -> mean loss vector of a pass (data-parallel runs: over all ranks' steps, gan_amd.ddp.mean_over_ranks).
     Returns (train_cost_functions, val_cost_functions): {key: [epoch mean, ...]}."""
     hist = {k: [] for k in keys}, {k: [] for k in keys}
     t0 = time.time()
@@ -100,7 +109,8 @@ def run_epochs(epochs: int, keys, train_batches, val_batches, step, on_checkpoin
                 n += 1
                 if training and n % 100 == 0:
                     print('.', end='', flush=True)
-            sums.append((acc / n).cpu().tolist() if n else [float('nan')] * len(keys))      # one drain per pass
+            mean = epoch_mean(acc, n) if epoch_mean is not None else ((acc / n) if n else None)
+            sums.append(mean.cpu().tolist() if mean is not None else [float('nan')] * len(keys))      # one drain per pass
         for h, means in zip(hist, sums):
             for k, v in zip(keys, means):
                 h[k].append(v)

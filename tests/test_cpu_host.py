@@ -148,7 +148,25 @@ def _ddp_worker(rank, world, port, q):
         tol = 2e-2 if compress else 1e-6
         ok = all(torch.allclose(a, b, rtol=tol, atol=tol) for a, b in zip(got, expect))
         q.put((rank, compress, ok, shard_batch(64, rank, world)))
-    dist.destroy_process_group()
+    # helpers of the data-parallel CLI runs (gan_amd/pix2pix.py main under torchrun)
+    from gan_amd import ddp
+    info = ddp.DistInfo(rank, world, 'cpu')
+    files = [f"f{i}" for i in range(11)]
+    mine_f = ddp.shard_files(files, rank, world)
+    acc, n = torch.tensor([2.0, 4.0]) * (rank + 1), rank + 1          # rank 0: one step, rank 1: two steps
+    mean = ddp.mean_over_ranks(acc, n, info)
+
+    class PS:
+        master = torch.arange(10.0)
+    ddp.assert_replicas_in_sync([PS], info)
+    PS.master = torch.arange(10.0) + rank
+    diverged = False
+    try:
+        ddp.assert_replicas_in_sync([PS], info)
+    except RuntimeError:
+        diverged = True
+    q.put((rank, 'helpers', (mine_f, mean.tolist(), diverged), None))
+    ddp.shutdown(info)
 
 
 def test_gradsync_world2_gloo():
@@ -159,13 +177,20 @@ def test_gradsync_world2_gloo():
     procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=120) for _ in range(4)]
+    res = [q.get(timeout=120) for _ in range(6)]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
+    helpers = {r: v for r, kind, v, _ in res if kind == 'helpers'}
+    res = [t for t in res if t[1] != 'helpers']
     assert all(ok for _, _, ok, _ in res), res
     shards = {r: s for r, _, _, s in res}
     assert shards[0] == (0, 32) and shards[1] == (32, 32)
+    # file shards: disjoint, equal length (every rank runs the same number of steps), every world-th file
+    assert helpers[0][0] == ['f0', 'f2', 'f4', 'f6', 'f8'] and helpers[1][0] == ['f1', 'f3', 'f5', 'f7', 'f9']
+    # epoch mean over ALL ranks' steps: (2 + 4, 4 + 8) / (1 + 2)
+    assert helpers[0][1] == helpers[1][1] == [2.0, 4.0]
+    assert helpers[0][2] and helpers[1][2]                  # diverged replicas are detected on every rank
 
 
 def test_bench_gpus_without_enough_devices_fails_loudly():
