@@ -133,6 +133,8 @@ def main():
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--fp32-allreduce', action='store_true', help='exchange gradients as fp32 instead of bf16')
     ap.add_argument('--repeats', type=int, default=5, help='the K-step timed region is run this many times; the median is reported')
+    ap.add_argument('--exchange', default='allreduce', choices=['allreduce', 'rs_ag'],
+                    help='gradient exchange: all-reduce per bucket, or fp32 reduce-scatter + all-gather in the wire format')
     ap.add_argument('--opt', action='append', default=[], metavar='KEY=VALUE',
                     help='planner option of the kernel library (gan_set_option, include/gan_amd.h); for A/B runs')
     args = ap.parse_args()
@@ -154,6 +156,10 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     local = local % max(1, torch.cuda.device_count())        # (rehearsals with several ranks on one GPU)
+    if args.gpus != world:                                   # before any process group exists: nothing to tear down
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but {world} rank(s) joined", file=sys.stderr)
+        sys.exit(4)
     # (TORCH_NCCL_HIGH_PRIORITY=1 - high-priority communicator streams - was measured on the one-rank rehearsal: 3.65 -> 4.56
     # ms/step; the presence of a high-priority queue slows every normal-priority one down.  Left at the default.)
     if world > 1:
@@ -169,14 +175,13 @@ def main():
     rehearse = world == 1 and os.environ.get('GAN_AMD_DDP_REHEARSE') == '1'
     if rehearse:
         import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29611')
+        if 'MASTER_PORT' not in os.environ:                  # a free port: two rehearsals on one host must not share a TCP store
+            with socket.socket() as sk:
+                sk.bind(('127.0.0.1', 0))
+                os.environ['MASTER_PORT'] = str(sk.getsockname()[1])
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         torch.cuda.set_device(local)
         dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device(f'cuda:{local}'))
-    if args.gpus != world:
-        if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but {world} rank(s) joined", file=sys.stderr)
-        sys.exit(4)
-
     from gan_amd.ddp import GradSync
     from gan_amd.nets import Ctx, workspace_mb_for
     from gan_amd.steps import CycleGANStep, Pix2PixStep
@@ -194,7 +199,7 @@ def main():
         step = CycleGANStep(ctx, B, S, 1, lam=10.0, seed=123)
     if world > 1 or rehearse:
         step.sync = GradSync([n.params.grad for n in step.nets()], compress_bf16=(args.dtype != "f32" and not args.fp32_allreduce), lib=ctx.lib,
-                             rehearse=rehearse)
+                             rehearse=rehearse, exchange=args.exchange)
     # synthetic inputs on the normalize() lattice u/127.5-1 (base_gan.py:56-61), different per rank
     g = torch.Generator(device='cpu').manual_seed(123 + rank)
     mk = lambda: (torch.randint(0, 256, (B, S, S, 1), generator=g).float() / 127.5 - 1.0).to(dev)

@@ -39,12 +39,12 @@ class CycleGAN(GAN):
         self._rng = np.random.default_rng(seed)
         self.sync = None
 
-    def enable_data_parallel(self, info, wire='bf16'):
+    def enable_data_parallel(self, info, wire='bf16', exchange='allreduce'):
         """As Pix2Pix.enable_data_parallel: one process per GPU, gradients of the four networks averaged over the ranks."""
         self.dist = info
         if info.world > 1:
             self._rng = np.random.default_rng(int(self.config.get('seed', 123)) + 7919 * info.rank)
-            self.sync = ddp.GradSync([m.net.params.grad for m in self._models()], compress_bf16=(wire == 'bf16'), lib=self.ctx.lib)
+            self.sync = ddp.GradSync([m.net.params.grad for m in self._models()], compress_bf16=(wire == 'bf16'), lib=self.ctx.lib, exchange=exchange)
 
     def _models(self):
         return (self.generator_g, self.generator_f, self.discriminator_x, self.discriminator_y)
@@ -198,6 +198,8 @@ def parse_opt(argv=None):
     parser.add_argument('--dist-backend', type=str, default='nccl', choices=['nccl', 'gloo'],
                         help='under torchrun (one process per GPU): collective backend; nccl = RCCL over xGMI')
     parser.add_argument('--wire', type=str, default='bf16', choices=['bf16', 'f32'], help='gradient all-reduce wire format')
+    parser.add_argument('--exchange', type=str, default='allreduce', choices=['allreduce', 'rs_ag'],
+                        help='gradient exchange: one all-reduce per bucket, or fp32 reduce-scatter + all-gather in the wire format')
     args = parser.parse_args(argv)
     assert (args.img_size == 256) or (args.img_size == 512), "img-size currently only supported for 256 x 256 or 512 x 512 pixels!"
     assert (args.validation_size > 0.0 and args.validation_size <= 0.3), "validation size is a proportion and bounded between 0-0.3!"
@@ -213,7 +215,7 @@ def main(opt):
     try:
         cgan = CycleGAN(vars(opt))
         if opt.train:
-            cgan.enable_data_parallel(info, opt.wire)
+            cgan.enable_data_parallel(info, opt.wire, opt.exchange)
         names = ('generator_g', 'generator_f', 'discriminator_x', 'discriminator_y')
         objects = {n: getattr(cgan, n) for n in names}
         objects.update({n + '_optimizer': getattr(cgan, n + '_optimizer') for n in names})

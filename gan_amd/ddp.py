@@ -21,17 +21,27 @@ import torch.distributed as dist
 
 
 class GradSync:
-    def __init__(self, grad_buffers, group=None, compress_bf16=False, lib=None, rehearse=False):
+    def __init__(self, grad_buffers, group=None, compress_bf16=False, lib=None, rehearse=False, exchange='allreduce'):
         """grad_buffers: list of flat fp32 tensors (ParamSet.grad of each network).  lib: the loaded C-ABI library
         (needed for the bf16 wire format on the GPU; CPU/gloo tests pass None and get a torch cast).  rehearse: issue the
-        collectives even in a group of ONE rank (a one-GPU box can then run the whole data-parallel schedule over RCCL)."""
+        collectives even in a group of ONE rank (a one-GPU box can then run the whole data-parallel schedule over RCCL).
+        exchange: 'allreduce' - one all-reduce per bucket in the wire format (bf16 wire: the SUM over ranks is taken in bf16);
+        'rs_ag' - reduce-scatter of the fp32 gradients (fp32 accumulation over the ranks, each rank reduces 1/world of the
+        bucket: the direct exchange on a fully connected xGMI mesh) followed by an all-gather of the reduced
+        shards in the wire format (bf16 wire: 6 bytes per element on the links instead of 4, one rounding instead of
+        world - 1)."""
         self.bufs = list(grad_buffers)
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.active = self.world > 1 or (bool(rehearse) and dist.is_initialized())
         self.compress = bool(compress_bf16)
         self.lib = lib
         self.wire = [torch.zeros_like(b, dtype=torch.bfloat16) for b in self.bufs] if self.compress else None
+        if exchange not in ('allreduce', 'rs_ag'):
+            raise ValueError(f"exchange {exchange!r}: 'allreduce' or 'rs_ag'")
+        self.exchange = exchange
+        self._has_rs = dist.is_initialized() and dist.get_backend(group) != 'gloo'     # gloo has no reduce-scatter (CPU tests)
         self._pending = []
 
     @property
@@ -45,8 +55,9 @@ class GradSync:
         return torch.cuda.current_stream(self.bufs[0].device).cuda_stream if self.bufs[0].is_cuda else None
 
     def pack(self, i, lo=0, hi=None):
-        """grad[i][lo:hi] (fp32) -> wire[i][lo:hi] (bf16).  No-op for fp32 exchanges."""
-        if not self.compress:
+        """grad[i][lo:hi] (fp32) -> wire[i][lo:hi] (bf16).  No-op for fp32 exchanges and for 'rs_ag' (which reduces the fp32
+        gradients and casts its own reduced shard inside start())."""
+        if not self.compress or (self.exchange == 'rs_ag' and self.active):
             return
         hi = self.bufs[i].numel() if hi is None else hi
         if self.lib is not None and self.bufs[i].is_cuda:
@@ -76,7 +87,36 @@ class GradSync:
             return None
         t = self.wire[i] if self.compress else self.bufs[i]
         hi = t.numel() if hi is None else hi
+        if self.exchange == 'rs_ag':
+            return self._start_rs_ag(i, lo, hi)
         return dist.all_reduce(t[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def _start_rs_ag(self, i, lo, hi):
+        """fp32 reduce-scatter (in place: rank r's shard of the bucket ends up holding the SUM over ranks), cast of that shard to
+        the wire format, all-gather (in place in the wire / fp32 buffer).  Runs on the CURRENT stream's order: the caller issues
+        it on the communicator launcher stream, which then waits for the reduce-scatter before the cast kernel."""
+        n, w = hi - lo, self.world
+        if n % (8 * w):
+            raise ValueError(f"bucket of {n} elements: 'rs_ag' needs a multiple of {8 * w}")
+        per = n // w
+        src = self.bufs[i][lo:hi]
+        mine = src[self.rank * per:(self.rank + 1) * per]
+        if self._has_rs:
+            h = dist.reduce_scatter_tensor(mine, src, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        else:           # gloo (CPU tests / one-GPU rehearsals of the schedule): the same sums through an all-reduce
+            h = dist.all_reduce(src, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        h.wait()
+        if self.compress:
+            a = lo + self.rank * per
+            self.exchange, keep = 'allreduce', self.exchange          # (pack() is a no-op under 'rs_ag')
+            try:
+                self.pack(i, a, a + per)
+            finally:
+                self.exchange = keep
+            out = self.wire[i][lo:hi]
+        else:
+            out = src
+        return dist.all_gather_into_tensor(out, out[self.rank * per:(self.rank + 1) * per], group=self.group, async_op=True)
 
     def wait(self, handle):
         """The current stream waits for the collective (asynchronous for the host with RCCL)."""

@@ -51,7 +51,7 @@ class Pix2Pix(GAN):
         self._rng = np.random.default_rng(seed)
         self.sync = None          # gan_amd.ddp.GradSync for data-parallel training
 
-    def enable_data_parallel(self, info, wire='bf16'):
+    def enable_data_parallel(self, info, wire='bf16', exchange='allreduce'):
         """One process per GPU (torchrun): gradients are averaged over the ranks with RCCL all-reduces overlapped with the
         backward pass (gan_amd/steps.py bucketed schedule); BatchNorm statistics stay per replica; the augmentation stream and
         the dropout masks differ per rank.  The reference is single-device (base_gan.py:18-19 only prints the GPU count)."""
@@ -59,7 +59,7 @@ class Pix2Pix(GAN):
         if info.world > 1:
             self._rng = np.random.default_rng(int(self.config.get('seed', 123)) + 7919 * info.rank)
             self.sync = ddp.GradSync([self.generator.net.params.grad, self.discriminator.net.params.grad],
-                                     compress_bf16=(wire == 'bf16'), lib=self.ctx.lib)
+                                     compress_bf16=(wire == 'bf16'), lib=self.ctx.lib, exchange=exchange)
 
     # ---- input pipeline (pix2pix.py:34-165) ------------------------------------------------------
     def split_img(self, image_file: str):
@@ -201,6 +201,8 @@ def parse_opt(argv=None):
     parser.add_argument('--dist-backend', type=str, default='nccl', choices=['nccl', 'gloo'],
                         help='under torchrun (one process per GPU): collective backend; nccl = RCCL over xGMI')
     parser.add_argument('--wire', type=str, default='bf16', choices=['bf16', 'f32'], help='gradient all-reduce wire format')
+    parser.add_argument('--exchange', type=str, default='allreduce', choices=['allreduce', 'rs_ag'],
+                        help='gradient exchange: one all-reduce per bucket, or fp32 reduce-scatter + all-gather in the wire format')
     args = parser.parse_args(argv)
     assert (args.img_size == 256) or (args.img_size == 512), "img-size currently only supported for 256 x 256 or 512 x 512 pixels!"
     assert (args.validation_size > 0.0 and args.validation_size <= 0.3), "validation size is a proportion and bounded between 0-0.3!"
@@ -218,7 +220,7 @@ def main(opt):
     try:
         p2p = Pix2Pix(vars(opt))
         if opt.train:
-            p2p.enable_data_parallel(info, opt.wire)
+            p2p.enable_data_parallel(info, opt.wire, opt.exchange)
         checkpoint = Checkpoint(generator_optimizer=p2p.generator_optimizer, discriminator_optimizer=p2p.discriminator_optimizer,
                                 generator=p2p.generator, discriminator=p2p.discriminator)
         run.write_json('config.json', p2p.config)

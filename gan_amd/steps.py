@@ -109,43 +109,95 @@ class _StepBase:
         if (split and hasattr(self, '_capture_bucketed') and self.ctx.ms_mode == 4 and self.ctx.ls is None      # (fp16: the whole-step
                 and os.environ.get('GAN_AMD_DDP_BUCKETS', '1') == '1'):                                   # inf/nan check precedes every Adam)
             return self._capture_bucketed()
+        if split:
+            return self._capture_phased(training)
         g1 = torch.cuda.CUDAGraph()
-        g2 = g3 = None
-        if not split:
-            with torch.cuda.graph(g1, capture_error_mode=CAPTURE_MODE):
-                self._run(*self._static_in, training=training)
-                self.ctx.assert_lanes_joined()
-        else:
-            # graph 1: forward, losses, generator-side backward  -> start the generators' (large) exchange
-            # graph 2: discriminator parameter pass (overlaps it) -> start the discriminators' exchange
-            # graph 3: Adam, after both exchanges have landed
-            with torch.cuda.graph(g1, capture_error_mode=CAPTURE_MODE):
-                self._forward_backward(*self._static_in, training, phase=1)
-                self.ctx.assert_lanes_joined()
-            g2 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g2, capture_error_mode=CAPTURE_MODE):
-                self._forward_backward(*self._static_in, training, phase=2)
-                self.ctx.assert_lanes_joined()
-            g3 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g3, capture_error_mode=CAPTURE_MODE):
-                self._update()
-                self.ctx.assert_lanes_joined()
-        self._graphs = (g1, g2, g3)
-        early, late = self.sync_order() if split else ((), ())
+        with torch.cuda.graph(g1, capture_error_mode=CAPTURE_MODE):
+            self._run(*self._static_in, training=training)
+            self.ctx.assert_lanes_joined()
+        self._graphs = (g1, None, None)
 
         def replay(*inputs):
             for dst, src in zip(self._static_in, inputs):
                 if src is not dst:
                     dst.copy_(src, non_blocking=True)
             g1.replay()
-            if g2 is not None:
-                for i in early:
-                    self.sync.start_all(i)
-                g2.replay()
-                for i in late:
-                    self.sync.start_all(i)
-                self.sync.finish(unpack=not self._wire_adam())
-                g3.replay()
+            return self.losses
+        return replay
+
+    def _capture_phased(self, training):
+        """Data-parallel schedule by PHASES (every step type has it; Pix2Pix bf16 prefers its finer bucketed schedule): the step is
+        cut where a network's gradients become complete - ddp_phases() lists (phase id, networks complete after it) in the order
+        the backward pass finishes them (cycle_gan.py:252-260 has four independent gradient sets) - one compute graph per phase;
+        a finished network's exchange starts at once on the communicator's stream and runs beside the following phases; its Adam
+        graph is replayed on a side stream as soon as the exchange has landed.  fp16: the inf/nan check must see every EXCHANGED
+        gradient before any weight moves (all ranks take the same skip decision), so the exchanges still overlap the compute
+        phases but one graph at the end checks, updates every network and adapts the loss scale."""
+        ctx, sync = self.ctx, self.sync
+        phases = self.ddp_phases()
+        nets = self.nets()
+        fp16 = ctx.ls is not None
+        wire = self._wire_adam()
+        main = torch.cuda.current_stream(ctx.device)
+        lane4 = ctx.lane_stream(4)
+
+        def graph(fn):
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr, capture_error_mode=CAPTURE_MODE):
+                fn()
+                ctx.assert_lanes_joined()
+            return gr
+
+        G = [graph(lambda pid=pid: self._forward_backward(*self._static_in, training, phase=pid)) for pid, _ in phases]
+        if fp16:
+            A = [graph(self._update)]
+        else:
+            gs = 1.0 / sync.world if wire else sync.grad_scale
+            wp = (lambda i: sync.wire[i].data_ptr()) if wire else (lambda i: None)
+            A = [graph(lambda i=i, n=n: n.params.adam(self.lr, self.b1, self.b2, grad_scale=gs, wire_ptr=wp(i))) for i, n in enumerate(nets)]
+        self._graphs = tuple(G + A)
+        evs = [torch.cuda.Event() for _ in G]
+        comm = torch.cuda.Stream(device=ctx.device)
+
+        def boundary(k, pending):
+            done = phases[k][1]
+            if not done:
+                return
+            comm.wait_event(evs[k])
+            with torch.cuda.stream(comm):
+                for i in done:
+                    sync.pack(i)                               # fp32 gradients -> wire format (no-op for the fp32 wire)
+                started = [(i, sync.start(i)) for i in done]
+            if fp16:
+                pending += started
+                return
+            lane4.wait_event(evs[k])
+            with torch.cuda.stream(lane4):
+                for i, h in started:
+                    sync.wait(h)                               # lane 4 waits for the collective; the host does not
+                    if not wire:
+                        sync.unpack(i)
+                    A[i].replay()
+
+        def replay(*inputs):
+            for dst, src in zip(self._static_in, inputs):
+                if src is not dst:
+                    dst.copy_(src, non_blocking=True)
+            cur = torch.cuda.current_stream(ctx.device)
+            pending = []
+            for k, gr in enumerate(G):
+                gr.replay()
+                evs[k].record(cur)
+                if k > 0:
+                    boundary(k - 1, pending)                   # issued behind the NEXT compute graph: the GPU never waits for the host
+            boundary(len(G) - 1, pending)
+            if fp16:
+                for i, h in pending:
+                    sync.wait(h)
+                    sync.unpack(i)
+                A[0].replay()
+            else:
+                ctx.join(cur, lane4)
             return self.losses
         return replay
 
@@ -176,8 +228,8 @@ class Pix2PixStep(_StepBase):
         sh = (self.B, self.S, self.S, self.C)
         return [torch.zeros(sh, dtype=torch.float32, device=self.ctx.device) for _ in range(2)]
 
-    def sync_order(self):
-        return (0,), (1,)          # indices into nets(): G's gradients are complete after phase 1, D's after phase 2
+    def ddp_phases(self):
+        return [(1, [0]), (2, [1])]          # (phase id, indices into nets() complete after it): G after phase 1, D after phase 2
 
     def _forward_backward(self, inp, tar, training=True, phase=0):
         B, Cc, g, d = self.B, self.C, self.g, self.d
@@ -504,13 +556,22 @@ class CycleGANStep(_StepBase):
         sh = (self.B, self.S, self.S, self.C)
         return [torch.zeros(sh, dtype=torch.float32, device=self.ctx.device) for _ in range(2)]
 
-    def sync_order(self):
-        return (0, 1), (2, 3)
+    def ddp_phases(self):
+        """Gradient sets in the order the backward pass completes them (cycle_gan.py:252-260): G_g | G_f | D_x | D_y."""
+        if self.merged:
+            return [(11, [0]), (12, [1]), (13, [2]), (14, [3])]
+        return [(1, [0, 1]), (2, [2, 3])]
 
     def _forward_backward(self, real_x, real_y, training=True, phase=0):
         B, Cc, lam = self.B, self.C, self.lam
         if phase == 2:
             self.dx.backward_params(); self.dy.backward_params()
+            return self.losses
+        if phase == 12:
+            self.gB.backward(use_dgen2=True, accumulate=True)          # G_f complete
+            return self.losses
+        if phase in (13, 14):
+            (self.dx if phase == 13 else self.dy).backward_params()
             return self.losses
         if self.merged:
             return self._forward_backward_merged(real_x, real_y, training, phase)
@@ -606,6 +667,8 @@ class CycleGANStep(_StepBase):
             # second upstream slot of the identity halves stays zero (never written); one backward per generator covers the
             # adversarial + cycle gradient of fake_* and the identity gradient of same_*
             gA.backward(use_dgen2=True, accumulate=True)              # G_g
+            if phase == 11:                                           # phased data-parallel schedule: G_g's exchange starts here
+                return self.losses
             gB.backward(use_dgen2=True, accumulate=True)              # G_f
             if phase != 1:
                 dx.backward_params(); dy.backward_params()

@@ -148,6 +148,17 @@ def _ddp_worker(rank, world, port, q):
         tol = 2e-2 if compress else 1e-6
         ok = all(torch.allclose(a, b, rtol=tol, atol=tol) for a, b in zip(got, expect))
         q.put((rank, compress, ok, shard_batch(64, rank, world)))
+    # 'rs_ag' exchange (fp32 reduce-scatter + all-gather in the wire format): the same means
+    for compress in (False, True):
+        bufs = [torch.cat([t, torch.zeros((-t.numel()) % 16)]).clone() for t in mine]          # buckets are multiples of 8 * world
+        sync = GradSync(bufs, compress_bf16=compress, exchange='rs_ag')
+        hs = [(i, sync.start(i)) for i in range(2)]
+        for i, h in hs:
+            sync.wait(h)
+        got = [(sync.wire[i].float() / world if compress else bufs[i] / world)[:full[i].numel()] for i in range(2)]
+        expect = [sum(per_rank[r][i] for r in range(world)) / world for i in range(2)]
+        tol = 1e-2 if compress else 1e-6
+        q.put((rank, 'rs_ag', all(torch.allclose(a, b, rtol=tol, atol=tol) for a, b in zip(got, expect)), shard_batch(64, rank, world)))
     # helpers of the data-parallel CLI runs (gan_amd/pix2pix.py main under torchrun)
     from gan_amd import ddp
     info = ddp.DistInfo(rank, world, 'cpu')
@@ -177,7 +188,7 @@ def test_gradsync_world2_gloo():
     procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=120) for _ in range(6)]
+    res = [q.get(timeout=120) for _ in range(10)]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0

@@ -265,7 +265,7 @@ class _FakeSync:
 @pytest.mark.parametrize("buckets", ['1', '0'])
 def test_ddp_schedules_match_single_graph(buckets, monkeypatch):
     """The bucketed data-parallel schedule (4 compute graphs, a bucket leaving after each of the last three, Adam per
-    bucket on a side stream) and the older 3-graph schedule both end in the same weights as the one-GPU graph."""
+    bucket on a side stream) and the phased schedule (a graph per network-complete point) both end in the one-GPU weights."""
     monkeypatch.setenv('GAN_AMD_DDP_BUCKETS', buckets)
     ctx, st, Gp, Dp, inp, tar, masks = _setup_p2p('f32', B=2)
     ti, tt = torch.from_numpy(inp).to(ctx.device), torch.from_numpy(tar).to(ctx.device)
@@ -291,7 +291,7 @@ def test_ddp_schedules_match_single_graph(buckets, monkeypatch):
                           ('start', 0, P.vec_start, P.total)]
         assert [c for c in st2.sync.calls if c[0] == 'wait'] != []
     else:
-        assert starts == [('start_all', 0), ('start_all', 1)]            # G's exchange starts before D's pass
+        assert starts == [('start', 0, 0, None), ('start', 1, 0, None)]  # phased schedule: G's exchange starts before D's pass
 
 
 def _ddp_gpu_worker(rank, world, port, q, bf16_wire=False):
@@ -421,7 +421,7 @@ def test_ddp_schedule_over_rccl_with_one_rank(model):
     assert p.exitcode == 0
     for wire in ('f32', 'bf16'):
         (w_one, l_one, n_one, f_one), (w_ddp, l_ddp, n_ddp, f_ddp) = out[wire]
-        assert n_one == 3 and n_ddp == (8 if model == "pix2pix" else 3)       # bucketed: 4 compute + 4 Adam graphs
+        assert n_one == 3 and n_ddp == 8       # Pix2Pix bucketed: 4 compute + 4 Adam graphs; CycleGAN phased: 4 phases + 4 Adam graphs
         assert np.allclose(l_one, l_ddp, rtol=2e-2 if wire == "bf16" else 1e-5), (wire, l_one, l_ddp)      # (third step)
         for ga, gb in zip(f_one[0], f_ddp[0]):            # gradients of the first step, every network
             rel = np.linalg.norm(ga - gb) / np.linalg.norm(ga)
