@@ -52,7 +52,7 @@ def gemm_profile(step, inputs, reps=5):
                 recs.setdefault(meta['kernel'], []).append((e0, e1, meta['flops']))
             if rc:
                 raise RuntimeError(f"{op[2]} failed rc={rc}")
-    ms_saved, ctx.ms_mode, ctx.multistream = ctx.ms_mode, 0, False   # instrumented passes: every launch on one stream
+    lanes_saved, ctx.lanes = ctx.lanes, False      # instrumented passes: every launch on one stream
     sync_saved, step.sync = step.sync, None    # rank-local measurement: no collectives (the other ranks are not here)
     try:
         step._run(*inputs, training=True)      # untimed eager pass (first eager launches pay one-time costs)
@@ -63,7 +63,7 @@ def gemm_profile(step, inputs, reps=5):
         torch.cuda.synchronize()
     finally:
         ctx.run = orig_run
-        ctx.ms_mode, ctx.multistream = ms_saved, ms_saved == 2
+        ctx.lanes = lanes_saved
         step.sync = sync_saved
     out = {}
     for k, lst in recs.items():
@@ -133,6 +133,7 @@ def main():
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--fp32-allreduce', action='store_true', help='exchange gradients as fp32 instead of bf16')
     ap.add_argument('--repeats', type=int, default=5, help='the K-step timed region is run this many times; the median is reported')
+    ap.add_argument('--single-stream', action='store_true', help='no side lanes: every launch of the captured step on one stream (profiling)')
     ap.add_argument('--exchange', default='allreduce', choices=['allreduce', 'rs_ag'],
                     help='gradient exchange: all-reduce per bucket, or fp32 reduce-scatter + all-gather in the wire format')
     ap.add_argument('--opt', action='append', default=[], metavar='KEY=VALUE',
@@ -192,7 +193,7 @@ def main():
     dev = f'cuda:{local}'
     torch.cuda.set_device(local)
     B, S = args.batch, args.img_size
-    ctx = Ctx(dev, args.dtype, workspace_mb=workspace_mb_for(B, S))
+    ctx = Ctx(dev, args.dtype, workspace_mb=workspace_mb_for(B, S), lanes=not args.single_stream)
     if args.model == 'pix2pix':
         step = Pix2PixStep(ctx, B, S, 1, lam=100.0, seed=123)
     else:

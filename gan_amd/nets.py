@@ -12,7 +12,6 @@ activation are written by their producers straight into channel slices of one NH
 from __future__ import annotations
 
 import ctypes as C
-import os
 
 import numpy as np
 import torch
@@ -25,7 +24,7 @@ LEAKY_ALPHA = 0.3                                    # Keras LeakyReLU() default
 BN_EPS, IN_EPS, BN_MOMENTUM = 1e-3, 1e-5, 0.99       # Keras BatchNormalization defaults; utils.py:9
 
 
-FUSE_BWD = os.environ.get('GAN_AMD_FUSE_BWD', '1') == '1'    # dgrad epilogues start the backward of the layer below
+FUSE_BWD = True              # dgrad epilogues start the backward of the layer below (GanBwdFuse)
 STATS_RESERVE = 8 << 20      # room kept behind a conv's split-K slabs for its fused statistics partials
 
 
@@ -56,7 +55,9 @@ class LaneStream(torch.cuda.Stream):
 class Ctx:
     """Device, dtype, library handle and the shared split-K / reduction workspace."""
 
-    def __init__(self, device='cuda:0', dtype='bf16', workspace_mb=256):
+    def __init__(self, device='cuda:0', dtype='bf16', workspace_mb=256, lanes=True, loss_scale=2.0 ** 15):
+        """lanes: a captured step forks independent chains onto side streams (the schedule of gan_amd/steps.py); False puts
+        every launch on the current stream (profiling, per-kernel timing).  loss_scale: initial dynamic loss scale (fp16)."""
         self.lib = L.load()
         if not torch.cuda.is_available():
             raise L.GanAmdError("gan_amd needs an MI355X (no CPU fallback)")
@@ -70,7 +71,7 @@ class Ctx:
         # (include/gan_amd.h, gan_grads_check / gan_loss_scale_update); None = no scaling
         self.ls = None
         if dtype == 'f16':
-            s0 = float(os.environ.get('GAN_AMD_LOSS_SCALE', 2.0 ** 15))
+            s0 = float(loss_scale)
             self.ls = torch.tensor([s0, 1.0 / s0, 0.0, 0.0], dtype=torch.float32, device=self.device)
         self.ls_ptr = self.ls.data_ptr() if self.ls is not None else None
         self.ls_growth_interval, self.ls_max = 2000, 2.0 ** 24        # Keras LossScaleOptimizer defaults
@@ -83,10 +84,7 @@ class Ctx:
         self.ws = self.ws_lanes[0]
         self.ws_ptr, self.ws_bytes = self.ws.data_ptr(), self.ws.numel()
         self.side = [LaneStream(device=self.device) for _ in range(4)]     # lanes 1..4 (4: early optimiser step)
-        # 0: everything on one stream; 1: one fork/join per step (deferred generator wgrads beside the
-        # discriminator's parameter pass); 2: per-op wgrad side stream + second chain
-        self.ms_mode = int(os.environ.get('GAN_AMD_MS', '4'))
-        self.multistream = self.ms_mode == 2
+        self.lanes = bool(lanes)
 
     def stream(self):
         return torch.cuda.current_stream(self.device).cuda_stream
@@ -116,21 +114,12 @@ class Ctx:
                 L.check(rc, op[2])
 
     def run(self, ops, lane=0):
-        main = self.lane_stream(lane)
-        side = self.side[lane] if self.multistream else main
-        st_main, st_side = main.cuda_stream, side.cuda_stream
-        used_side = False
+        """All ops in program order on lane `lane` (0 = the current stream)."""
+        st = self.lane_stream(lane).cuda_stream
         for op in ops:
-            if len(op) > 4 and op[4] and self.multistream:
-                side.wait_stream(main)            # the op's inputs were produced on the main chain just before it
-                rc = op[0](*op[1], st_side)
-                used_side = True
-            else:
-                rc = op[0](*op[1], st_main)
+            rc = op[0](*op[1], st)
             if rc:
                 L.check(rc, op[2])
-        if used_side:
-            self.join(main, side)
 
 
 class Buf:
@@ -348,6 +337,7 @@ class _Builder:
         self.ws_ptr, self.ws_bytes = ctx.ws_lanes[lane].data_ptr(), ctx.ws_lanes[lane].numel()
         self.ws_side_ptr = ctx.ws_lanes[lane + 1].data_ptr()
         self.lib = ctx.lib
+        self.wgrad_concurrent = False     # planner hint of the wgrad descriptors built here: the launch shares the chip with other lanes
         self.keep = []       # ctypes structs must outlive the op list
 
     def _desc(self, d):
@@ -439,7 +429,7 @@ class _Builder:
 
     def wgrad(self, big, small, dw_ptr, big_c, small_c, stride, accumulate):
         d = L.GanWgradDesc(self.ctx.dt, stride, big, small, dw_ptr, big_c, small_c, int(accumulate),
-                           self.ws_side_ptr, self.ws_bytes, int(getattr(self.ctx, 'wgrad_concurrent', False)))
+                           self.ws_side_ptr, self.ws_bytes, int(self.wgrad_concurrent))
         need = self.lib.gan_wgrad_workspace_bytes(C.byref(d))
         if need > self.ws_bytes:
             raise L.GanAmdError(f"workspace too small for wgrad: need {need}")
@@ -515,17 +505,20 @@ class GeneratorNet:
         self.params = ParamSet(ctx, self.spec)
         self.params.load_numpy(init_params_numpy(self.spec, seed))
 
-    def new_call(self, batch, size, dropout=True, seed=1234, stream_id=0):
-        return GenCall(self, batch, size, dropout, seed, stream_id)
+    def new_call(self, batch, size, dropout=True, seed=1234, stream_id=0, wgrads_on_side_lane=False):
+        """wgrads_on_side_lane: this call's kernel-gradient GEMMs run on a side lane of a captured step beside the dgrad chain
+        (GanWgradDesc.concurrent: the planner prefers half-chip grids with longer reductions)."""
+        return GenCall(self, batch, size, dropout, seed, stream_id, wgrads_on_side_lane)
 
 
 class GenCall:
     """Buffers + op lists for one invocation `generator(x, training=True)` and its backward."""
 
-    def __init__(self, net, B, S, dropout, seed, stream_id):
+    def __init__(self, net, B, S, dropout, seed, stream_id, wgrads_on_side_lane=False):
         ctx, P = net.ctx, net.params
         self.net, self.ctx, self.B, self.S, self.C = net, ctx, B, S, net.channels
         bd = _Builder(ctx, P, net.norm)
+        bd.wgrad_concurrent = bool(wgrads_on_side_lane)
         self._bd = bd
         C_ = net.channels
         groups = 1 if net.norm == 'batchnorm' else B
@@ -765,9 +758,6 @@ class GenCall:
                 self.ctx.run_on([o for o in ops[lo:hi] if is_w(o)], self.wgrad_stream)
                 if getattr(self, 'stage_hook', None) is not None:
                     self.stage_hook(k)         # e.g. the optimiser step of the layers whose gradients are now complete
-        elif defer_wgrads:
-            self.ctx.run([o for o in ops if not (len(o) > 4 and o[4])])
-            self._deferred = [o for o in ops if len(o) > 4 and o[4]]
         else:
             self.ctx.run(ops)
 
@@ -783,11 +773,6 @@ class GenCall:
         idx = [i for i, o in enumerate(ops) if is_w(o)]
         bounds = [0] + [idx[c] for c in cuts if 0 < c < len(idx)] + [len(ops)]
         return [([o for o in ops[lo:hi] if not is_w(o)], [o for o in ops[lo:hi] if is_w(o)]) for lo, hi in zip(bounds[:-1], bounds[1:])]
-
-    def run_deferred_wgrads(self, stream):
-        """Kernel-gradient GEMMs postponed by backward(defer_wgrads=True): they only feed Adam."""
-        self.ctx.run_on(self._deferred, stream)
-        self._deferred = []
 
     def output_f32(self):
         o = torch.empty((self.B, self.S, self.S, self.C), dtype=torch.float32, device=self.ctx.device)
@@ -994,7 +979,7 @@ class DiscCall:
         key = ('A', accumulate)
         if key not in self._cache:
             self._cache[key] = self._chain(0, self.N, self.groups, 0, True, False, accumulate)
-        self.ctx.run(self._cache[key], lane=2 if self.ctx.multistream else 0)      # (ops carry lane-2/3 workspaces either way)
+        self.ctx.run(self._cache[key])      # (the ops carry lane-2/3 workspaces either way)
 
     def backward_input(self, call, dst=None, c0=0):
         """Pass B: gradient w.r.t. the input of invocation `call`; its dlogits must be in self.dlogits_b.

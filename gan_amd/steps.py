@@ -10,7 +10,6 @@ computes forward + losses only (pix2pix.py:208, :291-292).
 from __future__ import annotations
 
 import ctypes as C
-import os
 
 import torch
 
@@ -106,9 +105,8 @@ class _StepBase:
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         split = training and self.sync is not None and getattr(self.sync, 'active', self.sync.world > 1)
-        if (split and hasattr(self, '_capture_bucketed') and self.ctx.ms_mode == 4 and self.ctx.ls is None      # (fp16: the whole-step
-                and os.environ.get('GAN_AMD_DDP_BUCKETS', '1') == '1'):                                   # inf/nan check precedes every Adam)
-            return self._capture_bucketed()
+        if split and hasattr(self, '_capture_bucketed') and self.ctx.lanes and self.ctx.ls is None and self.ddp_buckets:
+            return self._capture_bucketed()          # (fp16: the whole-step inf/nan check precedes every Adam -> phased schedule)
         if split:
             return self._capture_phased(training)
         g1 = torch.cuda.CUDAGraph()
@@ -203,17 +201,25 @@ class _StepBase:
 
 
 class Pix2PixStep(_StepBase):
+    # schedule constants (measured); attributes so that an experiment can change them per object
+    dreal_on_side_lane = True    # D(real)'s forward on lane 2 beside the generator's launch-bound inner layers (+0.8 %)
+    early_adam = True            # Adam + NK refresh of a stage's kernels on lane 4 as soon as its wgrads are done (+1.5 %)
+    wgrad_cuts = (8, 12)         # G's wgrad GEMMs in three coarse stages: decoder | down7..4 | down3..0
+    ddp_buckets = True           # data parallel, bf16/f32: the bucketed schedule (False: the phased one)
+    ddp_graphs = 4               # bucketed schedule: compute graphs per step (4, 3 or 2)
+    ddp_late_comm = True         # a boundary's collectives are issued after the NEXT compute graph has been enqueued
+
     def __init__(self, ctx: Ctx, batch, size, channels=1, lam=100.0, lr=2e-4, beta_1=0.5, beta_2=0.999,
                  seed=123, dropout=True, nets=None, mask_stream=0):
         self.ctx, self.B, self.S, self.C = ctx, batch, size, channels
         self.lam, self.lr, self.b1, self.b2 = float(lam), lr, beta_1, beta_2
-        ctx.wgrad_concurrent = ctx.ms_mode == 4      # G's wgrad GEMMs run on a side lane beside the main chain: planner hint
         if nets is not None:          # share weights with an existing step / model objects
             self.G, self.D = nets
         else:
             self.G = GeneratorNet(ctx, channels, 'batchnorm', seed=seed)          # pix2pix.py:29
             self.D = DiscriminatorNet(ctx, channels, True, 'batchnorm', seed=seed + 1)   # pix2pix.py:30
-        self.g = self.G.new_call(batch, size, dropout=dropout, seed=seed, stream_id=mask_stream)   # mask_stream: train / val steps draw different masks
+        self.g = self.G.new_call(batch, size, dropout=dropout, seed=seed, stream_id=mask_stream,   # mask_stream: train / val steps draw different masks
+                                 wgrads_on_side_lane=ctx.lanes)
         self.d = self.D.new_call(batch, size, calls=2)
         self.losses = torch.zeros(8, dtype=torch.float32, device=ctx.device)
         self.l1_ws = torch.zeros(4096, dtype=torch.float32, device=ctx.device)
@@ -239,7 +245,7 @@ class Pix2PixStep(_StepBase):
         # inputs -> typed, channel-padded buffers.  D input = concat([inp, tar|gen]) (base_gan.py:139)
         self._pack_multi([(inp, g.xin.view(0, Cc)), (inp, d.xin.view(0, Cc, 0, B)), (inp, d.xin.view(0, Cc, B, B)),
                           (tar, d.xin.view(Cc, Cc, 0, B))])
-        dreal = self.ctx.ms_mode == 4 and os.environ.get('GAN_AMD_DREAL', '1') == '1'
+        dreal = self.ctx.lanes and self.dreal_on_side_lane
         if dreal:
             # D(real) does not depend on the generator: it starts on lane 2 when G reaches its inner layers (down3 on:
             # launch-bound layers that leave the chip idle; measured best start point, +0.8 %) and D(fake) follows G on the main chain.  Same
@@ -255,7 +261,7 @@ class Pix2PixStep(_StepBase):
         # generator loss (pix2pix.py:167-188): BCE(1, D(fake)) + lambda * mean|target - gen|; discriminator loss
         # (base_gan.py:233-245, factor 0.5 at pix2pix.py:206) - the L1 term (it only needs G's output: beside D's
         # forward when lanes are on), then all three BCE terms in one pass
-        side = self.ctx.lane_stream(2) if self.ctx.ms_mode == 4 else None
+        side = self.ctx.lane_stream(2) if self.ctx.lanes else None
         if dreal:
             self.ctx.join(self.ctx.lane_stream(0), side)                 # D(real) done (its BatchNorm updates come first)
         if side is not None:
@@ -280,37 +286,14 @@ class Pix2PixStep(_StepBase):
                 return self.losses
             # two independent chains: D's parameter gradients (pix2pix.py:211) beside G's backward (:210)
             main, lane2 = self.ctx.lane_stream(0), self.ctx.lane_stream(2)
-            if phase == 1 and self.ctx.ms_mode == 4:   # data-parallel: D's parameter pass is phase 2 (beside G's all-reduce)
+            if phase == 1 and self.ctx.lanes:   # data-parallel, phased: D's parameter pass is phase 2 (beside G's all-reduce)
                 lane3 = self.ctx.lane_stream(3)
                 g.wgrad_stream, g.wgrad_cuts = lane3, [8]
                 g.backward(use_dgen2=True, defer_wgrads='staged')
                 self.ctx.join(main, lane3)
             elif phase == 1:
                 g.backward(use_dgen2=True)
-            elif self.ctx.ms_mode == 2:
-                lane2.wait_stream(main)
-                d.backward_params()
-                g.backward(use_dgen2=True)
-                self.ctx.join(main, lane2)
-            elif self.ctx.ms_mode == 1:       # one fork/join: G's wgrads (they only feed Adam) beside D's pass
-                g.backward(use_dgen2=True, defer_wgrads=True)
-                lane2.wait_stream(main)
-                g.run_deferred_wgrads(lane2)
-                d.backward_params()
-                self.ctx.join(main, lane2)
-            elif self.ctx.ms_mode == 5:       # mode 3 + G's wgrads on their own side stream (per-op dependencies)
-                lane2.wait_stream(main)
-                self.ctx.run_on(d.params_ops(), lane2)
-                self.ctx.multistream = True
-                g.backward(use_dgen2=True)
-                self.ctx.multistream = False
-                self.ctx.join(main, lane2)
-            elif self.ctx.ms_mode == 3:       # D's parameter pass beside the whole G backward
-                lane2.wait_stream(main)
-                self.ctx.run_on(d.params_ops(), lane2)
-                g.backward(use_dgen2=True)
-                self.ctx.join(main, lane2)
-            elif self.ctx.ms_mode == 4:       # three chains: D params | G dgrad/norm chain | G wgrads in two stages
+            elif self.ctx.lanes:              # three chains: D params | G dgrad/norm chain | G wgrads in coarse stages
                 lane3 = self.ctx.lane_stream(3)
                 lane2.wait_stream(main)
                 self.ctx.run_on(d.params_ops(), lane2)
@@ -320,9 +303,9 @@ class Pix2PixStep(_StepBase):
                     self._adam_done = (self.D,)
                 # the decoder's wgrad GEMMs start on lane 3 once the main chain has passed the decoder, the encoder's
                 # at its end (+2.5 % over one stage at the end; per-op dependencies, mode 5, lose 9 %)
-                g.wgrad_stream, g.wgrad_cuts = lane3, [int(c) for c in os.environ.get('GAN_AMD_WCUT', '8,12').split(',')]
+                g.wgrad_stream, g.wgrad_cuts = lane3, list(self.wgrad_cuts)
                 g.stage_hook = None
-                if getattr(self, '_updating', False) and self.sync is None and self.ctx.ls is None and os.environ.get('GAN_AMD_EARLY_ADAM', '1') == '1':
+                if getattr(self, '_updating', False) and self.sync is None and self.ctx.ls is None and self.early_adam:
                     # a segment's kernel gradients are complete once its wgrads (a stage on lane 3) are done: its Adam +
                     # NK refresh (HBM-bound) runs on lane 4 beside the rest of the backward pass.  Stages: decoder
                     # (last, up6..up0) | down7..down4 | down3..down0 (the tail, updated after the join with the vectors)
@@ -448,13 +431,13 @@ class Pix2PixStep(_StepBase):
         def a3():
             PD.adam(self.lr, self.b1, self.b2, grad_scale=gs, wire_ptr=wp[1])
 
-        # The four logical stages can be captured as fewer graphs: GAN_AMD_DDP_GRAPHS = 4 (one per stage; default: every
+        # The four logical stages can be captured as fewer graphs: ddp_graphs = 4 (one per stage; default: every
         # bucket leaves as early as it can), 3 (stages 3+4 together) or 2 (1+2 | 3+4).  On the one-rank rehearsal the three
         # are within noise of each other (3.57-3.65 ms): the boundaries (~50 us of drained lanes each) are not what the
         # schedule costs.  A bucket leaves at the end of the graph that holds its stage.
         stages_fn = (g1, g2, g3, g4)
         base_plan = {0: [(4, 3)], 1: [(0, 0)], 2: [(1, 1)], 3: [(2, None), (3, 2)]}
-        grouping = {'4': [[0], [1], [2], [3]], '3': [[0], [1], [2, 3]], '2': [[0, 1], [2, 3]]}[os.environ.get('GAN_AMD_DDP_GRAPHS', '4')]
+        grouping = {4: [[0], [1], [2], [3]], 3: [[0], [1], [2, 3]], 2: [[0, 1], [2, 3]]}[self.ddp_graphs]
 
         def group_fn(idx):
             def f():
@@ -472,7 +455,7 @@ class Pix2PixStep(_StepBase):
         # for the host's communicator calls between two compute graphs (that was ~50 us of idle chip per boundary).
         evs = [torch.cuda.Event() for _ in G]
         comm = torch.cuda.Stream(device=ctx.device)
-        late = os.environ.get('GAN_AMD_DDP_LATE_COMM', '1') == '1'
+        late = self.ddp_late_comm
 
         def boundary(k):
             todo = plan.get(k, ())
@@ -512,8 +495,10 @@ class Pix2PixStep(_StepBase):
 
 
 class CycleGANStep(_StepBase):
+    ddp_buckets = False
+
     def __init__(self, ctx: Ctx, batch, size, channels=1, lam=10.0, lr=2e-4, beta_1=0.5, beta_2=0.999,
-                 seed=123, dropout=True, nets=None, mask_stream=0):
+                 seed=123, dropout=True, nets=None, mask_stream=0, merged=True):
         self.ctx, self.B, self.S, self.C = ctx, batch, size, channels
         self.lam, self.lr, self.b1, self.b2 = float(lam), lr, beta_1, beta_2
         n = 'instancenorm'                                                    # cycle_gan.py:30-33
@@ -528,8 +513,8 @@ class CycleGANStep(_StepBase):
         # The step is launch- and small-grid-bound (~1,200 launches): G_g(x) and G_g(y) - likewise G_f(y), G_f(x) - use the same
         # weights and InstanceNormalization is per sample, so the two invocations run as ONE call of batch 2B (exactly the
         # same arithmetic per sample, a third fewer generator launches); the cycle calls depend on their outputs and stay.
-        # Measured +30 % (B=1) ... +15 % (B=16) pairs/s; GAN_AMD_CYC_MERGE=0 keeps the six separate calls for A/B runs.
-        self.merged = os.environ.get('GAN_AMD_CYC_MERGE', '1') == '1'
+        # Measured +30 % (B=1) ... +15 % (B=16) pairs/s; merged=False keeps the six separate calls (equivalence test, A/B runs).
+        self.merged = bool(merged)
         self.cx, self.cy = mk(self.Gf, 1), mk(self.Gg, 3)      # cycled_x = G_f(fake_y); cycled_y = G_g(fake_x)
         if self.merged:
             self.gA = self.Gg.new_call(2 * batch, size, dropout=dropout, seed=seed, stream_id=mask_stream + 0)   # [fake_y ; same_y]
@@ -613,18 +598,10 @@ class CycleGANStep(_StepBase):
             dx.backward_input(1, dst=fx.dgen.view(0, Cc))
             self._copy(cy.dxin.view(0, Cc), fx.dgen2.view(0, Cc))
             fx.backward(use_dgen2=True, accumulate=True)              # G_f
-            main, lane2 = self.ctx.lane_stream(0), self.ctx.lane_stream(2)
-            if phase == 0 and self.ctx.ms_mode == 2:
-                lane2.wait_stream(main)
-                dx.backward_params(); dy.backward_params()            # :257-260, second chain beside the identity terms
-                sy.backward(accumulate=True)                          # identity_y -> G_g
-                sx.backward(accumulate=True)                          # identity_x -> G_f
-                self.ctx.join(main, lane2)
-            else:
-                sy.backward(accumulate=True)
-                sx.backward(accumulate=True)
-                if phase != 1:
-                    dx.backward_params(); dy.backward_params()
+            sy.backward(accumulate=True)                              # identity_y -> G_g
+            sx.backward(accumulate=True)                              # identity_x -> G_f
+            if phase != 1:
+                dx.backward_params(); dy.backward_params()            # :257-260
         return self.losses                                            # four Adam applies: _update() (:263-273)
 
     def _forward_backward_merged(self, real_x, real_y, training, phase):

@@ -218,12 +218,11 @@ def test_loss_scale_state_machine():
     assert ls.cpu().tolist() == [512.0, 1.0 / 512.0, 0.0, 0.0]             # grew after growth_interval = 2 finite steps
 
 
-def test_pix2pix_f16_step_vs_oracle(monkeypatch):
+def test_pix2pix_f16_step_vs_oracle():
     """The fp16 storage path (v_mfma_f32_16x16x32_f16, fp32 master weights, loss-scaled gradients) on a Pix2Pix step."""
-    monkeypatch.setenv('GAN_AMD_LOSS_SCALE', '1024')
     from gan_amd.nets import Ctx
     from gan_amd.steps import Pix2PixStep
-    ctx = Ctx('cuda:0', 'f16')
+    ctx = Ctx('cuda:0', 'f16', loss_scale=1024.0)
     B, S = 2, 256
     st = Pix2PixStep(ctx, B, S, 1, lam=100.0, seed=123)
     Gp, Dp = O.init_generator(1, seed=11), O.init_discriminator(1, True, seed=12)
@@ -251,13 +250,12 @@ def test_pix2pix_f16_step_vs_oracle(monkeypatch):
     assert np.abs(newG['down3.kernel'] - G0['down3.kernel']).max() > 1e-4  # the step was applied
 
 
-def test_cyclegan_512_f16_batch16_directional_derivative(monkeypatch):
+def test_cyclegan_512_f16_batch16_directional_derivative():
     """BASELINE config 5's per-GPU shape: CycleGAN 512x512 fp16, batch 16."""
-    monkeypatch.setenv('GAN_AMD_LOSS_SCALE', '1024')
     from gan_amd.nets import Ctx, workspace_mb_for
     from gan_amd.steps import CycleGANStep
     B, S = 16, 512
-    ctx = Ctx('cuda:0', 'f16', workspace_mb=workspace_mb_for(B, S))
+    ctx = Ctx('cuda:0', 'f16', workspace_mb=workspace_mb_for(B, S), loss_scale=1024.0)
     st = CycleGANStep(ctx, B, S, 1, lam=10.0, seed=7, dropout=True)
     rx, ry = O.synthetic_pair(B, S, 1, seed=31)
     tx, ty = torch.from_numpy(rx).to(ctx.device), torch.from_numpy(ry).to(ctx.device)

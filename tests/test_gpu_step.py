@@ -162,9 +162,9 @@ def test_cyclegan_train_step_parity(dtype):
     check_grads(dtype, pairs, 1e-1)
 
 
-def test_cyclegan_batched_generator_calls_equal_separate_calls(monkeypatch):
+def test_cyclegan_batched_generator_calls_equal_separate_calls():
     """G_g([x ; y]) / G_f([y ; x]) as one batch-2B call each (the default schedule) against six separate generator calls
-    (GAN_AMD_CYC_MERGE=0) at B=2, fp32: same masks per logical call, same losses and the same 4 gradient sets."""
+    (merged=False) at B=2, fp32: same masks per logical call, same losses and the same 4 gradient sets."""
     from gan_amd.nets import Ctx
     from gan_amd.steps import CycleGANStep
     B, S, C = 2, 256, 1
@@ -172,11 +172,10 @@ def test_cyclegan_batched_generator_calls_equal_separate_calls(monkeypatch):
     keys = ['fake_y', 'cycled_x', 'fake_x', 'cycled_y', 'same_x', 'same_y']
     masks = {k: O.dropout_masks(B, S, seed=60 + i) for i, k in enumerate(keys)}
     res = []
-    for merge in ('1', '0'):
-        monkeypatch.setenv('GAN_AMD_CYC_MERGE', merge)
+    for merge in (True, False):
         ctx = Ctx('cuda:0', 'f32')
-        st = CycleGANStep(ctx, B, S, C, lam=10.0, seed=7, dropout=True)
-        assert st.merged == (merge == '1')
+        st = CycleGANStep(ctx, B, S, C, lam=10.0, seed=7, dropout=True, merged=merge)
+        assert st.merged == merge
         for k, call in st.gen_calls().items():
             call.set_dropmasks(masks[k])
         losses = st.train_step(torch.from_numpy(rx).to(ctx.device), torch.from_numpy(ry).to(ctx.device), True).cpu().numpy().copy()
@@ -263,16 +262,16 @@ class _FakeSync:
 
 
 @pytest.mark.parametrize("buckets", ['1', '0'])
-def test_ddp_schedules_match_single_graph(buckets, monkeypatch):
+def test_ddp_schedules_match_single_graph(buckets):
     """The bucketed data-parallel schedule (4 compute graphs, a bucket leaving after each of the last three, Adam per
     bucket on a side stream) and the phased schedule (a graph per network-complete point) both end in the one-GPU weights."""
-    monkeypatch.setenv('GAN_AMD_DDP_BUCKETS', buckets)
     ctx, st, Gp, Dp, inp, tar, masks = _setup_p2p('f32', B=2)
     ti, tt = torch.from_numpy(inp).to(ctx.device), torch.from_numpy(tar).to(ctx.device)
     st.train_step(ti, tt, True)
     w_ref, d_ref = st.G.params.master.clone(), st.D.params.master.clone()
     ctx2, st2, *_ = _setup_p2p('f32', B=2)
     st2.sync = _FakeSync()
+    st2.ddp_buckets = buckets == '1'
     replay = st2.capture(training=True)
     for rep in range(2):                       # replays are repeatable
         st2.G.params.load_numpy(Gp); st2.D.params.load_numpy(Dp)

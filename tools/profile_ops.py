@@ -10,12 +10,11 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--batch', type=int, default=16); ap.add_argument('--img-size', type=int, default=256)
 ap.add_argument('--dtype', default='bf16'); ap.add_argument('--model', default='pix2pix'); ap.add_argument('--reps', type=int, default=5)
 a = ap.parse_args()
-ctx = Ctx('cuda:0', a.dtype)
+ctx = Ctx('cuda:0', a.dtype, lanes=False)
 step = (Pix2PixStep if a.model == 'pix2pix' else CycleGANStep)(ctx, a.batch, a.img_size, 1)
 x = [torch.rand(a.batch, a.img_size, a.img_size, 1, device='cuda') * 2 - 1 for _ in range(2)]
 recs = []
 orig = ctx.run
-ctx.multistream = False; ctx.ms_mode = 0
 def timed(ops, lane=0):
     st = ctx.stream()
     for op in ops:
