@@ -69,6 +69,7 @@ def _directional(step, nets_losses, ti, tt, eps_frac, tol):
     step._forward_backward(ti, tt, True)
     torch.cuda.synchronize()
     base = step.losses.clone()
+    gaps = []
     for net, li in nets_losses:
         P = net.params
         g, w0 = P.grad.clone(), P.master.clone()
@@ -87,6 +88,8 @@ def _directional(step, nets_losses, ti, tt, eps_frac, tol):
         fd, pred = (vals[0] - vals[1]) / 2.0, eps * g2
         print(f"loss[{li}] = {float(base[li]):.5f}: finite difference {fd:.6e} vs <g,delta> {pred:.6e}")
         assert abs(fd - pred) < tol * abs(pred), (li, fd, pred)
+        gaps.append(abs(fd - pred) / abs(pred))
+    return gaps
 
 
 def test_pix2pix_512_bf16_batch8_directional_derivative():
@@ -98,7 +101,7 @@ def test_pix2pix_512_bf16_batch8_directional_derivative():
     inp, tar = O.synthetic_pair(8, 512, 1, seed=5)
     st.g.set_dropmasks(O.dropout_masks(8, 512, seed=6))
     ti, tt = torch.from_numpy(inp).to(ctx.device), torch.from_numpy(tar).to(ctx.device)
-    _directional(st, ((st.G, 0), (st.D, 3)), ti, tt, 3e-2, 0.2)
+    _directional(st, ((st.G, 0), (st.D, 3)), ti, tt, 3e-2, 0.12)        # (measured 4 % / 0.02 % off)
 
 
 def test_pix2pix_512_bf16_batch2_vs_oracle():
@@ -117,7 +120,7 @@ def test_pix2pix_512_bf16_batch2_vs_oracle():
     gen = st.g.output_f32().cpu().numpy()
     err = float(np.abs(gen - ref[4]).max())
     print(f"[512 bf16 B=2] gen max-abs err {err:.3e}; losses {losses} ref {[float(v) for v in ref[:4]]}")
-    assert err < 0.15 and np.allclose(losses, np.array(ref[:4], np.float64), rtol=5e-2)
+    assert err < 0.03 and np.allclose(losses, np.array(ref[:4], np.float64), rtol=5e-3)      # (measured 1.0e-2, <= 1.1e-3)
     gG, gD = st.G.params.to_numpy('grad'), st.D.params.to_numpy('grad')
     gmax = max(np.linalg.norm(v) for v in ref[5].values())
     for k, v in ref[5].items():
@@ -173,6 +176,31 @@ def test_cyclegan_bf16_directional_derivative(batch, size):
         call.set_dropmasks(O.dropout_masks(batch, size, seed=80 + i))
     tx, ty = torch.from_numpy(rx).to(ctx.device), torch.from_numpy(ry).to(ctx.device)
     _directional(st, ((st.Gg, 3), (st.Gf, 4), (st.Dx, 5), (st.Dy, 6)), tx, ty, 3e-2, 0.25)
+
+
+def test_cyclegan_directional_derivative_curvature_not_bf16():
+    """The generators' 12-15 % gap between <g, delta> and the central difference in the test above is CURVATURE of the loss
+    along the gradient at a 3 % step (lambda * |.| terms: kinks on both sides), not a bf16 gradient bias: the fp32 path shows the
+    same gap at the same step, and in both dtypes it shrinks about linearly when the step is halved and quartered."""
+    from gan_amd.nets import Ctx, workspace_mb_for
+    from gan_amd.steps import CycleGANStep
+    batch, size = 4, 256
+    rx, ry = O.synthetic_pair(batch, size, 1, seed=29)
+    gaps = {}
+    for dtype in ('f32', 'bf16'):
+        for frac in (3e-2, 1.5e-2, 7.5e-3):
+            ctx = Ctx('cuda:0', dtype, workspace_mb=workspace_mb_for(batch, size))
+            st = CycleGANStep(ctx, batch, size, 1, lam=10.0, seed=7, dropout=True)
+            for i, call in enumerate(st.gen_calls().values()):
+                call.set_dropmasks(O.dropout_masks(batch, size, seed=80 + i))
+            tx, ty = torch.from_numpy(rx).to(ctx.device), torch.from_numpy(ry).to(ctx.device)
+            gaps[dtype, frac] = _directional(st, ((st.Gg, 3), (st.Gf, 4)), tx, ty, frac, 0.25)
+    print("relative gaps (G_g, G_f):", {k: [round(x, 4) for x in v] for k, v in gaps.items()})
+    for i in range(2):
+        assert abs(gaps['f32', 3e-2][i] - gaps['bf16', 3e-2][i]) < 0.04          # the same gap in fp32: not a bf16 effect
+        for dtype in ('f32', 'bf16'):
+            assert gaps[dtype, 7.5e-3][i] < 0.6 * gaps[dtype, 3e-2][i] + 0.01     # ... and it goes away with the step
+        assert gaps['f32', 7.5e-3][i] < 0.06
 
 
 def test_loss_scale_state_machine():
@@ -236,7 +264,7 @@ def test_pix2pix_f16_step_vs_oracle():
     gen = st.g.output_f32().cpu().numpy()
     err = float(np.abs(gen - ref[4]).max())
     print(f"[f16] gen max-abs err {err:.3e}; losses {losses} ref {[float(v) for v in ref[:4]]}; scale state {ctx.ls.cpu().tolist()}")
-    assert err < 2e-2 and np.allclose(losses, np.array(ref[:4], np.float64), rtol=1e-2)
+    assert err < 6e-3 and np.allclose(losses, np.array(ref[:4], np.float64), rtol=1e-3)      # (measured 1.7e-3, <= 7e-5)
     assert ctx.ls.cpu().tolist() == [1024.0, 1.0 / 1024.0, 1.0, 0.0]        # finite step, nothing skipped
     gG = st.G.params.to_numpy('grad')
     gmax = max(np.linalg.norm(v) for v in ref[5].values())

@@ -83,8 +83,8 @@ def test_pix2pix_train_step_parity(dtype):
         assert np.allclose(losses, ref_losses, rtol=2e-4)
         ptol = 2e-5
     else:
-        assert err < 0.15                      # bf16 storage: reported, not the parity gate
-        assert np.allclose(losses, ref_losses, rtol=5e-2)
+        assert err < 0.04                      # bf16 storage (measured 1.4e-2): reported, not the parity gate
+        assert np.allclose(losses, ref_losses, rtol=5e-3)       # (measured <= 1.2e-3)
         ptol = 4.1e-4
     got_gG, got_gD = st.G.params.to_numpy('grad'), st.D.params.to_numpy('grad')
     check_grads(dtype, [('G.' + k, got_gG[k], gG[k]) for k in gG] + [('D.' + k, got_gD[k], gD[k]) for k in gD], 2e-2)
@@ -152,7 +152,7 @@ def test_cyclegan_train_step_parity(dtype):
     if dtype == 'f32':
         assert err < 1e-3 and np.allclose(losses, ref_losses, rtol=5e-4)
     else:
-        assert err < 0.2 and np.allclose(losses, ref_losses, rtol=8e-2)
+        assert err < 0.025 and np.allclose(losses, ref_losses, rtol=5e-3)      # (measured 7.8e-3, <= 1.2e-3)
     pairs = []
     for nm, net, g in zip(('Gg', 'Gf', 'Dx', 'Dy'), (st.Gg, st.Gf, st.Dx, st.Dy), grads):
         got = net.params.to_numpy('grad')
@@ -160,6 +160,41 @@ def test_cyclegan_train_step_parity(dtype):
     # the numpy oracle itself run in fp32 differs from its fp64 run by up to 5.5e-2 on these tensors
     # (instance-norm + ReLU kinks at batch 1), so that is the noise floor for a per-tensor max-abs bound
     check_grads(dtype, pairs, 1e-1)
+
+
+def test_cyclegan_batch2_f32_vs_oracle():
+    """CycleGAN at B = 2 (the merged schedule: G_g([x ; y]), G_f([y ; x]) as batch-4 calls with per-sample InstanceNorm) against
+    the oracle: 7 losses, the six generator outputs and the gradients of all four networks (cycle_gan.py:252-260)."""
+    from gan_amd.nets import Ctx
+    from gan_amd.steps import CycleGANStep
+    ctx = Ctx('cuda:0', 'f32')
+    B, S, C = 2, 256, 1
+    st = CycleGANStep(ctx, B, S, C, lam=10.0, seed=7, dropout=True)
+    n = 'instancenorm'
+    Ps = [O.init_generator(C, n, seed=51), O.init_generator(C, n, seed=52),
+          O.init_discriminator(C, False, n, seed=53), O.init_discriminator(C, False, n, seed=54)]
+    for net, P in zip(st.nets(), Ps):
+        net.params.load_numpy(P)
+    rx, ry = O.synthetic_pair(B, S, C, seed=13)
+    keys = ['fake_y', 'cycled_x', 'fake_x', 'cycled_y', 'same_x', 'same_y']
+    masks = {k: O.dropout_masks(B, S, seed=140 + i) for i, k in enumerate(keys)}
+    for k, call in st.gen_calls().items():
+        call.set_dropmasks(masks[k])
+    Pr = [{k: v.astype(np.float64) for k, v in P.items()} for P in Ps]
+    m64 = {k: [m.astype(np.float64) for m in v] for k, v in masks.items()}
+    out = O.cyclegan_train_step(*Pr, [O.AdamTF() for _ in range(4)], rx.astype(np.float64), ry.astype(np.float64), 10.0, m64, True,
+                                return_grads=True)
+    ref_losses, fakes, grads = np.array(out[:7], np.float64), out[7], out[8:]
+    losses = st.train_step(torch.from_numpy(rx).to(ctx.device), torch.from_numpy(ry).to(ctx.device), True).cpu().numpy()
+    assert np.allclose(losses, ref_losses, rtol=5e-4), (losses, ref_losses)
+    for k, call in st.gen_calls().items():
+        if k in fakes:
+            assert np.abs(call.output_f32().cpu().numpy() - fakes[k]).max() < 1e-3, k
+    pairs = []
+    for nm, net, g in zip(('Gg', 'Gf', 'Dx', 'Dy'), st.nets(), grads):
+        got = net.params.to_numpy('grad')
+        pairs += [(nm + '.' + k, got[k], g[k]) for k in g]
+    check_grads('f32', pairs, 1e-1)
 
 
 def test_cyclegan_batched_generator_calls_equal_separate_calls():
