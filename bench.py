@@ -75,6 +75,24 @@ def gemm_profile(step, inputs, reps=5):
     return out
 
 
+def read_sclk_mhz(index=0):
+    """Current shader clock from sysfs (pp_dpm_sclk lists the levels, the active one carries a '*'): the HIGHEST clock over the
+    visible cards - the node's other GPUs idle at their floor and sysfs card numbers are not HIP device numbers; None when no file
+    is readable.  Reported beside the sustained figure: a burst of 50 steps and seconds of back-to-back replays can hold different
+    clocks (MI355X_MICROARCH.md, DVFS give-back)."""
+    import glob
+    import re
+    best = None
+    for f in glob.glob('/sys/class/drm/card*/device/pp_dpm_sclk'):
+        try:
+            m = re.search(r'(\d+)\s*[Mm][Hh]z\s*\*', open(f).read())
+            if m:
+                best = max(best or 0, int(m.group(1)))
+        except Exception:
+            pass
+    return best
+
+
 def cpu_baseline(budget_s=20.0):
     """The numpy oracle's pix2pix_train_step (the CPU restatement of the reference path; the TF reference
     itself is not installable here) on this box's host cores: 256x256, batch 1 (BASELINE config 1)."""
@@ -133,6 +151,7 @@ def main():
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--fp32-allreduce', action='store_true', help='exchange gradients as fp32 instead of bf16')
     ap.add_argument('--repeats', type=int, default=5, help='the K-step timed region is run this many times; the median is reported')
+    ap.add_argument('--sustain', type=float, default=3.0, help='seconds of back-to-back steps for the "sustained" key (0: skip)')
     ap.add_argument('--single-stream', action='store_true', help='no side lanes: every launch of the captured step on one stream (profiling)')
     ap.add_argument('--exchange', default='allreduce', choices=['allreduce', 'rs_ag'],
                     help='gradient exchange: all-reduce per bucket, or fp32 reduce-scatter + all-gather in the wire format')
@@ -232,6 +251,29 @@ def main():
             dt = float(t.item())
         times.append(dt)
     dt = sorted(times)[len(times) // 2]             # median over the repeats (max over ranks inside each)
+    # sustained figure: >= --sustain seconds of back-to-back steps (the timed region above is a few 0.2 s bursts)
+    sustained = None
+    if args.sustain > 0:
+        n_sus = max(args.steps, int(np.ceil(args.sustain / (dt / args.steps))))
+        clk0 = read_sclk_mhz(local)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(n_sus):
+            run()
+        clk_mid = read_sclk_mhz(local)                # (read while the queue is still full)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        ds = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([ds], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            ds = float(t.item())
+        sustained = {"seconds": round(ds, 3), "steps": n_sus, "ms_per_step": round(ds / n_sus * 1e3, 4),
+                     "value": round(world * B * n_sus / ds, 2), "sclk_mhz_before": clk0, "sclk_mhz_under_load": clk_mid,
+                     "sclk_mhz_after": read_sclk_mhz(local)}
     losses = step.losses.cpu().numpy()
     if not np.all(np.isfinite(losses)):
         raise RuntimeError(f"non-finite losses {losses}")
@@ -244,7 +286,7 @@ def main():
                "value": round(value, 2), "unit": unit, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": args.dtype, "data": "synthetic", "repeats": len(times), **({"ddp_rehearsal_one_rank": True} if rehearse else {}),
-               "ms_per_step_all_repeats": [round(t_ / args.steps * 1e3, 4) for t_ in times],
+               "ms_per_step_all_repeats": [round(t_ / args.steps * 1e3, 4) for t_ in times], "sustained": sustained,
                "config": {"workload": f"{'Pix2Pix' if args.model == 'pix2pix' else 'CycleGAN'} {S}x{S} {args.dtype} "
                                       f"batch={B}/GPU train_step (G fwd, D fwd real+fake, losses, dgrad+wgrad, Adam"
                                       f"{', RCCL grad all-reduce' if world > 1 else ''})",
@@ -261,7 +303,7 @@ def main():
         # HBM bytes per launch come from a separate rocprofv3 --pmc pass of this same command (counters cannot be
         # collected inside this process); the committed summary is quoted and named, never re-measured here
         traffic, traffic_src = None, None
-        for name in ('r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
+        for name in ('r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
             try:
                 pmc = json.load(open(os.path.join(ROOT, 'profiles', name)))
                 if B == 16 and S == 256 and args.model == 'pix2pix' and kname in pmc:

@@ -9,7 +9,7 @@ for round in 1 2; do
   for v in "$@"; do
     envs=""; args=""
     for w in $v; do case "$w" in [A-Z_]*=*) envs="$envs $w";; *) args="$args $w";; esac; done
-    r=$(env $envs python bench.py --no-cpu-baseline --repeats 3 $args 2>/dev/null | grep '^{"metric"' | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])")
+    r=$(env $envs python bench.py --no-cpu-baseline --repeats 3 --sustain 0 $args 2>/dev/null | grep '^{"metric"' | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])")
     echo "[$v] round$round: $r" | tee -a $out
   done
 done

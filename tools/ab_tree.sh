@@ -5,7 +5,7 @@ out=$1; shift
 mkdir -p $(dirname $out); : > $out
 for round in 1 2 3; do
   for tree in _ab/base .; do
-    r=$(cd $tree && python bench.py --no-cpu-baseline --repeats 3 "$@" 2>/dev/null | grep '^{"metric"' | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])")
+    r=$(cd $tree && python bench.py --no-cpu-baseline --repeats 3 --sustain 0 "$@" 2>/dev/null | grep '^{"metric"' | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])")
     echo "[$tree] round$round: $r" | tee -a $out
   done
 done

@@ -6,7 +6,7 @@ mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 i=0
 for v in "$@"; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d $out/v$i -o s -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --repeats 1 --no-cpu-baseline --single-stream $v > $out/v$i.json 2> $out/v$i.err
+  rocprofv3 --kernel-trace --stats --output-format csv -d $out/v$i -o s -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --repeats 1 --no-cpu-baseline --sustain 0 --single-stream $v > $out/v$i.json 2> $out/v$i.err
   cp $out/v$i/s_kernel_stats.csv $out/v${i}_kernel_stats.csv
   cp $out/v$i/s_kernel_trace.csv $out/v${i}_kernel_trace.csv
   rm -rf $out/v$i
