@@ -155,6 +155,8 @@ def main():
     ap.add_argument('--single-stream', action='store_true', help='no side lanes: every launch of the captured step on one stream (profiling)')
     ap.add_argument('--exchange', default='allreduce', choices=['allreduce', 'rs_ag'],
                     help='gradient exchange: all-reduce per bucket, or fp32 reduce-scatter + all-gather in the wire format')
+    ap.add_argument('--step-attr', action='append', default=[], metavar='NAME=PYLITERAL',
+                    help='schedule attribute of the step object (gan_amd/steps.py class attributes, e.g. early_adam=False); for A/B runs')
     ap.add_argument('--opt', action='append', default=[], metavar='KEY=VALUE',
                     help='planner option of the kernel library (gan_set_option, include/gan_amd.h); for A/B runs')
     args = ap.parse_args()
@@ -217,6 +219,12 @@ def main():
         step = Pix2PixStep(ctx, B, S, 1, lam=100.0, seed=123)
     else:
         step = CycleGANStep(ctx, B, S, 1, lam=10.0, seed=123)
+    for kv in args.step_attr:
+        import ast
+        k, v = kv.split('=', 1)
+        if not hasattr(step, k):
+            raise SystemExit(f"bench.py: the step has no attribute {k!r}")
+        setattr(step, k, ast.literal_eval(v))
     if world > 1 or rehearse:
         step.sync = GradSync([n.params.grad for n in step.nets()], compress_bf16=(args.dtype != "f32" and not args.fp32_allreduce), lib=ctx.lib,
                              rehearse=rehearse, exchange=args.exchange)

@@ -183,6 +183,97 @@ __global__ __launch_bounds__(256) void conv_thin_col2im_kernel(const Col2imParam
   }
 }
 
+// thin-N in ONE kernel for <= 2 output channels (the tanh head, the logits layer and the dgrad into the image at C = 1): a block
+// owns a TH x TW tile of the GEMM grid, computes Z for the tile plus its halo into LDS (same MFMA formulation as step 1 above)
+// and gathers the outputs from there - Z never goes through memory (33.5 MB written + read per launch before) and one launch
+// instead of two.  The halo pixels are computed twice (tile 16 x 32: 1.2x the input reads, mostly L2 hits).
+//   parity (stride-2 transposed conv / conv dgrad): halo 1 pixel each side; a thread produces the 2 x 2 output quad of a grid pixel
+//   stride 1, pad 1 (logits layer): halo 1 before, 2 after; a thread produces one output pixel
+struct ThinNFusedParams {
+  const void* x; const void* w; void* y; const float* bias;
+  int Hs, Ws, xpitch, Cin, Wrows, CO;
+  int Ho, Wo, ypitch, out_f32, act, f16;
+  float slope;
+  int tilesY, tilesX;
+};
+
+template <typename T, int KS, bool PARITY, int TH, int TW>
+__global__ __launch_bounds__(256) void conv_thin_n_fused_kernel(const ThinNFusedParams p) {
+  constexpr int HB = 1, HA = PARITY ? 1 : 2;                 // halo before / after
+  constexpr int SH = TH + HB + HA, SW = TW + HB + HA, NPX = SH * SW, NT = (NPX + 15) / 16;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint4* wl = (uint4*)smem;                                  // [c][s][lane] weight fragments
+  float* zl = (float*)(smem + (size_t)p.CO * KS * 1024);     // [pixel][c][16 taps]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = lane & 15, q = lane >> 4;
+  int b = blockIdx.x;
+  const int tx = b % p.tilesX; b /= p.tilesX;
+  const int ty = b % p.tilesY; const int img = b / p.tilesY;
+  const int y0 = ty * TH - HB, x0 = tx * TW - HB;            // source origin of the halo region
+  for (int e = threadIdx.x; e < p.CO * KS * 64; e += 256) {
+    const int l = e & 63, s = (e >> 6) % KS, c = (e >> 6) / KS;
+    wl[e] = *(const uint4*)((const T*)p.w + ((size_t)(l & 15) * p.Wrows + c) * p.Cin + s * 32 + (l >> 4) * 8);
+  }
+  __syncthreads();
+  for (int tile = wave; tile < NT; tile += 4) {
+    const int e = tile * 16 + n;
+    const int hy = e / SW, hx = e - hy * SW;
+    const int sy = y0 + hy, sx = x0 + hx;
+    const bool ok = e < NPX && (unsigned)sy < (unsigned)p.Hs && (unsigned)sx < (unsigned)p.Ws;
+    uint4 xf[KS];
+    const T* xp = (const T*)p.x + ((size_t)(img * p.Hs + sy) * p.Ws + sx) * p.xpitch + q * 8;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) xf[s] = ok ? *(const uint4*)(xp + s * 32) : make_uint4(0, 0, 0, 0);
+    for (int c = 0; c < p.CO; ++c) {
+      f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < KS; ++s) acc = mma16<T>(wl[(c * KS + s) * 64 + lane], xf[s], acc);
+      if (e < NPX) *(f32x4*)(zl + ((size_t)e * p.CO + c) * 16 + q * 4) = acc;      // (pixels outside the map: x = 0, so Z = 0)
+    }
+  }
+  __syncthreads();
+  auto store = [&](int Y, int X, int c, float v) {
+    v += p.bias ? p.bias[c] : 0.f;
+    v = apply_act(v, p.act, p.slope);
+    const size_t o = ((size_t)(img * p.Ho + Y) * p.Wo + X) * p.ypitch + c;
+    if (p.out_f32) ((float*)p.y)[o] = v;
+    else if (p.f16) ((f16_t*)p.y)[o] = (f16_t)v;
+    else ((bf16_t*)p.y)[o] = (bf16_t)v;
+  };
+  for (int t = threadIdx.x; t < TH * TW; t += 256) {
+    const int ly = t / TW, lx = t - ly * TW;
+    const int gy = ty * TH + ly, gx = tx * TW + lx;          // grid position (parity: source pixel; stride 1: output pixel)
+    if (PARITY) {
+      if (gy >= p.Hs || gx >= p.Ws) continue;
+      for (int c = 0; c < p.CO; ++c) {
+#pragma unroll
+        for (int py = 0; py < 2; ++py)
+#pragma unroll
+          for (int px = 0; px < 2; ++px) {
+            float v = 0.f;
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+              for (int bb = 0; bb < 2; ++bb)     // y[2g+py] = sum_a x[g + py - a] * w[1 - py + 2a]
+                v += zl[((size_t)((ly + HB + py - a) * SW + (lx + HB + px - bb)) * p.CO + c) * 16 + (1 - py + 2 * a) * 4 + (1 - px + 2 * bb)];
+            store(2 * gy + py, 2 * gx + px, c, v);
+          }
+      }
+    } else {
+      if (gy >= p.Ho || gx >= p.Wo) continue;
+      for (int c = 0; c < p.CO; ++c) {
+        float v = 0.f;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int bb = 0; bb < 4; ++bb)         // y[g] = sum_a x[g - 1 + a] * w[a]
+            v += zl[((size_t)((ly + a) * SW + (lx + bb)) * p.CO + c) * 16 + a * 4 + bb];
+        store(gy, gx, c, v);
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 int thin_family(const GanConvDesc* d, int op, const GemmParams& p) {
   const int on = gan_opt("conv.thin"), off = (on & 1) ? (~on & 6) : 1;      // off: 1 = none, bit 1 = no thin-N, bit 2 = no thin-K
@@ -199,8 +290,13 @@ int thin_family(const GanConvDesc* d, int op, const GemmParams& p) {
   return 0;
 }
 
+// thin-N in one kernel (conv_thin_n_fused_kernel): <= 2 output channels, parity form or stride 1 with pad 1
+static bool thin_n_fused_ok(const GanConvDesc* d, const GemmParams& p) {
+  return gan_opt("conv.thin_fused") && d->y.c <= 2 && (p.parity || (p.S == 1 && p.dstep == 1 && p.dy0 == -1 && p.dx0 == -1));
+}
+
 size_t thin_workspace_bytes(int family, const GanConvDesc* d, const GemmParams& p) {
-  if (family != 1) return 0;
+  if (family != 1 || thin_n_fused_ok(d, p)) return 0;
   return (size_t)d->x.n * d->x.h * d->x.w * d->y.c * 16 * sizeof(float);
 }
 
@@ -223,6 +319,35 @@ int thin_launch(int family, const GanConvDesc* d, const GemmParams& p, hipStream
     return 0;
   }
   if (family != 1) return GAN_E_ARG;
+  if (thin_n_fused_ok(d, p)) {
+    ThinNFusedParams f;
+    f.x = p.x; f.w = p.w; f.y = p.y; f.bias = p.bias;
+    f.Hs = p.Hs; f.Ws = p.Ws; f.xpitch = p.xpitch; f.Cin = x.c; f.Wrows = p.Wrows; f.CO = y.c;
+    f.Ho = p.Ho; f.Wo = p.Wo; f.ypitch = p.ypitch; f.out_f32 = p.out_f32; f.act = p.act; f.f16 = d->dtype == GAN_F16; f.slope = p.slope;
+    const int KS = x.c / 32;
+    auto launch_f = [&](auto* tag, auto parc) -> int {
+      typedef typename std::remove_pointer<decltype(tag)>::type T;
+      constexpr bool PAR = decltype(parc)::value;
+      constexpr int TH = PAR ? 16 : 10, TW = 32;
+      constexpr int NPX = (TH + (PAR ? 2 : 3)) * (TW + (PAR ? 2 : 3));
+      f.tilesY = ((PAR ? p.Hs : p.Ho) + TH - 1) / TH; f.tilesX = ((PAR ? p.Ws : p.Wo) + TW - 1) / TW;
+      const size_t smem = (size_t)f.CO * KS * 1024 + (size_t)NPX * f.CO * 64;
+      const dim3 grid((unsigned)(x.n * f.tilesY * f.tilesX));
+#define THIN_F(KSV)                                                                                                                  \
+      {                                                                                                                               \
+        auto kern = conv_thin_n_fused_kernel<T, KSV, PAR, TH, TW>;                                                                    \
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                 \
+        if (e != hipSuccess) return (int)e;                                                                                           \
+        hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, f);                                                                       \
+      }
+      if (KS == 2) THIN_F(2) else if (KS == 4) THIN_F(4) else THIN_F(16)
+#undef THIN_F
+      GAN_CHECK_LAUNCH();
+      return 0;
+    };
+    if (d->dtype == GAN_F16) return p.parity ? launch_f((f16_t*)nullptr, std::true_type{}) : launch_f((f16_t*)nullptr, std::false_type{});
+    return p.parity ? launch_f((bf16_t*)nullptr, std::true_type{}) : launch_f((bf16_t*)nullptr, std::false_type{});
+  }
   const size_t zbytes = thin_workspace_bytes(1, d, p);
   if (!d->workspace || d->workspace_bytes < zbytes) return GAN_E_WORKSPACE;
   ThinNParams n;

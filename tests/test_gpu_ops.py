@@ -194,7 +194,10 @@ def test_thin_layers_take_streaming_kernels():
     assert c.lib.gan_conv_plan_info(C.byref(d), 0, info) == 0 and (info[0], info[1]) == (0, 2)
     d = L.GanConvDesc(c.dt, 2, x128.view(), y1.view(0, 1), 16, 1, None, 0, 0.3, 0, c.ws_ptr, c.ws_bytes)
     assert c.lib.gan_conv_plan_info(C.byref(d), 2, info) == 0 and (info[0], info[1]) == (0, 1)
-    assert c.lib.gan_conv_workspace_bytes(C.byref(d), 2) == 2 * 16 * 16 * 16 * 4
+    assert c.lib.gan_conv_workspace_bytes(C.byref(d), 2) == 0                # one output channel: Z stays in LDS (conv_thin_n_fused_kernel)
+    prev = L.set_option('conv.thin_fused', 0)
+    assert c.lib.gan_conv_workspace_bytes(C.byref(d), 2) == 2 * 16 * 16 * 16 * 4    # two-kernel form: Z[pixel][c][tap] in the workspace
+    L.set_option('conv.thin_fused', prev)
     c16 = Ctx('cuda:0', 'f16')
     d = L.GanConvDesc(c16.dt, 2, x8.view(), y64.view(), 16, 64, None, 0, 0.3, 0, c.ws_ptr, c.ws_bytes)
     assert c16.lib.gan_conv_plan_info(C.byref(d), 0, info) == 0 and (info[0], info[1]) == (0, 2)      # fp16 streams too
