@@ -505,19 +505,20 @@ class GeneratorNet:
         self.params = ParamSet(ctx, self.spec)
         self.params.load_numpy(init_params_numpy(self.spec, seed))
 
-    def new_call(self, batch, size, dropout=True, seed=1234, stream_id=0, wgrads_on_side_lane=False):
+    def new_call(self, batch, size, dropout=True, seed=1234, stream_id=0, wgrads_on_side_lane=False, lane=0):
         """wgrads_on_side_lane: this call's kernel-gradient GEMMs run on a side lane of a captured step beside the dgrad chain
-        (GanWgradDesc.concurrent: the planner prefers half-chip grids with longer reductions)."""
-        return GenCall(self, batch, size, dropout, seed, stream_id, wgrads_on_side_lane)
+        (GanWgradDesc.concurrent: the planner prefers half-chip grids with longer reductions).  lane: whose workspace the call's
+        launches use (0 | 2): calls that may run at the same time must not share one."""
+        return GenCall(self, batch, size, dropout, seed, stream_id, wgrads_on_side_lane, lane)
 
 
 class GenCall:
     """Buffers + op lists for one invocation `generator(x, training=True)` and its backward."""
 
-    def __init__(self, net, B, S, dropout, seed, stream_id, wgrads_on_side_lane=False):
+    def __init__(self, net, B, S, dropout, seed, stream_id, wgrads_on_side_lane=False, lane=0):
         ctx, P = net.ctx, net.params
         self.net, self.ctx, self.B, self.S, self.C = net, ctx, B, S, net.channels
-        bd = _Builder(ctx, P, net.norm)
+        bd = _Builder(ctx, P, net.norm, lane=lane)
         bd.wgrad_concurrent = bool(wgrads_on_side_lane)
         self._bd = bd
         C_ = net.channels
@@ -816,8 +817,9 @@ class DiscriminatorNet:
         self.params = ParamSet(ctx, self.spec)
         self.params.load_numpy(init_params_numpy(self.spec, seed))
 
-    def new_call(self, batch, size, calls=2):
-        return DiscCall(self, batch, size, calls)
+    def new_call(self, batch, size, calls=2, lane=0, params_lane=2):
+        """lane / params_lane: whose workspace the forward + input-gradient chain / the parameter-gradient pass use."""
+        return DiscCall(self, batch, size, calls, lane, params_lane)
 
 
 class DiscCall:
@@ -828,14 +830,14 @@ class DiscCall:
 
     LAYERS = [('down0', 64, 2), ('down1', 128, 2), ('down2', 256, 2), ('conv', 512, 1), ('last', 1, 1)]
 
-    def __init__(self, net, B, S, calls):
+    def __init__(self, net, B, S, calls, lane=0, params_lane=2):
         ctx, P = net.ctx, net.params
         self.net, self.ctx, self.B, self.S, self.calls = net, ctx, B, S, calls
         N = B * calls
         self.N = N
-        bd = _Builder(ctx, P, net.norm)
+        bd = _Builder(ctx, P, net.norm, lane=lane)
         self._bd = bd
-        self._bd2 = _Builder(ctx, P, net.norm, lane=2)      # parameter-gradient pass: second chain
+        self._bd2 = _Builder(ctx, P, net.norm, lane=params_lane)      # parameter-gradient pass: second chain
         bn = net.norm == 'batchnorm'
         groups = calls if bn else N
         self.groups = groups

@@ -9,6 +9,7 @@ computes forward + losses only (pix2pix.py:208, :291-292).
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 
 import torch
@@ -496,6 +497,7 @@ class Pix2PixStep(_StepBase):
 
 class CycleGANStep(_StepBase):
     ddp_buckets = False
+    two_chains = True            # one-GPU step: the G_g-side and the G_f-side chains on two lanes (_forward_backward_merged)
 
     def __init__(self, ctx: Ctx, batch, size, channels=1, lam=10.0, lr=2e-4, beta_1=0.5, beta_2=0.999,
                  seed=123, dropout=True, nets=None, mask_stream=0, merged=True):
@@ -509,23 +511,28 @@ class CycleGANStep(_StepBase):
             self.Gf = GeneratorNet(ctx, channels, n, seed=seed + 1)
             self.Dx = DiscriminatorNet(ctx, channels, False, n, seed=seed + 2)
             self.Dy = DiscriminatorNet(ctx, channels, False, n, seed=seed + 3)
-        mk = lambda net, sid: net.new_call(batch, size, dropout=dropout, seed=seed, stream_id=mask_stream + sid)
+        mk = lambda net, sid, lane=0: net.new_call(batch, size, dropout=dropout, seed=seed, stream_id=mask_stream + sid, lane=lane)
         # The step is launch- and small-grid-bound (~1,200 launches): G_g(x) and G_g(y) - likewise G_f(y), G_f(x) - use the same
         # weights and InstanceNormalization is per sample, so the two invocations run as ONE call of batch 2B (exactly the
         # same arithmetic per sample, a third fewer generator launches); the cycle calls depend on their outputs and stay.
         # Measured +30 % (B=1) ... +15 % (B=16) pairs/s; merged=False keeps the six separate calls (equivalence test, A/B runs).
         self.merged = bool(merged)
-        self.cx, self.cy = mk(self.Gf, 1), mk(self.Gg, 3)      # cycled_x = G_f(fake_y); cycled_y = G_g(fake_x)
+        # chain "A" (lane 0 workspaces): G_g([x ; y]) -> G_f(fake_y) -> D_y;  chain "B" (lane 2): G_f([y ; x]) -> G_g(fake_x) -> D_x
+        self.cx, self.cy = mk(self.Gf, 1), mk(self.Gg, 3, 2 if self.merged else 0)      # cycled_x = G_f(fake_y); cycled_y = G_g(fake_x)
         if self.merged:
             self.gA = self.Gg.new_call(2 * batch, size, dropout=dropout, seed=seed, stream_id=mask_stream + 0)   # [fake_y ; same_y]
-            self.gB = self.Gf.new_call(2 * batch, size, dropout=dropout, seed=seed, stream_id=mask_stream + 2)   # [fake_x ; same_x]
+            self.gB = self.Gf.new_call(2 * batch, size, dropout=dropout, seed=seed, stream_id=mask_stream + 2, lane=2)   # [fake_x ; same_x]
             self.fy, self.sy = self.gA.half(0, batch), self.gA.half(batch, batch)
             self.fx, self.sx = self.gB.half(0, batch), self.gB.half(batch, batch)
         else:
             self.fy, self.fx = mk(self.Gg, 0), mk(self.Gf, 2)  # fake_y = G_g(x); fake_x = G_f(y)
             self.sx, self.sy = mk(self.Gf, 4), mk(self.Gg, 5)  # same_x = G_f(x); same_y = G_g(y)
-        self.dx = self.Dx.new_call(batch, size, calls=2)       # D_x(real_x) ++ D_x(fake_x)
-        self.dy = self.Dy.new_call(batch, size, calls=2)
+        if self.merged:
+            self.dx = self.Dx.new_call(batch, size, calls=2, lane=2, params_lane=2)       # D_x(real_x) ++ D_x(fake_x): chain B
+            self.dy = self.Dy.new_call(batch, size, calls=2, lane=0, params_lane=0)
+        else:
+            self.dx = self.Dx.new_call(batch, size, calls=2)
+            self.dy = self.Dy.new_call(batch, size, calls=2)
         self.losses = torch.zeros(12, dtype=torch.float32, device=ctx.device)
         self.l1_ws = torch.zeros(4096, dtype=torch.float32, device=ctx.device)
         self.bce_ws = torch.zeros(1024, dtype=torch.float32, device=ctx.device)
@@ -609,15 +616,27 @@ class CycleGANStep(_StepBase):
         B, Cc, lam = self.B, self.C, self.lam
         gA, gB, cx, cy, dx, dy = self.gA, self.gB, self.cx, self.cy, self.dx, self.dy
         fy, sy, fx, sx = self.fy, self.sy, self.fx, self.sx
+        # Two independent halves until the losses and again in the backward pass (cycle_gan.py:220-234 lists them interleaved):
+        # chain A = G_g([x ; y]) -> G_f(fake_y) -> D_y, chain B = G_f([y ; x]) -> G_g(fake_x) -> D_x.  The step is launch- and
+        # small-grid-bound at the reference's batch sizes, so the chains run on two lanes of the captured graph.
+        two = bool(self.ctx.lanes and self.two_chains and phase == 0)
+        main, l2 = self.ctx.lane_stream(0), self.ctx.lane_stream(2)
+        chain_b = (lambda: torch.cuda.stream(l2)) if two else contextlib.nullcontext
         self._pack_multi([(real_x, fy.xin_view()), (real_y, sy.xin_view()), (real_y, fx.xin_view()), (real_x, sx.xin_view())])
         self._pack_multi([(real_x, dx.xin.view(0, Cc, 0, B)), (real_y, dy.xin.view(0, Cc, 0, B))])
+        if two:
+            l2.wait_stream(main)
         gA.forward()                                                  # cycle_gan.py:220 and :228
-        gB.forward()                                                  # :223 and :227
         self._copy(fy.out_view(), cx.xin.view(0, Cc)); self._copy(fy.out_view(), dy.xin.view(0, Cc, B, B))
-        self._copy(fx.out_view(), cy.xin.view(0, Cc)); self._copy(fx.out_view(), dx.xin.view(0, Cc, B, B))
         cx.forward()                                                  # :221
-        cy.forward()                                                  # :224
-        dx.forward(); dy.forward()                                    # :230-234
+        dy.forward()                                                  # :233-234
+        with chain_b():
+            gB.forward()                                              # :223 and :227
+            self._copy(fx.out_view(), cy.xin.view(0, Cc)); self._copy(fx.out_view(), dx.xin.view(0, Cc, B, B))
+            cy.forward()                                              # :224
+            dx.forward()                                              # :230-231
+        if two:
+            self.ctx.join(main, l2)
         rx_ptr, cnt = dx.logits_view(0); fxl_ptr, _ = dx.logits_view(1)
         ry_ptr, _ = dy.logits_view(0); fyl_ptr, _ = dy.logits_view(1)
         xv, yv = fy.xin_view(), sy.xin_view()                         # typed real_x / real_y
@@ -635,6 +654,27 @@ class CycleGANStep(_StepBase):
         self._bce(ry_ptr, cnt, 1.0, 6, 0.5, False, 0.5, dy.dlogits_ptr(0))                # disc_y_loss :247
         self._bce(fyl_ptr, cnt, 0.0, 6, 0.5, True, 0.5, dy.dlogits_ptr(1))
         if training:
+            if two:
+                # A: cycle_x through G_f, then G_g's own backward, then D_y;  B: cycle_y through G_g, G_f's backward, D_x.  The
+                # second backward of each generator ACCUMULATES onto what the other chain's first one wrote: one cross-wait.
+                l2.wait_stream(main)
+                cx.backward(need_dx=True, accumulate=False)           # G_f grads (cycle_x), d/d fake_y
+                dy.backward_input(1, dst=fy.dgen_view())              # adversarial term through D_y(fake_y)
+                self._copy(cx.dxin.view(0, Cc), fy.dgen_view(second=True))
+                with chain_b():
+                    cy.backward(need_dx=True, accumulate=False)       # G_g grads (cycle_y), d/d fake_x
+                    dx.backward_input(1, dst=fx.dgen_view())
+                    self._copy(cy.dxin.view(0, Cc), fx.dgen_view(second=True))
+                ea, eb = torch.cuda.Event(), torch.cuda.Event()
+                ea.record(main); eb.record(l2)
+                main.wait_event(eb); l2.wait_event(ea)
+                gA.backward(use_dgen2=True, accumulate=True)          # G_g
+                dy.backward_params()
+                with chain_b():
+                    gB.backward(use_dgen2=True, accumulate=True)      # G_f
+                    dx.backward_params()
+                self.ctx.join(main, l2)
+                return self.losses
             cx.backward(need_dx=True, accumulate=False)               # G_f grads (cycle_x), d/d fake_y
             cy.backward(need_dx=True, accumulate=False)               # G_g grads (cycle_y), d/d fake_x
             dy.backward_input(1, dst=fy.dgen_view())                  # adversarial term through D_y(fake_y)
