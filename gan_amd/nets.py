@@ -80,7 +80,8 @@ class Ctx:
         # feed Adam, so they run beside the dgrad/norm chain); lane 2 / 3 = a second chain (discriminator
         # parameter-gradient pass beside the generator backward) and its wgrad side stream.  Each lane has its
         # own workspace (split-K slabs / reduction partials).
-        self.ws_lanes = [torch.empty(workspace_mb << 20, dtype=torch.uint8, device=self.device) for _ in range(4)]
+        # (workspaces 4..7: parameter-gradient passes of the discriminators in the two-chain CycleGAN schedule)
+        self.ws_lanes = [torch.empty(workspace_mb << 20, dtype=torch.uint8, device=self.device) for _ in range(8)]
         self.ws = self.ws_lanes[0]
         self.ws_ptr, self.ws_bytes = self.ws.data_ptr(), self.ws.numel()
         self.side = [LaneStream(device=self.device) for _ in range(4)]     # lanes 1..4 (4: early optimiser step)

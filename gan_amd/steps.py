@@ -498,6 +498,8 @@ class Pix2PixStep(_StepBase):
 class CycleGANStep(_StepBase):
     ddp_buckets = False
     two_chains = True            # one-GPU step: the G_g-side and the G_f-side chains on two lanes (_forward_backward_merged)
+    early_adam = True            # ... and every network's Adam where its gradients complete, inside the chains
+XX
 
     def __init__(self, ctx: Ctx, batch, size, channels=1, lam=10.0, lr=2e-4, beta_1=0.5, beta_2=0.999,
                  seed=123, dropout=True, nets=None, mask_stream=0, merged=True):
@@ -528,8 +530,9 @@ class CycleGANStep(_StepBase):
             self.fy, self.fx = mk(self.Gg, 0), mk(self.Gf, 2)  # fake_y = G_g(x); fake_x = G_f(y)
             self.sx, self.sy = mk(self.Gf, 4), mk(self.Gg, 5)  # same_x = G_f(x); same_y = G_g(y)
         if self.merged:
-            self.dx = self.Dx.new_call(batch, size, calls=2, lane=2, params_lane=2)       # D_x(real_x) ++ D_x(fake_x): chain B
-            self.dy = self.Dy.new_call(batch, size, calls=2, lane=0, params_lane=0)
+            # (own workspaces for the parameter passes: they run beside the generators' wgrad lanes)
+            self.dx = self.Dx.new_call(batch, size, calls=2, lane=2, params_lane=6)       # D_x(real_x) ++ D_x(fake_x): chain B
+            self.dy = self.Dy.new_call(batch, size, calls=2, lane=0, params_lane=4)
         else:
             self.dx = self.Dx.new_call(batch, size, calls=2)
             self.dy = self.Dy.new_call(batch, size, calls=2)
@@ -655,9 +658,35 @@ class CycleGANStep(_StepBase):
         self._bce(fyl_ptr, cnt, 0.0, 6, 0.5, True, 0.5, dy.dlogits_ptr(1))
         if training:
             if two:
-                # A: cycle_x through G_f, then G_g's own backward, then D_y;  B: cycle_y through G_g, G_f's backward, D_x.  The
-                # second backward of each generator ACCUMULATES onto what the other chain's first one wrote: one cross-wait.
+                # A: cycle_x through G_f, D_y's input gradient, then G_g's own backward and D_y's parameter pass;  B: the mirror
+                # image.  The second backward of each generator ACCUMULATES onto what the OTHER chain's first one wrote: one
+                # cross-wait.  With nothing else pending (one GPU, no loss scaling) each network's Adam runs where its gradients
+                # complete: the generators' kernel segments on lane 1 (A) / lane 3 (B) as soon as the backward pass has left
+                # them (HBM-bound, beside the launch-bound rest of the pass), the discriminators' after their parameter pass.
+                fused_adam = bool(getattr(self, '_updating', False) and self.sync is None and self.ctx.ls is None and self.early_adam)
                 l2.wait_stream(main)
+
+                def second_backward(call, net, delay):
+                    """call.backward(use_dgen2, accumulate) with the Adam step of a kernel segment (decoder | down7..4 | down3..0)
+                    enqueued on the chain itself `delay` stages after its last wgrad GEMM: HBM-bound work of one chain beside
+                    the launch-bound kernels of the other (side lanes forked from lane 2 end the capture with "unjoined work"
+                    on this runtime, and wgrad GEMMs on side lanes lose here: measured, profiles/r03_experiments_not_kept.txt)."""
+                    if not fused_adam:
+                        call.backward(use_dgen2=True, accumulate=True)
+                        return
+                    P = net.params
+                    if P._segments is None or len(P._segments) != 3:
+                        P.split_kernels_at('down4.kernel', 'up0.kernel')
+                    adam = lambda k: self.ctx.run((P.adam_begin_ops(self.lr, self.b1, self.b2) if k == 0 else []) +
+                                                  P.adam_segment_ops(2 - k, self.b1, self.b2, vectors=False))
+                    stages = call.bwd_stages([8, 12], use_dgen2=True, accumulate=True)
+                    for k, (ops, wops) in enumerate(stages):
+                        self.ctx.run(ops + wops)
+                        if k - delay >= 0:
+                            adam(k - delay)
+                    for k in range(max(len(stages) - delay, 0), len(stages)):
+                        adam(k)
+
                 cx.backward(need_dx=True, accumulate=False)           # G_f grads (cycle_x), d/d fake_y
                 dy.backward_input(1, dst=fy.dgen_view())              # adversarial term through D_y(fake_y)
                 self._copy(cx.dxin.view(0, Cc), fy.dgen_view(second=True))
@@ -668,11 +697,19 @@ class CycleGANStep(_StepBase):
                 ea, eb = torch.cuda.Event(), torch.cuda.Event()
                 ea.record(main); eb.record(l2)
                 main.wait_event(eb); l2.wait_event(ea)
-                gA.backward(use_dgen2=True, accumulate=True)          # G_g
+                second_backward(gA, self.Gg, self.adam_delay[0])      # G_g
                 dy.backward_params()
+                if fused_adam:
+                    self.Dy.params.adam(self.lr, self.b1, self.b2, stream=main)
+                    self.ctx.run(self.Gg.params.adam_segment_ops(0, self.b1, self.b2, vectors=True, kernels=False))
                 with chain_b():
-                    gB.backward(use_dgen2=True, accumulate=True)      # G_f
+                    second_backward(gB, self.Gf, self.adam_delay[1])      # G_f
                     dx.backward_params()
+                    if fused_adam:
+                        self.Dx.params.adam(self.lr, self.b1, self.b2, stream=l2)
+                        self.ctx.run(self.Gf.params.adam_segment_ops(0, self.b1, self.b2, vectors=True, kernels=False))
+                if fused_adam:
+                    self._adam_done = self.nets()
                 self.ctx.join(main, l2)
                 return self.losses
             cx.backward(need_dx=True, accumulate=False)               # G_f grads (cycle_x), d/d fake_y
