@@ -499,7 +499,7 @@ class CycleGANStep(_StepBase):
     ddp_buckets = False
     two_chains = True            # one-GPU step: the G_g-side and the G_f-side chains on two lanes (_forward_backward_merged)
     early_adam = True            # ... and every network's Adam where its gradients complete, inside the chains
-XX
+    adam_delay = (0, 0)          # ... stages by which chain A / B hold a segment's Adam back (measured: no offset is best)
 
     def __init__(self, ctx: Ctx, batch, size, channels=1, lam=10.0, lr=2e-4, beta_1=0.5, beta_2=0.999,
                  seed=123, dropout=True, nets=None, mask_stream=0, merged=True):
