@@ -279,13 +279,21 @@ def parse_object_graph(blob):
 
 
 # ---- bundle ----------------------------------------------------------------------------------------------------------
-def _string_tensor_bytes(values):
-    """DT_STRING tensor data: [varint64 length]... [fixed32 masked crc32c of the lengths as uint64s] [bytes]...; the entry's
-    checksum runs over the uint64 lengths, the 4 checksum bytes and the string bytes."""
-    lens = b''.join(_varint(len(v)) for v in values)
+def _string_lengths_crc(lengths):
+    """Running crc32c over the element lengths as TensorFlow's WriteStringTensor extends it (tensor_bundle.cc): a length that
+    fits 32 bits enters as a little-endian uint32 (kept for files written before 64-bit lengths existed), a longer one as a
+    uint64 - NOT the varint bytes that are stored."""
     crc = 0
-    for v in values:
-        crc = _crc32c(struct.pack('<Q', len(v)), crc)
+    for ln in lengths:
+        crc = _crc32c(struct.pack('<I', ln) if ln <= 0xffffffff else struct.pack('<Q', ln), crc)
+    return crc
+
+
+def _string_tensor_bytes(values):
+    """DT_STRING tensor data: [varint64 length]... [fixed32 masked crc32c of the lengths] [bytes]...; the entry's checksum
+    keeps running from the length crc over the 4 stored checksum bytes and then the string bytes."""
+    lens = b''.join(_varint(len(v)) for v in values)
+    crc = _string_lengths_crc(len(v) for v in values)
     chk = struct.pack('<I', _mask(crc))
     crc = _crc32c(chk, crc)
     for v in values:
@@ -338,11 +346,19 @@ def read_bundle(prefix, verify=True):
             for _ in range(n):
                 ln, pos = _read_varint(raw, pos)
                 lens.append(ln)
+            crc = _string_lengths_crc(lens)
+            stored = raw[pos:pos + 4]
+            if verify and (len(stored) != 4 or struct.unpack('<I', stored)[0] != _mask(crc)):
+                raise ValueError(f"{key}: string-length checksum mismatch")
+            crc = _crc32c(stored, crc)
             pos += 4
             vals = []
             for ln in lens:
                 vals.append(raw[pos:pos + ln])
                 pos += ln
+                crc = _crc32c(vals[-1], crc)
+            if verify and (pos != len(raw) or _unmask(f.get(6, 0)) != crc):
+                raise ValueError(f"{key}: tensor checksum mismatch")
             if key == OBJECT_GRAPH_KEY:
                 graph = vals[0]
             continue

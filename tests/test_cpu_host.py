@@ -332,6 +332,48 @@ def test_tensorbundle_container_structure_and_roundtrip(tmp_path):
         TB.read_table(str(tmp_path / 'bad.index'))
 
 
+def test_tensorbundle_string_tensor_checksum_golden(tmp_path):
+    """DT_STRING entries (the object graph): TensorFlow's WriteStringTensor (tensor_bundle.cc) extends the checksum with each
+    element length as a little-endian uint32 when it fits 32 bits (uint64 only beyond), stores the masked length crc after the
+    varint lengths and keeps the SAME running crc over those 4 bytes and the string bytes.  Golden bytes below were derived
+    with an independent bit-by-bit CRC-32C (polynomial 0x82F63B78), not with tfbundle's table-driven one."""
+    import struct
+    from gan_amd import tfbundle as TB
+
+    def crc_bitwise(data, crc=0):
+        crc ^= 0xffffffff
+        for b in data:
+            crc ^= b
+            for _ in range(8):
+                crc = (crc >> 1) ^ (0x82F63B78 if crc & 1 else 0)
+        return crc ^ 0xffffffff
+    vals = [b'ab', b'c' * 300]
+    blob, crc = TB._string_tensor_bytes(vals)
+    assert blob[:3] == bytes([0x02, 0xac, 0x02])                                   # varint lengths 2, 300
+    assert blob[3:7] == bytes.fromhex('7dadccda')                                  # mask(crc32c(u32(2) ++ u32(300))) little-endian
+    assert blob[7:] == b'ab' + b'c' * 300 and len(blob) == 309
+    assert crc == 0xef56a1ce and TB._mask(crc) == 0xe620c985                       # entry checksum (BundleEntryProto.crc32c, masked)
+    lc = crc_bitwise(struct.pack('<I', 2) + struct.pack('<I', 300))
+    assert lc == 0xe1529c24 and TB._string_lengths_crc([2, 300]) == lc
+    assert crc_bitwise(struct.pack('<Q', 2) + struct.pack('<Q', 300)) == 0xa5a13801 != lc      # the uint64 convention differs
+    assert TB._string_lengths_crc([1 << 32]) == crc_bitwise(struct.pack('<Q', 1 << 32))        # > 32 bits: uint64
+    # the reader verifies both checksums of the object-graph entry
+    prefix = str(tmp_path / 'ckpt-1')
+    names = {'a/.ATTRIBUTES/VARIABLE_VALUE': 'a'}
+    TB.write_bundle(prefix, {'a/.ATTRIBUTES/VARIABLE_VALUE': np.zeros(4, np.float32)}, TB.object_graph(names, []))
+    _, graph = TB.read_bundle(prefix)
+    assert graph and TB.parse_object_graph(graph)[0]['children'] == {'a': 1}
+    data = bytearray(open(prefix + '.data-00000-of-00001', 'rb').read())
+    for pos, what in ((len(data) - 1, "tensor checksum"), (16 + 1 + 1, "string-length checksum")):     # a string byte; a length-crc byte
+        bad = bytearray(data)
+        bad[pos] ^= 0x40
+        open(prefix + '.data-00000-of-00001', 'wb').write(bad)
+        with pytest.raises(ValueError, match=what):
+            TB.read_bundle(prefix)
+    open(prefix + '.data-00000-of-00001', 'wb').write(data)
+    assert TB.read_bundle(prefix)[1] == graph
+
+
 def test_checkpoint_keys_follow_the_keras_object_graph(tmp_path):
     """Variable naming of the reference's models under tf.train.Checkpoint (which layers are nested Sequentials, which sit
     directly in the functional model: base_gan.py:124-225), Adam slots under the variable's path, legacy (round-1 JSON)
