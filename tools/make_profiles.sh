@@ -13,6 +13,9 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o s -- pytho
 # the same with every launch on ONE stream (--single-stream): per-kernel durations without the other lanes' kernels sharing the chip
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats1 -o s1 -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --repeats 1 --no-cpu-baseline --sustain 0 --single-stream > $out/bench_single_stream_under_rocprof.json 2>> $out/bench.err
 cp $out/stats1/s1_kernel_stats.csv $out/${tag}_bench_p16_kernel_stats_single_stream.csv
+# CycleGAN 256x256 batch 1 (BASELINE.json configs[3] per-GPU shape): the two-chain schedule under the same profiler
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/statscg -o cg -- python3 $GRAFT_REPO_ROOT/bench.py --model cyclegan --batch 1 --steps 20 --warmup 5 --repeats 1 --no-cpu-baseline --sustain 0 > $out/bench_cyclegan_b1_under_rocprof.json 2>> $out/bench.err
+cp $out/statscg/cg_kernel_stats.csv $out/${tag}_bench_cyclegan_b1_kernel_stats.csv
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -o f -- $CMD > /dev/null 2>> $out/bench.err
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write -o w -- $CMD > /dev/null 2>> $out/bench.err
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU --output-format csv -d $out/sq -o q -- $CMD > /dev/null 2>> $out/bench.err
