@@ -24,16 +24,16 @@ CAPTURE_MODE = "thread_local"
 
 
 class _StepBase:
-    def _bce(self, logits_ptr, count, target, loss_idx, loss_scale, acc, grad_scale, dx_ptr):
+    def _bce(self, logits_ptr, count, target, loss_idx, loss_scale, acc, grad_scale, dx_ptr, ws=None):
         lib, ctx = self.ctx.lib, self.ctx
         rc = lib.gan_bce_logits(logits_ptr, count, target, loss_scale, int(acc), self.losses.data_ptr() + 4 * loss_idx,
-                                grad_scale, ctx.dt, dx_ptr, 8, self.bce_ws.data_ptr(), ctx.ls_ptr, ctx.stream())
+                                grad_scale, ctx.dt, dx_ptr, 8, (ws if ws is not None else self.bce_ws).data_ptr(), ctx.ls_ptr, ctx.stream())
         L.check(rc, "bce_logits")
 
-    def _l1(self, a, b, loss_idx, loss_scale, acc, grad_scale, da, stream=None):
+    def _l1(self, a, b, loss_idx, loss_scale, acc, grad_scale, da, stream=None, ws=None):
         lib, ctx = self.ctx.lib, self.ctx
         rc = lib.gan_l1(ctx.dt, C.byref(a), C.byref(b), loss_scale, int(acc), self.losses.data_ptr() + 4 * loss_idx,
-                        grad_scale, C.byref(da) if da is not None else None, self.l1_ws.data_ptr(), ctx.ls_ptr,
+                        grad_scale, C.byref(da) if da is not None else None, (ws if ws is not None else self.l1_ws).data_ptr(), ctx.ls_ptr,
                         stream.cuda_stream if stream is not None else ctx.stream())
         L.check(rc, "l1")
 
@@ -536,9 +536,11 @@ class CycleGANStep(_StepBase):
         else:
             self.dx = self.Dx.new_call(batch, size, calls=2)
             self.dy = self.Dy.new_call(batch, size, calls=2)
-        self.losses = torch.zeros(12, dtype=torch.float32, device=ctx.device)
+        self.losses = torch.zeros(12, dtype=torch.float32, device=ctx.device)     # [0..8] as below; [9] cycle term of chain B; [10] stays 0
         self.l1_ws = torch.zeros(4096, dtype=torch.float32, device=ctx.device)
         self.bce_ws = torch.zeros(1024, dtype=torch.float32, device=ctx.device)
+        self.l1_ws_b = torch.zeros(4096, dtype=torch.float32, device=ctx.device)   # chain B's loss kernels run beside chain A's
+        self.bce_ws_b = torch.zeros(1024, dtype=torch.float32, device=ctx.device)
         self.sync = None
 
     def nets(self):
@@ -627,44 +629,59 @@ class CycleGANStep(_StepBase):
         chain_b = (lambda: torch.cuda.stream(l2)) if two else contextlib.nullcontext
         self._pack_multi([(real_x, fy.xin_view()), (real_y, sy.xin_view()), (real_y, fx.xin_view()), (real_x, sx.xin_view())])
         self._pack_multi([(real_x, dx.xin.view(0, Cc, 0, B)), (real_y, dy.xin.view(0, Cc, 0, B))])
+        rx_ptr, cnt = dx.logits_view(0); fxl_ptr, _ = dx.logits_view(1)
+        ry_ptr, _ = dy.logits_view(0); fyl_ptr, _ = dy.logits_view(1)
+        xv, yv = fy.xin_view(), sy.xin_view()                         # typed real_x / real_y
+        lp = self.losses.data_ptr()
         if two:
             l2.wait_stream(main)
         gA.forward()                                                  # cycle_gan.py:220 and :228
         self._copy(fy.out_view(), cx.xin.view(0, Cc)); self._copy(fy.out_view(), dy.xin.view(0, Cc, B, B))
         cx.forward()                                                  # :221
         dy.forward()                                                  # :233-234
+        if two:
+            # each chain takes the loss terms (and their gradients) of its own outputs; only the reported totals need both
+            # chains and are summed after the final join - no join between the forward and the backward pass
+            self._bce(fyl_ptr, cnt, 1.0, 0, 1.0, False, 1.0, dy.dlogits_b.t.data_ptr())      # gen_g_loss :237
+            self._l1(cx.out_view(), xv, 2, lam, False, lam, cx.dgen.view(0, Cc))              # cycle term of x :240
+            self._l1(sy.out_view(), yv, 7, lam * 0.5, False, lam * 0.5, sy.dgen_view())       # identity :243
+            self._bce(ry_ptr, cnt, 1.0, 6, 0.5, False, 0.5, dy.dlogits_ptr(0))                # disc_y_loss :247
+            self._bce(fyl_ptr, cnt, 0.0, 6, 0.5, True, 0.5, dy.dlogits_ptr(1))
         with chain_b():
             gB.forward()                                              # :223 and :227
             self._copy(fx.out_view(), cy.xin.view(0, Cc)); self._copy(fx.out_view(), dx.xin.view(0, Cc, B, B))
             cy.forward()                                              # :224
             dx.forward()                                              # :230-231
-        if two:
+            if two:
+                wl, wb = self.l1_ws_b, self.bce_ws_b
+                self._bce(fxl_ptr, cnt, 1.0, 1, 1.0, False, 1.0, dx.dlogits_b.t.data_ptr(), ws=wb)      # gen_f_loss :238
+                self._l1(cy.out_view(), yv, 9, lam, False, lam, cy.dgen.view(0, Cc), ws=wl)              # cycle term of y
+                self._l1(sx.out_view(), xv, 8, lam * 0.5, False, lam * 0.5, sx.dgen_view(), ws=wl)       # identity :244
+                self._bce(rx_ptr, cnt, 1.0, 5, 0.5, False, 0.5, dx.dlogits_ptr(0), ws=wb)                # disc_x_loss :246
+                self._bce(fxl_ptr, cnt, 0.0, 5, 0.5, True, 0.5, dx.dlogits_ptr(1), ws=wb)
+        if not two:
+            self._bce(fyl_ptr, cnt, 1.0, 0, 1.0, False, 1.0, dy.dlogits_b.t.data_ptr())      # gen_g_loss :237
+            self._bce(fxl_ptr, cnt, 1.0, 1, 1.0, False, 1.0, dx.dlogits_b.t.data_ptr())      # gen_f_loss :238
+            self._l1(cx.out_view(), xv, 2, lam, False, lam, cx.dgen.view(0, Cc))              # total_cycle_loss :240
+            self._l1(cy.out_view(), yv, 2, lam, True, lam, cy.dgen.view(0, Cc))
+            self._l1(sy.out_view(), yv, 7, lam * 0.5, False, lam * 0.5, sy.dgen_view())       # identity :243
+            self._l1(sx.out_view(), xv, 8, lam * 0.5, False, lam * 0.5, sx.dgen_view())       # identity :244
+            self._totals(False)
+            self._bce(rx_ptr, cnt, 1.0, 5, 0.5, False, 0.5, dx.dlogits_ptr(0))                # disc_x_loss :246
+            self._bce(fxl_ptr, cnt, 0.0, 5, 0.5, True, 0.5, dx.dlogits_ptr(1))
+            self._bce(ry_ptr, cnt, 1.0, 6, 0.5, False, 0.5, dy.dlogits_ptr(0))                # disc_y_loss :247
+            self._bce(fyl_ptr, cnt, 0.0, 6, 0.5, True, 0.5, dy.dlogits_ptr(1))
+        elif not training:
             self.ctx.join(main, l2)
-        rx_ptr, cnt = dx.logits_view(0); fxl_ptr, _ = dx.logits_view(1)
-        ry_ptr, _ = dy.logits_view(0); fyl_ptr, _ = dy.logits_view(1)
-        xv, yv = fy.xin_view(), sy.xin_view()                         # typed real_x / real_y
-        self._bce(fyl_ptr, cnt, 1.0, 0, 1.0, False, 1.0, dy.dlogits_b.t.data_ptr())      # gen_g_loss :237
-        self._bce(fxl_ptr, cnt, 1.0, 1, 1.0, False, 1.0, dx.dlogits_b.t.data_ptr())      # gen_f_loss :238
-        self._l1(cx.out_view(), xv, 2, lam, False, lam, cx.dgen.view(0, Cc))              # total_cycle_loss :240
-        self._l1(cy.out_view(), yv, 2, lam, True, lam, cy.dgen.view(0, Cc))
-        self._l1(sy.out_view(), yv, 7, lam * 0.5, False, lam * 0.5, sy.dgen_view())       # identity :243
-        self._l1(sx.out_view(), xv, 8, lam * 0.5, False, lam * 0.5, sx.dgen_view())       # identity :244
-        lp = self.losses.data_ptr()
-        L.check(self.ctx.lib.gan_sum3(lp, lp + 8, lp + 28, lp + 12, 1, self.ctx.stream()), "sum3")
-        L.check(self.ctx.lib.gan_sum3(lp + 4, lp + 8, lp + 32, lp + 16, 1, self.ctx.stream()), "sum3")
-        self._bce(rx_ptr, cnt, 1.0, 5, 0.5, False, 0.5, dx.dlogits_ptr(0))                # disc_x_loss :246
-        self._bce(fxl_ptr, cnt, 0.0, 5, 0.5, True, 0.5, dx.dlogits_ptr(1))
-        self._bce(ry_ptr, cnt, 1.0, 6, 0.5, False, 0.5, dy.dlogits_ptr(0))                # disc_y_loss :247
-        self._bce(fyl_ptr, cnt, 0.0, 6, 0.5, True, 0.5, dy.dlogits_ptr(1))
+            self._totals(True)
         if training:
             if two:
                 # A: cycle_x through G_f, D_y's input gradient, then G_g's own backward and D_y's parameter pass;  B: the mirror
                 # image.  The second backward of each generator ACCUMULATES onto what the OTHER chain's first one wrote: one
                 # cross-wait.  With nothing else pending (one GPU, no loss scaling) each network's Adam runs where its gradients
-                # complete: the generators' kernel segments on lane 1 (A) / lane 3 (B) as soon as the backward pass has left
-                # them (HBM-bound, beside the launch-bound rest of the pass), the discriminators' after their parameter pass.
+                # complete: the generators' kernel segments inside their chain as soon as the backward pass has left them
+                # (HBM-bound, beside the other chain's launch-bound kernels), the discriminators' after their parameter pass.
                 fused_adam = bool(getattr(self, '_updating', False) and self.sync is None and self.ctx.ls is None and self.early_adam)
-                l2.wait_stream(main)
 
                 def second_backward(call, net, delay):
                     """call.backward(use_dgen2, accumulate) with the Adam step of a kernel segment (decoder | down7..4 | down3..0)
@@ -711,6 +728,7 @@ class CycleGANStep(_StepBase):
                 if fused_adam:
                     self._adam_done = self.nets()
                 self.ctx.join(main, l2)
+                self._totals(True)
                 return self.losses
             cx.backward(need_dx=True, accumulate=False)               # G_f grads (cycle_x), d/d fake_y
             cy.backward(need_dx=True, accumulate=False)               # G_g grads (cycle_y), d/d fake_x
@@ -727,6 +745,15 @@ class CycleGANStep(_StepBase):
             if phase != 1:
                 dx.backward_params(); dy.backward_params()
         return self.losses
+
+    def _totals(self, split_cycle):
+        """total_cycle_loss and total_gen_g / total_gen_f (cycle_gan.py:240-244): [3] = [0] + [2] + [7], [4] = [1] + [2] + [8];
+        split_cycle: the two chains left the cycle terms of x and y in [2] and [9] ([10] is never written: 0)."""
+        lp, lib, st_ = self.losses.data_ptr(), self.ctx.lib, self.ctx.stream()
+        if split_cycle:
+            L.check(lib.gan_sum3(lp + 8, lp + 36, lp + 40, lp + 8, 1, st_), "sum3")         # [2] += [9]
+        L.check(lib.gan_sum3(lp, lp + 8, lp + 28, lp + 12, 1, st_), "sum3")
+        L.check(lib.gan_sum3(lp + 4, lp + 8, lp + 32, lp + 16, 1, st_), "sum3")
 
     def train_step(self, real_x, real_y, training=True):
         """7 losses in the reference's order (cycle_gan.py:275-276)."""
