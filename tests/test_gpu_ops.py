@@ -824,7 +824,12 @@ def test_bad_arguments_return_codes(ctx):
     if ctx.dtype == 'bf16':
         xt, yt = Buf(ctx, 1, 8, 8, 128), Buf(ctx, 1, 16, 16, 8)
         dt_ = L.GanConvDesc(ctx.dt, 2, xt.view(), yt.view(0, 1), ws_.data_ptr(), 1, None, 0, 0.3, 0, None, 0)
-        assert ctx.lib.gan_convT2d_fwd(C.byref(dt_), ctx.stream()) == -3
+        L.set_option('conv.thin_fused', 0)          # the two-launch thin-N path keeps its per-tap products in the workspace
+        try:
+            assert ctx.lib.gan_convT2d_fwd(C.byref(dt_), ctx.stream()) == -3
+        finally:
+            L.set_option('conv.thin_fused', 1)
+        assert ctx.lib.gan_convT2d_fwd(C.byref(dt_), ctx.stream()) == 0         # fused (default): they stay in LDS, no workspace
     torch.cuda.synchronize()
 
 
