@@ -126,9 +126,23 @@ class Ctx:
 class Buf:
     """Zero-initialised NHWC device buffer; view() makes a GanTensor channel/batch slice."""
 
+    parent = None      # the wider buffer this one is a batch slice of (Buf.slice_of)
+
     def __init__(self, ctx, n, h, w, c, tdtype=None):
         self.n, self.h, self.w, self.c = n, h, w, c
         self.t = torch.zeros((n, h, w, c), dtype=tdtype or ctx.tdtype, device=ctx.device)
+
+    @classmethod
+    def slice_of(cls, big, n0, n):
+        """Samples [n0, n0 + n) of `big` as a buffer of its own (same storage; .parent = big)."""
+        b = cls.__new__(cls)
+        b.n, b.h, b.w, b.c = n, big.h, big.w, big.c
+        b.t = big.t[n0:n0 + n]
+        b.parent = big
+        return b
+
+    def wide(self):
+        return self.parent if self.parent is not None else self
 
     def view(self, c0=0, c=None, n0=0, n=None):
         c = self.c - c0 if c is None else c
@@ -506,19 +520,38 @@ class GeneratorNet:
         self.params = ParamSet(ctx, self.spec)
         self.params.load_numpy(init_params_numpy(self.spec, seed))
 
-    def new_call(self, batch, size, dropout=True, seed=1234, stream_id=0, wgrads_on_side_lane=False, lane=0):
+    def new_call(self, batch, size, dropout=True, seed=1234, stream_id=0, wgrads_on_side_lane=False, lane=0, guest_batch=0, host=None):
         """wgrads_on_side_lane: this call's kernel-gradient GEMMs run on a side lane of a captured step beside the dgrad chain
         (GanWgradDesc.concurrent: the planner prefers half-chip grids with longer reductions).  lane: whose workspace the call's
-        launches use (0 | 2): calls that may run at the same time must not share one."""
-        return GenCall(self, batch, size, dropout, seed, stream_id, wgrads_on_side_lane, lane)
+        launches use (0 | 2): calls that may run at the same time must not share one.
+        guest_batch / host: two invocations of one generator whose kernel gradients are taken by ONE wgrad GEMM per layer over
+        both (CycleGAN: no write + accumulate pair): the host call allocates every saved tensor `guest_batch` samples wider and
+        the guest call (host=that call) lives in those extra samples; host.backward(wgrads='wide') then covers both."""
+        return GenCall(self, batch, size, dropout, seed, stream_id, wgrads_on_side_lane, lane, guest_batch, host)
 
 
 class GenCall:
     """Buffers + op lists for one invocation `generator(x, training=True)` and its backward."""
 
-    def __init__(self, net, B, S, dropout, seed, stream_id, wgrads_on_side_lane=False, lane=0):
+    def __init__(self, net, B, S, dropout, seed, stream_id, wgrads_on_side_lane=False, lane=0, guest_batch=0, host=None):
         ctx, P = net.ctx, net.params
         self.net, self.ctx, self.B, self.S, self.C = net, ctx, B, S, net.channels
+        self.guest_batch, self.host, self._pool, self._pool_i = int(guest_batch), host, [], 0
+        if host is not None and (host.guest_batch != B or host.net is not net or host.S != S):
+            raise ValueError("guest call: batch / network / size must match what the host call reserved")
+
+        def Buf(ctx_, n_, h_, w_, c_, tdtype=None, _B=globals()['Buf']):
+            """Saved tensors: plain buffers, or batch slices of buffers shared by a host call and its guest (same creation order)."""
+            if host is not None:
+                big = host._pool[self._pool_i]
+                self._pool_i += 1
+                assert (big.h, big.w, big.c) == (h_, w_, c_) and big.n == host.B + n_
+                return _B.slice_of(big, host.B, n_)
+            if self.guest_batch:
+                big = _B(ctx_, n_ + self.guest_batch, h_, w_, c_, tdtype)
+                self._pool.append(big)
+                return _B.slice_of(big, 0, n_)
+            return _B(ctx_, n_, h_, w_, c_, tdtype)
         bd = _Builder(ctx, P, net.norm, lane=lane)
         bd.wgrad_concurrent = bool(wgrads_on_side_lane)
         self._bd = bd
@@ -608,15 +641,26 @@ class GenCall:
         self.dxin = Buf(ctx, B, S, S, 8)
         self._bwd_cache = {}
 
-    def _build_bwd(self, use_dgen2, need_dx, accumulate):
-        """Backward op list.  Wherever the launch shape allows it, the dgrad that produces the gradient w.r.t. a layer's
+    def _build_bwd(self, use_dgen2, need_dx, accumulate, wgrads='own'):
+        """wgrads: 'own' - this call's kernel gradients (accumulate as the other gradients do); 'none' - a guest call whose host
+        takes them; 'wide' - a host call: one wgrad GEMM per layer over its own AND its guest's samples, plain write (the guest's
+        saved activations and output gradients must be in place: its forward and its backward(wgrads='none') have run).
+        Backward op list.  Wherever the launch shape allows it, the dgrad that produces the gradient w.r.t. a layer's
         activation starts that layer's backward in its epilogue (dz + partial sums; `fused` = chunk count) and the layer is
         finished by finalize + apply; otherwise the three-launch normalisation backward / act_bwd follows."""
         bd, P, C_, groups = self._bd, self.net.params, self.C, self.groups
+        if wgrads == 'wide' and not self.guest_batch:
+            raise ValueError("wgrads='wide' needs a host call (guest_batch > 0)")
+        W = (lambda b_: b_.wide()) if wgrads == 'wide' else (lambda b_: b_)
+        wacc = accumulate and wgrads != 'wide'
+
+        def wgrad(*a_):
+            if wgrads != 'none':
+                ops.append(bd.wgrad(*a_, wacc))
         ops = []
         ops.append(bd.act_bwd(self.out.view(), self.dgen.view(), self.dgen2.view() if use_dgen2 else None,
                               self.dpre.view(), 'tanh'))
-        ops.append(bd.wgrad(self.dpre.view(), self.cat[6].view(), P.ptr('last.kernel', 'grad'), C_, 128, 2, accumulate))
+        wgrad(W(self.dpre).view(), W(self.cat[6]).view(), P.ptr('last.kernel', 'grad'), C_, 128, 2)
         ops.append(bd.bias_grad(self.dpre.view(), P.ptr('last.bias', 'grad'), accumulate))
 
         def up_spec(j):         # backward of up j (ReLU [+ dropout] after the norm) on the leading G_UP[j] channels of dcat[j]
@@ -643,7 +687,7 @@ class GenCall:
             xin = self.a7 if j == 0 else self.cat[j - 1]
             dxin = self.da7 if j == 0 else self.dcat[j - 1]
             cin = xin.c
-            ops.append(bd.wgrad(self.dy_up[j].view(), xin.view(), P.ptr(name + '.kernel', 'grad'), G_UP[j], cin, 2, accumulate))
+            wgrad(W(self.dy_up[j]).view(), W(xin).view(), P.ptr(name + '.kernel', 'grad'), G_UP[j], cin, 2)
             if j > 0:
                 spec, nfz = up_spec(j - 1), bd.bwd_norm_fuse(f'up{j - 1}', self.dy_up[j - 1].view(), True, accumulate)
             else:               # da7: gradient w.r.t. the bottleneck activation = down7's backward
@@ -679,13 +723,14 @@ class GenCall:
                                            mean.data_ptr(), rstd.data_ptr(), 'lrelu', None, True, accumulate))
             dyi = dy0 if i == 0 else self.dy_down[i]
             if i == 0:
-                xin, cin_real = self.xin.view(), C_
+                xin, cin_real = W(self.xin).view(), C_
+                self.dy0_in_dA = dy0 is self.dA[0]        # (host and guest must agree on where down0's output gradient lives)
             elif i == 1:
-                xin, cin_real = self.cat[6].view(G_UP[6], 64), 64
+                xin, cin_real = W(self.cat[6]).view(G_UP[6], 64), 64
             else:
                 jj = 6 - (i - 1)
-                xin, cin_real = self.cat[jj].view(G_UP[jj], G_DOWN[i - 1]), G_DOWN[i - 1]
-            ops.append(bd.wgrad(xin, dyi.view(), P.ptr(name + '.kernel', 'grad'), cin_real, G_DOWN[i], 2, accumulate))
+                xin, cin_real = W(self.cat[jj]).view(G_UP[jj], G_DOWN[i - 1]), G_DOWN[i - 1]
+            wgrad(xin, W(dyi).view(), P.ptr(name + '.kernel', 'grad'), cin_real, G_DOWN[i], 2)
             fused, full = 0, False
             if i > 0:
                 jb = 6 - (i - 1)                                     # layer below: down i-1, its skip gradient sits in dcat[jb]
@@ -740,9 +785,9 @@ class GenCall:
         """Samples [n0, n0 + n) of this call as a call-like object (CycleGAN batches two logical calls of one generator)."""
         return CallSlice(self, n0, n)
 
-    def backward(self, use_dgen2=False, need_dx=False, accumulate=False, defer_wgrads=False):
-        """Upstream gradient(s) w.r.t. the tanh output must be in self.dgen (and self.dgen2)."""
-        key = (use_dgen2, need_dx, accumulate)
+    def backward(self, use_dgen2=False, need_dx=False, accumulate=False, defer_wgrads=False, wgrads='own'):
+        """Upstream gradient(s) w.r.t. the tanh output must be in self.dgen (and self.dgen2).  wgrads: see _build_bwd."""
+        key = (use_dgen2, need_dx, accumulate) if wgrads == 'own' else (use_dgen2, need_dx, accumulate, wgrads)
         if key not in self._bwd_cache:
             self._bwd_cache[key] = self._build_bwd(*key)
         ops = self._bwd_cache[key]
@@ -763,11 +808,18 @@ class GenCall:
         else:
             self.ctx.run(ops)
 
-    def bwd_stages(self, cuts, use_dgen2=False, need_dx=False, accumulate=False):
+    def bwd_ops(self, use_dgen2=False, need_dx=False, accumulate=False, wgrads='own'):
+        """The (cached) backward op list; building it also settles self.dy0_in_dA."""
+        key = (use_dgen2, need_dx, accumulate) if wgrads == 'own' else (use_dgen2, need_dx, accumulate, wgrads)
+        if key not in self._bwd_cache:
+            self._bwd_cache[key] = self._build_bwd(*key)
+        return self._bwd_cache[key]
+
+    def bwd_stages(self, cuts, use_dgen2=False, need_dx=False, accumulate=False, wgrads='own'):
         """The backward op list cut into coarse stages at the wgrad indices `cuts` (the same cuts as the 'staged'
         mode): [(main-chain ops, wgrad ops)] per stage.  The wgrad GEMMs of a stage only feed Adam, so a caller may
         run them beside the NEXT stage's main chain (gan_amd/steps.py data-parallel schedule)."""
-        key = (use_dgen2, need_dx, accumulate)
+        key = (use_dgen2, need_dx, accumulate) if wgrads == 'own' else (use_dgen2, need_dx, accumulate, wgrads)
         if key not in self._bwd_cache:
             self._bwd_cache[key] = self._build_bwd(*key)
         ops = self._bwd_cache[key]

@@ -499,6 +499,7 @@ class CycleGANStep(_StepBase):
     ddp_buckets = False
     two_chains = True            # one-GPU step: the G_g-side and the G_f-side chains on two lanes (_forward_backward_merged)
     early_adam = True            # ... and every network's Adam where its gradients complete, inside the chains
+    wide_wgrads = True           # ... one wgrad GEMM per layer over a generator's three invocations (host + guest call)
     adam_delay = (0, 0)          # ... stages by which chain A / B hold a segment's Adam back (measured: no offset is best)
 
     def __init__(self, ctx: Ctx, batch, size, channels=1, lam=10.0, lr=2e-4, beta_1=0.5, beta_2=0.999,
@@ -520,10 +521,17 @@ class CycleGANStep(_StepBase):
         # Measured +30 % (B=1) ... +15 % (B=16) pairs/s; merged=False keeps the six separate calls (equivalence test, A/B runs).
         self.merged = bool(merged)
         # chain "A" (lane 0 workspaces): G_g([x ; y]) -> G_f(fake_y) -> D_y;  chain "B" (lane 2): G_f([y ; x]) -> G_g(fake_x) -> D_x
-        self.cx, self.cy = mk(self.Gf, 1), mk(self.Gg, 3, 2 if self.merged else 0)      # cycled_x = G_f(fake_y); cycled_y = G_g(fake_x)
         if self.merged:
-            self.gA = self.Gg.new_call(2 * batch, size, dropout=dropout, seed=seed, stream_id=mask_stream + 0)   # [fake_y ; same_y]
-            self.gB = self.Gf.new_call(2 * batch, size, dropout=dropout, seed=seed, stream_id=mask_stream + 2, lane=2)   # [fake_x ; same_x]
+            # the cycle call of a generator is the GUEST of its batched call (shared, wider saved tensors): one wgrad GEMM per
+            # layer then covers all three invocations of the generator instead of a write + accumulate pair
+            self.gA = self.Gg.new_call(2 * batch, size, dropout=dropout, seed=seed, stream_id=mask_stream + 0, guest_batch=batch)   # [fake_y ; same_y]
+            self.gB = self.Gf.new_call(2 * batch, size, dropout=dropout, seed=seed, stream_id=mask_stream + 2, lane=2, guest_batch=batch)   # [fake_x ; same_x]
+            mkc = lambda net, sid, lane, host: net.new_call(batch, size, dropout=dropout, seed=seed, stream_id=mask_stream + sid, lane=lane, host=host)
+            self.cx, self.cy = mkc(self.Gf, 1, 0, self.gB), mkc(self.Gg, 3, 2, self.gA)      # cycled_x = G_f(fake_y); cycled_y = G_g(fake_x)
+        else:
+            self.cx, self.cy = mk(self.Gf, 1), mk(self.Gg, 3)
+        self._wide = None
+        if self.merged:
             self.fy, self.sy = self.gA.half(0, batch), self.gA.half(batch, batch)
             self.fx, self.sx = self.gB.half(0, batch), self.gB.half(batch, batch)
         else:
@@ -683,20 +691,26 @@ class CycleGANStep(_StepBase):
                 # (HBM-bound, beside the other chain's launch-bound kernels), the discriminators' after their parameter pass.
                 fused_adam = bool(getattr(self, '_updating', False) and self.sync is None and self.ctx.ls is None and self.early_adam)
 
+                if self._wide is None:       # host and guest must keep down0's output gradient in the same buffer (plan dependent)
+                    self._wide = all(h.bwd_ops(True, False, True, 'wide') is not None and g_.bwd_ops(False, True, False, 'none') is not None
+                                     and h.dy0_in_dA == g_.dy0_in_dA for h, g_ in ((gA, cy), (gB, cx)))
+                wide = self._wide and self.wide_wgrads
+                w1, w2 = ('none', 'wide') if wide else ('own', 'own')
+
                 def second_backward(call, net, delay):
                     """call.backward(use_dgen2, accumulate) with the Adam step of a kernel segment (decoder | down7..4 | down3..0)
                     enqueued on the chain itself `delay` stages after its last wgrad GEMM: HBM-bound work of one chain beside
                     the launch-bound kernels of the other (side lanes forked from lane 2 end the capture with "unjoined work"
                     on this runtime, and wgrad GEMMs on side lanes lose here: measured, profiles/r03_experiments_not_kept.txt)."""
                     if not fused_adam:
-                        call.backward(use_dgen2=True, accumulate=True)
+                        call.backward(use_dgen2=True, accumulate=True, wgrads=w2)
                         return
                     P = net.params
                     if P._segments is None or len(P._segments) != 3:
                         P.split_kernels_at('down4.kernel', 'up0.kernel')
                     adam = lambda k: self.ctx.run((P.adam_begin_ops(self.lr, self.b1, self.b2) if k == 0 else []) +
                                                   P.adam_segment_ops(2 - k, self.b1, self.b2, vectors=False))
-                    stages = call.bwd_stages([8, 12], use_dgen2=True, accumulate=True)
+                    stages = call.bwd_stages([8, 12], use_dgen2=True, accumulate=True, wgrads=w2)
                     for k, (ops, wops) in enumerate(stages):
                         self.ctx.run(ops + wops)
                         if k - delay >= 0:
@@ -704,11 +718,11 @@ class CycleGANStep(_StepBase):
                     for k in range(max(len(stages) - delay, 0), len(stages)):
                         adam(k)
 
-                cx.backward(need_dx=True, accumulate=False)           # G_f grads (cycle_x), d/d fake_y
+                cx.backward(need_dx=True, accumulate=False, wgrads=w1)    # G_f grads (cycle_x), d/d fake_y
                 dy.backward_input(1, dst=fy.dgen_view())              # adversarial term through D_y(fake_y)
                 self._copy(cx.dxin.view(0, Cc), fy.dgen_view(second=True))
                 with chain_b():
-                    cy.backward(need_dx=True, accumulate=False)       # G_g grads (cycle_y), d/d fake_x
+                    cy.backward(need_dx=True, accumulate=False, wgrads=w1)    # G_g grads (cycle_y), d/d fake_x
                     dx.backward_input(1, dst=fx.dgen_view())
                     self._copy(cy.dxin.view(0, Cc), fx.dgen_view(second=True))
                 ea, eb = torch.cuda.Event(), torch.cuda.Event()

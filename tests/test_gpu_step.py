@@ -231,6 +231,40 @@ def test_cyclegan_batched_generator_calls_equal_separate_calls():
     print("batched vs separate generator calls: worst per-tensor gradient rel diff", worst)
 
 
+def test_cyclegan_wide_wgrads_equal_write_plus_accumulate():
+    """One-GPU CycleGAN schedule: the cycle call of a generator lives in extra samples of its batched call's saved tensors and ONE
+    wgrad GEMM per layer covers all three invocations (CycleGANStep.wide_wgrads) - against the write + accumulate pair, fp32:
+    identical forward, the same kernel gradients up to the fp32 summation order, identical norm-vector gradients."""
+    from gan_amd.nets import Ctx
+    from gan_amd.steps import CycleGANStep
+    B, S, C = 2, 256, 1
+    rx, ry = O.synthetic_pair(B, S, C, seed=23)
+    keys = ['fake_y', 'cycled_x', 'fake_x', 'cycled_y', 'same_x', 'same_y']
+    masks = {k: O.dropout_masks(B, S, seed=80 + i) for i, k in enumerate(keys)}
+    res = []
+    for wide in (True, False):
+        ctx = Ctx('cuda:0', 'f32')
+        st = CycleGANStep(ctx, B, S, C, lam=10.0, seed=7, dropout=True)
+        st.wide_wgrads = wide
+        for k, call in st.gen_calls().items():
+            call.set_dropmasks(masks[k])
+        losses = st.train_step(torch.from_numpy(rx).to(ctx.device), torch.from_numpy(ry).to(ctx.device), True).cpu().numpy().copy()
+        assert st._wide is True            # host and guest agree on the buffer of down0's output gradient at this shape
+        res.append((losses, [n.params.to_numpy('grad') for n in st.nets()]))
+    (la, ga), (lb, gb) = res
+    assert np.array_equal(la, lb)
+    worst = ('', 0.0)
+    for nm, a, b in zip(('Gg', 'Gf', 'Dx', 'Dy'), ga, gb):
+        for k in b:
+            if k.endswith('.kernel') and nm in ('Gg', 'Gf'):
+                rel = float(np.linalg.norm(a[k] - b[k]) / (np.linalg.norm(b[k]) + 1e-20))
+                worst = max(worst, (nm + '.' + k, rel), key=lambda t: t[1])
+                assert rel < 2e-6, (nm, k, rel)
+            else:
+                assert np.array_equal(a[k], b[k]), (nm, k)
+    print("wide wgrad vs write + accumulate: worst per-tensor kernel-gradient rel diff", worst)
+
+
 @pytest.mark.parametrize("dtype", ['f32', 'bf16'])
 def test_generator_output_on_reference_example_pairs(dtype):
     """BASELINE.json gate: generator output on the reference's own 256x256 thermal/visible example pairs within
@@ -406,7 +440,8 @@ def _rccl_one_rank_worker(port, q, model):
         for ddp in (False, True):
             ctx = Ctx('cuda:0', 'bf16')
             st = Pix2PixStep(ctx, 2, 256, 1, lam=100.0, seed=123) if model == 'pix2pix' else CycleGANStep(ctx, 1, 256, 1, lam=10.0, seed=123)
-            if ddp:
+            st.wide_wgrads = False        # (CycleGAN one-GPU default: one wgrad GEMM over a generator's three invocations - another summation
+            if ddp:                       # order than the write + accumulate pair of the phased schedule; compared in its own test)
                 st.sync = GradSync([n.params.grad for n in st.nets()], compress_bf16=(wire == 'bf16'), lib=ctx.lib, rehearse=True)
                 assert st.sync.active and st.sync.world == 1
             g = torch.Generator(device='cpu').manual_seed(5)
