@@ -204,8 +204,9 @@ class _StepBase:
 class Pix2PixStep(_StepBase):
     # schedule constants (measured); attributes so that an experiment can change them per object
     dreal_on_side_lane = True    # D(real)'s forward on lane 2 beside the generator's launch-bound inner layers (+0.8 %)
-    early_adam = True            # Adam + NK refresh of a stage's kernels on lane 4 as soon as its wgrads are done (+1.5 %)
-    wgrad_cuts = (8, 12)         # G's wgrad GEMMs in three coarse stages: decoder | down7..4 | down3..0
+    early_adam = False           # Adam + NK refresh of a stage's kernels on lane 4 as soon as its wgrads are done: +1.5 % in round 2,
+    adam_lane = 4                # -0.5 % since the step became work-bound (round 3; adam_lane 3 = behind the wgrads on their lane: same)
+    wgrad_cuts = (4, 8, 12)      # G's wgrad GEMMs in four coarse stages: up7..up4 | up3..up0 | down7..4 | down3..0 (finer: -3 %)
     ddp_buckets = True           # data parallel, bf16/f32: the bucketed schedule (False: the phased one)
     ddp_graphs = 4               # bucketed schedule: compute graphs per step (4, 3 or 2)
     ddp_late_comm = True         # a boundary's collectives are issued after the NEXT compute graph has been enqueued
@@ -310,7 +311,7 @@ class Pix2PixStep(_StepBase):
                     # a segment's kernel gradients are complete once its wgrads (a stage on lane 3) are done: its Adam +
                     # NK refresh (HBM-bound) runs on lane 4 beside the rest of the backward pass.  Stages: decoder
                     # (last, up6..up0) | down7..down4 | down3..down0 (the tail, updated after the join with the vectors)
-                    P, lane4 = self.G.params, self.ctx.lane_stream(4)
+                    P, lane4 = self.G.params, self.ctx.lane_stream(self.adam_lane)
                     g.wgrad_cuts = [8, 12]          # the segments below are cut at exactly these wgrads
                     if P._segments is None or len(P._segments) != 3:
                         P.split_kernels_at('down4.kernel', 'up0.kernel')
@@ -321,7 +322,8 @@ class Pix2PixStep(_StepBase):
                     def hook(k):
                         if k >= nst or k > 1:          # the last stage's segment is updated after the join
                             return
-                        self.ctx.join(lane4, lane3)
+                        if lane4 is not lane3:
+                            self.ctx.join(lane4, lane3)
                         ops = P.adam_begin_ops(self.lr, self.b1, self.b2) if k == 0 else []
                         self.ctx.run_on(ops + P.adam_segment_ops(2 - k, self.b1, self.b2), lane4)
                         self._early_segs.add(2 - k)
@@ -331,8 +333,8 @@ class Pix2PixStep(_StepBase):
                 g.stage_hook = None
                 self.ctx.join(main, lane2)
                 self.ctx.join(main, lane3)
-                if self._early_adam is not None:
-                    self.ctx.join(main, self.ctx.lane_stream(4))
+                if self._early_adam is not None and self.adam_lane != 3:
+                    self.ctx.join(main, self.ctx.lane_stream(self.adam_lane))
             else:
                 g.backward(use_dgen2=True)
                 d.backward_params()
