@@ -196,40 +196,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
         cga[e] = p.bf_gamma[c0 + e]; cbe[e] = p.bf_beta[c0 + e];
       }
     }
-    // Fused backward epilogue, fast path (every thread serves ITERS whole row vectors of its column group): the reference /
-    // skip / mask vectors of a group of U rows are requested one group AHEAD - the first group before the accumulators are
-    // staged, the next one before the current one is used - so their latency (one dependent HBM round trip per group made
-    // this loop +6 us per 256x128 tile, +15 us per 256x256 one) hides behind the staging pass and the stores.
-    constexpr int FTOTAL = WAVES_M * IPP * 16 * VPR;
-    constexpr bool FFAST = FTOTAL % NTHREADS == 0;
-    constexpr int FITERS = FFAST ? FTOTAL / NTHREADS : 1, FU = FITERS % 4 == 0 ? 4 : (FITERS % 2 == 0 ? 2 : 1);
-    struct FuseRows { uint4 rv[FU], av[FU]; uint2 mv[FU]; size_t pix[FU]; bool ok[FU]; };
-    const int fn = bn0 + (scg % PVECS) * VEC;
-    const int fcpy = PARCOLS ? (scg / PVECS) >> 1 : py, fcpx = PARCOLS ? (scg / PVECS) & 1 : px;
-    const bool fcolok = fn < p.Cout, ffuse = p.bf_mode != 0 && fn < p.bf_cols;
-    auto fuse_load = [&](int ip, int it0, FuseRows& f) {
-#pragma unroll
-      for (int u = 0; u < FU; ++u) {
-        const int sr = (tid + (it0 + u) * NTHREADS) / VPR, g16 = sr >> 4;
-        const int m = bm0 + (g16 / IPP) * WTM + (ip * IPP + g16 % IPP) * 16 + (sr & 15);
-        f.ok[u] = m < p.M && fcolok;
-        f.pix[u] = f.ok[u] ? out_pixel_index(p, m, fcpy, fcpx) : 0;
-        f.rv[u] = f.av[u] = make_uint4(0, 0, 0, 0); f.mv[u] = make_uint2(0, 0);
-        if (f.ok[u] && ffuse) {
-          f.rv[u] = *(const uint4*)((const T*)p.bf_ref + f.pix[u] * (size_t)p.bf_refpitch + fn);
-          if (p.bf_add) f.av[u] = *(const uint4*)((const T*)p.bf_add + f.pix[u] * (size_t)p.bf_addpitch + fn);
-          if (p.bf_mode == 3) {
-            if constexpr (VEC == 8) f.mv[u] = *(const uint2*)(p.bf_mask + f.pix[u] * (size_t)p.bf_maskpitch + fn);
-            else f.mv[u].x = *(const uint32_t*)(p.bf_mask + f.pix[u] * (size_t)p.bf_maskpitch + fn);
-          }
-        }
-      }
-    };
 #pragma unroll
     for (int ip = 0; ip < MT / IPP; ++ip) {
       if (ip) __syncthreads();
-      FuseRows fcur;
-      if (FFAST && p.bf_mode) fuse_load(ip, 0, fcur);
       // activation resolved once per pass, not per element (the run-time select chain over 64 accumulators per
       // lane was ~3 us of the epilogue)
       auto stage = [&](auto actc) {
@@ -278,18 +247,38 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
             }
           }
         } else {
-          for (int it0 = 0; it0 < FITERS; it0 += FU) {
-            FuseRows fnext;
-            if (it0 + FU < FITERS) fuse_load(ip, it0 + FU, fnext);
+          // fused backward epilogue: the reference / skip / mask vectors of U rows are requested together before any of them
+          // is used (one dependent global load per iteration made this loop pure latency: +9..+40 us per launch)
+          constexpr int ITERS = TOTAL / NTHREADS, U = ITERS % 4 == 0 ? 4 : (ITERS % 2 == 0 ? 2 : 1);
+          const int n = bn0 + (scg % PVECS) * VEC;
+          const int cpy = PARCOLS ? (scg / PVECS) >> 1 : py, cpx = PARCOLS ? (scg / PVECS) & 1 : px;
+          const bool colok = n < p.Cout, fuse = n < p.bf_cols;
+          for (int it0 = 0; it0 < ITERS; it0 += U) {
+            uint4 rv[U], av[U]; uint2 mv[U]; size_t pix[U]; bool ok[U];
 #pragma unroll
-            for (int u = 0; u < FU; ++u) {
-              if (!fcur.ok[u]) continue;
+            for (int u = 0; u < U; ++u) {
+              const int sr = (tid + (it0 + u) * NTHREADS) / VPR, g16 = sr >> 4;
+              const int m = bm0 + (g16 / IPP) * WTM + (ip * IPP + g16 % IPP) * 16 + (sr & 15);
+              ok[u] = m < p.M && colok;
+              pix[u] = ok[u] ? out_pixel_index(p, m, cpy, cpx) : 0;
+              rv[u] = av[u] = make_uint4(0, 0, 0, 0); mv[u] = make_uint2(0, 0);
+              if (ok[u] && fuse) {
+                rv[u] = *(const uint4*)((const T*)p.bf_ref + pix[u] * (size_t)p.bf_refpitch + n);
+                if (p.bf_add) av[u] = *(const uint4*)((const T*)p.bf_add + pix[u] * (size_t)p.bf_addpitch + n);
+                if constexpr (MODE == 3) {
+                  if constexpr (VEC == 8) mv[u] = *(const uint2*)(p.bf_mask + pix[u] * (size_t)p.bf_maskpitch + n);
+                  else mv[u].x = *(const uint32_t*)(p.bf_mask + pix[u] * (size_t)p.bf_maskpitch + n);
+                }
+              }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+              if (!ok[u]) continue;
               const int sr = (tid + (it0 + u) * NTHREADS) / VPR;
               uint4 raw = *(const uint4*)(Cs + sr * CS + scg * 16);
-              if (ffuse) raw = bwd_fuse_vec<T, MODE, VEC>(p, raw, fcur.rv[u], fcur.av[u], fcur.mv[u], cmu, crs, cga, cbe, ssum, ssq);
-              *(uint4*)((T*)p.y + fcur.pix[u] * (size_t)p.ypitch + fn) = raw;
+              if (fuse) raw = bwd_fuse_vec<T, MODE, VEC>(p, raw, rv[u], av[u], mv[u], cmu, crs, cga, cbe, ssum, ssq);
+              *(uint4*)((T*)p.y + pix[u] * (size_t)p.ypitch + n) = raw;
             }
-            if (it0 + FU < FITERS) fcur = fnext;
           }
         }
       };
