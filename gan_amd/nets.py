@@ -553,7 +553,7 @@ class GenCall:
                 return _B.slice_of(big, 0, n_)
             return _B(ctx_, n_, h_, w_, c_, tdtype)
         bd = _Builder(ctx, P, net.norm, lane=lane)
-        bd.wgrad_concurrent = bool(wgrads_on_side_lane)
+        bd.wgrad_concurrent = int(wgrads_on_side_lane)      # (2: beside a mirror chain, GanWgradDesc.concurrent)
         self._bd = bd
         C_ = net.channels
         groups = 1 if net.norm == 'batchnorm' else B

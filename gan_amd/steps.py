@@ -533,6 +533,9 @@ class CycleGANStep(_StepBase):
         else:
             self.cx, self.cy = mk(self.Gf, 1), mk(self.Gg, 3)
         self._wide = None
+        if self.merged and ctx.lanes:       # planner hint of the wgrad GEMMs: they run beside the mirror chain's
+            for c_ in (self.gA, self.gB, self.cx, self.cy):
+                c_._bd.wgrad_concurrent = 2
         if self.merged:
             self.fy, self.sy = self.gA.half(0, batch), self.gA.half(batch, batch)
             self.fx, self.sx = self.gB.half(0, batch), self.gB.half(batch, batch)
@@ -543,6 +546,8 @@ class CycleGANStep(_StepBase):
             # (own workspaces for the parameter passes: they run beside the generators' wgrad lanes)
             self.dx = self.Dx.new_call(batch, size, calls=2, lane=2, params_lane=6)       # D_x(real_x) ++ D_x(fake_x): chain B
             self.dy = self.Dy.new_call(batch, size, calls=2, lane=0, params_lane=4)
+            if ctx.lanes:
+                self.dx._bd2.wgrad_concurrent = self.dy._bd2.wgrad_concurrent = 2
         else:
             self.dx = self.Dx.new_call(batch, size, calls=2)
             self.dy = self.Dy.new_call(batch, size, calls=2)

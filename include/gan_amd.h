@@ -142,7 +142,9 @@ typedef struct GanWgradDesc {
   void* workspace;
   size_t workspace_bytes;
   int32_t concurrent;    /* scheduling hint: nonzero = this launch shares the GPU with other streams' kernels (a side lane of a
-                            captured step); the planner then prefers half-chip grids with longer reductions (less slab traffic) */
+                            captured step): the planner then prefers fewer, longer blocks (less slab traffic; the other streams get
+                            the rest of the chip).  2 = beside a MIRROR chain doing the same work (the two-chain CycleGAN step):
+                            the K-split target is halved as well. */
 } GanWgradDesc;
 /* Kernel gradient of Conv2D / Conv2DTranspose (GradientTape.gradient w.r.t. trainable_variables,
  * pix2pix.py:210-211, cycle_gan.py:252-260). */
