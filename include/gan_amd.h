@@ -334,7 +334,7 @@ const char* gan_version(void);
  * conv.split_target_big (256), conv.split_min_ktiles (4), conv.split_max (64), conv.bwd_fuse_tile (1: the fused backward
  * epilogue rides on every tile epilogue; 0 never, 2 not on 64-column tiles, 3 only on them), conv.thin (7: bit 0
  * streaming kernels for the <= 8-channel layers, bit 1 thin-N, bit 2 thin-K), conv.norm_fuse (1), conv.thin_fused (1), wgrad.tile256 (0), wgrad.pingpong (1),
- * wgrad.pingpong_min_rows (0 = automatic), wgrad.pingpong_128 (0), wgrad.pingpong_min_gflop (30),
+ * wgrad.pingpong_min_rows (0 = automatic), wgrad.pingpong_128 (1), wgrad.pingpong_min_gflop (30),
  * wgrad.split_target (512). */
 int gan_set_option(const char* key, int32_t value);
 int gan_get_option(const char* key, int32_t* value);

@@ -608,6 +608,30 @@ def test_wgrad_tr_read_matches_plain(ctx, monkeypatch):
     assert np.array_equal(dw.cpu().numpy().reshape(4, 4, ci, co), ref)    # small integers: exact in bf16 and fp32
 
 
+def test_wgrad_pingpong_128_columns_matches_128_tile_kernel(ctx, planner_options):
+    """A 64-channel x 128-channel kernel gradient (G / D down1) on the 256-column ping-pong kernel (wgrad.pingpong_128, the
+    default from 30 GFLOP up: half its columns are computed and dropped) against the 128x128-tile kernel, exact integer data."""
+    from gan_amd import _lib as L
+    if ctx.dtype == 'f32':
+        pytest.skip("ping-pong wgrad: 16-bit storage only")
+    N, H, ci, co = 2, 128, 64, 128
+    rng = np.random.default_rng(11)
+    x = rng.integers(-2, 3, (N, H, H, ci)).astype(np.float64)
+    dy = rng.integers(-2, 3, (N, H // 2, H // 2, co)).astype(np.float64)
+    xb, xv = dev(ctx, x)
+    dyb, dyv = dev(ctx, dy)
+    planner_options('wgrad.pingpong_min_gflop', 1)
+    out = []
+    for pp in (1, 0):
+        planner_options('wgrad.pingpong_128', pp)
+        dw = torch.zeros((16, ci, co), dtype=torch.float32, device=ctx.device)
+        d = L.GanWgradDesc(ctx.dt, 2, xv, dyv, dw.data_ptr(), ci, co, 0, ctx.ws_ptr, ctx.ws_bytes)
+        assert ctx.lib.gan_conv_wgrad(C.byref(d), ctx.stream()) == 0
+        torch.cuda.synchronize()
+        out.append(dw.cpu().numpy())
+    assert np.abs(out[1]).max() > 100 and np.array_equal(out[0], out[1])
+
+
 @pytest.mark.parametrize("kind,groups_of", [('batchnorm', lambda n: 1), ('batchnorm', lambda n: 2), ('instancenorm', lambda n: n)])
 @pytest.mark.parametrize("act,drop", [('lrelu', False), ('relu', True)])
 def test_norm_act_fwd_bwd(ctx, kind, groups_of, act, drop):
