@@ -56,10 +56,15 @@ class GanConvDesc(_Desc):
                 ("norm_fuse", C.c_void_p)]
 
 
+class GanAdamFuse(C.Structure):
+    _fields_ = [("master", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("nk_native", C.c_void_p), ("nk_transposed", C.c_void_p),
+                ("lr_t", C.c_void_p), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float)]
+
+
 class GanWgradDesc(_Desc):
     _fields_ = [("struct_size", C.c_uint32), ("dtype", C.c_int32), ("stride", C.c_int32), ("big", GanTensor), ("small", GanTensor),
                 ("dw", C.c_void_p), ("big_c", C.c_int32), ("small_c", C.c_int32), ("accumulate", C.c_int32),
-                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("concurrent", C.c_int32)]
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("concurrent", C.c_int32), ("adam_fuse", C.c_void_p)]
 
 
 class GanNormDesc(_Desc):
@@ -95,6 +100,7 @@ SYMBOLS = {
     "gan_wgrad_plan_info": (C.c_int, [C.POINTER(GanWgradDesc), C.POINTER(C.c_int32)]),
     "gan_conv_wgrad": (C.c_int, [C.POINTER(GanWgradDesc), C.c_void_p]),
     "gan_wgrad_workspace_bytes": (C.c_size_t, [C.POINTER(GanWgradDesc)]),
+    "gan_wgrad_adam_fused": (C.c_int, [C.POINTER(GanWgradDesc)]),
     "gan_weights_prepare": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gan_weights_prepare_multi": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "gan_adam_prepare_multi": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -80,6 +80,15 @@ template <> __device__ __forceinline__ f32x4 mma16<f16_t>(const uint4& a, const 
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(*(const f16x8*)&a, *(const f16x8*)&b, c, 0, 0, 0);
 }
 int gan_opt(const char* key);      // planner options (host_util.cpp; changed only by gan_set_option)
+// One element of the TF-form Adam step (Keras optimizer_v2/adam.py): the ONE definition used by every kernel that applies it, so
+// that the update fused into a wgrad epilogue is bit-identical to the stand-alone kernels.
+__device__ __forceinline__ void gan_adam1(float& p, float& m, float& v, float g, float gscale, float omb1, float omb2, float lr, float eps) {
+  const float gr = g * gscale;
+  m += (gr - m) * omb1;
+  v += (gr * gr - v) * omb2;
+  p -= (m * lr) / (sqrtf(v) + eps);
+}
+
 static inline bool gan_dtype_ok(int dtype) { return dtype == GAN_F32 || dtype == GAN_BF16 || dtype == GAN_F16; }
 
 __device__ __forceinline__ float apply_act(float v, int act, float slope) {

@@ -253,12 +253,7 @@ __global__ __launch_bounds__(256) void adam_prep_multi_kernel(const PrepEntry* e
   const float lr = *lr_t;
   T* nat = (T*)en.nat;
   T* tr = (T*)en.tr;
-  auto adam1 = [&](float& p, float& m, float& v, float g) {
-    const float gr = g * gscale;
-    m += (gr - m) * omb1;
-    v += (gr * gr - v) * omb2;
-    p -= (m * lr) / (sqrtf(v) + eps);
-  };
+  auto adam1 = [&](float& p, float& m, float& v, float g) { gan_adam1(p, m, v, g, gscale, omb1, omb2, lr, eps); };
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;     // 4 consecutive b per thread, 16 rows per pass
   const bool vecB = (B & 3) == 0;
 #pragma unroll

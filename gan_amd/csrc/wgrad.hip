@@ -27,6 +27,10 @@ struct WgradParams {
   int splits, kchunks;
   int accumulate, fold;
   int swap, shift;  // swap: roles exchanged (thin SMALL tensor folded, thick BIG tensor streamed), taps flipped, rows shifted
+  // GanAdamFuse (adam != 0: un-split launch, !fold, !swap, !accumulate, CaReal % 8 == CbReal % 8 == 0): the epilogue applies Adam
+  int adam;
+  float* aw; float* am; float* av; void* anat; void* atr; const float* alr;
+  float omb1, omb2, aeps;
 };
 
 template <typename T, int TA, int TB, int WAVES_A, int WAVES_B, bool TR>
@@ -263,7 +267,7 @@ static int plan_wgrad(const GanWgradDesc* d, WgradPlan* pl, bool allow_swap = tr
   p.S = d->stride; p.M = (int)M; p.divW = make_fastdiv(s.w); p.divH = make_fastdiv(s.h);
   p.CaReal = d->big_c; p.CbReal = d->small_c; p.accumulate = d->accumulate;
   p.fold = (b.c == 8) ? 1 : 0;
-  p.swap = 0; p.shift = 0;
+  p.swap = 0; p.shift = 0; p.adam = 0;
   int TA, TB, tilesA, taps;
   if (allow_swap && !p.fold && d->stride == 1 && s.c == 8 && b.c >= 64) {
     // Thin SMALL tensor (the logits layer's dy): iterate over the BIG grid instead and fold the 16 taps of the thin
@@ -334,6 +338,13 @@ static int plan_wgrad(const GanWgradDesc* d, WgradPlan* pl, bool allow_swap = tr
     if (splits > 1024) splits = 1024;
   }
   p.splits = splits;
+  if (const GanAdamFuse* af = d->adam_fuse; af && allow_swap && splits == 1 && !p.fold && !p.swap && !d->accumulate && d->dtype != GAN_F32 &&
+      taps == 16 && TA == 128 && TB == 128 && p.CaReal % 8 == 0 && p.CbReal % 8 == 0 && af->master && af->m && af->v && af->lr_t &&
+      !(((uintptr_t)af->master | (uintptr_t)af->m | (uintptr_t)af->v | (uintptr_t)af->nk_native | (uintptr_t)af->nk_transposed) & 15)) {
+    p.adam = 1;
+    p.aw = af->master; p.am = af->m; p.av = af->v; p.anat = af->nk_native; p.atr = af->nk_transposed; p.alr = af->lr_t;
+    p.omb1 = 1.f - af->beta1; p.omb2 = 1.f - af->beta2; p.aeps = af->eps;
+  }
   pl->TA = TA; pl->TB = TB;
   pl->grid = dim3((unsigned)(tilesA * tilesB), (unsigned)taps, (unsigned)splits);
   pl->slab_bytes = splits > 1 ? (size_t)splits * 16 * p.CaReal * p.CbReal * sizeof(float) : 0;
@@ -542,6 +553,63 @@ __global__ __launch_bounds__(64 * WAVES_A * WAVES_B) void wgrad_dma_kernel(const
   // The MFMAs ran with the SMALL-tensor fragment as the "A" operand, so acc[i][j][e] = dW[a = i*16 + (lane & 15)]
   // [cb = j*16 + (lane >> 4)*4 + e]: four consecutive cb per lane -> one 16-byte store where the layout allows.
   const bool vec4 = !p.swap && p.CbReal % 4 == 0;
+  if (p.adam) {
+    // GanAdamFuse (128 x 128 tiles, 4 waves as 2 x 2; the planner asks for nothing else): the gradient tile goes through LDS,
+    // 64 rows at a time, so that the optimiser step touches master / m / v in whole 512-byte rows (32 lanes x 16 bytes, as
+    // adam_prep_multi_kernel does: straight from the accumulator layout it was 64-byte pieces of 16 rows per instruction and
+    // the launch took twice as long as the stand-alone pass), writes the native NK rows, leaves the UPDATED weights in LDS and
+    // transposes them into the other NK copy.  Same per-element arithmetic as the stand-alone kernels (gan_adam1); dw is not written.
+    if constexpr (sizeof(T) == 2 && TA == 128 && TB == 128 && WAVES_A == 2 && WAVES_B == 2) {
+      constexpr int LP = 129;                                // padded row of the 64 x 128 fp32 half tile
+      float* tile = (float*)smem;
+      const float lr = *p.alr;
+      __syncthreads();                                       // every wave has left the last stage
+      for (int h = 0; h < 2; ++h) {
+        if (wa == h) {
+#pragma unroll
+          for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) tile[(i * 16 + r) * LP + wb * WTB + j * 16 + q * 4 + e] = acc[i][j][e];
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int it = 0; it < 8; ++it) {
+          const int idx = tid + it * 256, row = idx >> 5, c4 = (idx & 31) * 4;
+          const int a = ca0 + h * 64 + row, cb = cb0 + c4;
+          if (a < p.CaReal && cb < p.CbReal) {
+            const size_t o = ((size_t)tap * p.CaReal + a) * p.CbReal + cb;
+            float* t4 = tile + row * LP + c4;
+            float4 pp = *(const float4*)(p.aw + o), mm = *(const float4*)(p.am + o), vv = *(const float4*)(p.av + o);
+            gan_adam1(pp.x, mm.x, vv.x, t4[0], 1.f, p.omb1, p.omb2, lr, p.aeps);
+            gan_adam1(pp.y, mm.y, vv.y, t4[1], 1.f, p.omb1, p.omb2, lr, p.aeps);
+            gan_adam1(pp.z, mm.z, vv.z, t4[2], 1.f, p.omb1, p.omb2, lr, p.aeps);
+            gan_adam1(pp.w, mm.w, vv.w, t4[3], 1.f, p.omb1, p.omb2, lr, p.aeps);
+            *(float4*)(p.aw + o) = pp; *(float4*)(p.am + o) = mm; *(float4*)(p.av + o) = vv;
+            if (p.anat) *(uint2*)((T*)p.anat + o) = make_uint2(pack2<T>(pp.x, pp.y), pack2<T>(pp.z, pp.w));
+            t4[0] = pp.x; t4[1] = pp.y; t4[2] = pp.z; t4[3] = pp.w;
+          }
+        }
+        __syncthreads();
+        if (p.atr) {
+#pragma unroll
+          for (int it = 0; it < 4; ++it) {
+            const int idx = tid + it * 256, bl = idx >> 3, a8 = (idx & 7) * 8;
+            const int b = cb0 + bl, a = ca0 + h * 64 + a8;
+            if (b < p.CbReal && a < p.CaReal) {
+              const float* c = tile + a8 * LP + bl;
+              const uint4 w8 = make_uint4(pack2<T>(c[0], c[LP]), pack2<T>(c[2 * LP], c[3 * LP]), pack2<T>(c[4 * LP], c[5 * LP]),
+                                          pack2<T>(c[6 * LP], c[7 * LP]));
+              *(uint4*)((T*)p.atr + ((size_t)tap * p.CbReal + b) * p.CaReal + a) = w8;
+            }
+          }
+        }
+        __syncthreads();
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
     const int a = ca0 + wa * WTA + i * 16 + r;
@@ -869,6 +937,17 @@ int gan_wgrad_plan_info(const GanWgradDesc* d, int32_t* info /*[4]: TA, TB, spli
   if (rc) return rc;
   info[0] = pl.TA; info[1] = pl.TB; info[2] = pl.p.splits; info[3] = pl.p.fold;
   return 0;
+}
+int gan_wgrad_adam_fused(const GanWgradDesc* d) {
+  if (!d || d->struct_size != sizeof(GanWgradDesc)) return GAN_E_ARG;
+  const size_t es = d->dtype == GAN_F32 ? 4 : 2;
+  const size_t bb = (((size_t)d->big.n * d->big.h * d->big.w - 1) * d->big.pitch + d->big.c) * es;
+  const size_t sb = (((size_t)d->small.n * d->small.h * d->small.w - 1) * d->small.pitch + d->small.c) * es;
+  const bool dma_ok = bb < 0x7fffffffull && sb < 0x7fffffffull && !(((uintptr_t)d->big.ptr | (uintptr_t)d->small.ptr) & 15);
+  WgradPlan pl;
+  const int rc = plan_wgrad(d, &pl, dma_ok);
+  if (rc) return rc;
+  return pl.p.adam && !pl.pp ? 1 : 0;
 }
 size_t gan_wgrad_workspace_bytes(const GanWgradDesc* d) {
   WgradPlan pl;

@@ -236,6 +236,30 @@ class ParamSet:
             ops.append((lib.gan_adam_tf, vptrs + (nvec, self.lr_t.data_ptr(), b1, b2, eps, grad_scale, self.ctx.ls_ptr, gw), "adam_tf"))
         return ops
 
+    def adam_fuse_desc(self, name, b1, b2, eps=1e-7):
+        """GanAdamFuse for kernel `name`: its wgrad launch applies this step's Adam update and refreshes its NK copies."""
+        o = 4 * self.entries[name][0]
+        return L.GanAdamFuse(self.master.data_ptr() + o, self.m.data_ptr() + o, self.v.data_ptr() + o, self.nat[name].data_ptr(),
+                             self.tr[name].data_ptr(), self.lr_t.data_ptr(), b1, b2, eps)
+
+    def adam_rest_ops(self, fused_names, b1, b2, eps=1e-7):
+        """Adam of everything the wgrad launches did NOT update themselves: the other kernels (own table) and the vectors.
+        gan_adam_begin must already have run this step (before the first fused wgrad)."""
+        key = frozenset(fused_names)
+        if getattr(self, '_rest_key', None) != key:
+            names = [n_ for n_ in self.nat if n_ not in key]
+            self._rest_key, self._rest = key, (self._kernel_table(names) if names else None)
+        lib = self.ctx.lib
+        ptrs = (self.master.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), self.grad.data_ptr())
+        ops = []
+        if self._rest is not None:
+            ops.append((lib.gan_adam_prepare_multi, self._rest[1] + ptrs + (self.lr_t.data_ptr(), b1, b2, eps, 1.0, self.ctx.ls_ptr, 0), "adam_prepare_multi"))
+        nvec = self.total - self.vec_start
+        if nvec > 0:
+            vptrs = tuple(p_ + 4 * self.vec_start for p_ in ptrs)
+            ops.append((lib.gan_adam_tf, vptrs + (nvec, self.lr_t.data_ptr(), b1, b2, eps, 1.0, self.ctx.ls_ptr, 0), "adam_tf"))
+        return ops
+
     def ptr(self, name, which='master'):
         return getattr(self, which).data_ptr() + 4 * self.entries[name][0]
 
@@ -442,9 +466,21 @@ class _Builder:
                     shape=f"{op} M{M}{'x4' if info[3] == 4 else ''} N{y.c} K{T * x.c} s{info[2]}")
         return (fn, (self._desc(d),), op, meta)
 
-    def wgrad(self, big, small, dw_ptr, big_c, small_c, stride, accumulate):
+    def wgrad(self, big, small, dw_ptr, big_c, small_c, stride, accumulate, adam_fuse=None):
+        """adam_fuse: a GanAdamFuse - ask the launch to apply the optimiser step itself; self.last_adam_fused tells whether it will."""
+        if adam_fuse is not None:
+            self.keep.append(adam_fuse)
         d = L.GanWgradDesc(self.ctx.dt, stride, big, small, dw_ptr, big_c, small_c, int(accumulate),
-                           self.ws_side_ptr, self.ws_bytes, int(self.wgrad_concurrent))
+                           self.ws_side_ptr, self.ws_bytes, int(self.wgrad_concurrent),
+                           C.addressof(adam_fuse) if adam_fuse is not None else None)
+        self.last_adam_fused = False
+        if adam_fuse is not None:
+            rc = self.lib.gan_wgrad_adam_fused(C.byref(d))
+            if rc < 0:
+                L.check(rc, "wgrad_adam_fused")
+            self.last_adam_fused = rc == 1
+            if not self.last_adam_fused:
+                d.adam_fuse = None
         need = self.lib.gan_wgrad_workspace_bytes(C.byref(d))
         if need > self.ws_bytes:
             raise L.GanAmdError(f"workspace too small for wgrad: need {need}")
@@ -640,11 +676,16 @@ class GenCall:
         self.dgen2 = Buf(ctx, B, S, S, 8)     # upstream gradient slot 2 (e.g. from the discriminator)
         self.dxin = Buf(ctx, B, S, S, 8)
         self._bwd_cache = {}
+        self.adam_fused = {}
 
-    def _build_bwd(self, use_dgen2, need_dx, accumulate, wgrads='own'):
+    def _build_bwd(self, use_dgen2, need_dx, accumulate, wgrads='own', adam=None):
         """wgrads: 'own' - this call's kernel gradients (accumulate as the other gradients do); 'none' - a guest call whose host
         takes them; 'wide' - a host call: one wgrad GEMM per layer over its own AND its guest's samples, plain write (the guest's
         saved activations and output gradients must be in place: its forward and its backward(wgrads='none') have run).
+        adam = (beta_1, beta_2): every wgrad launch that can applies this step's Adam update to its kernel itself (GanAdamFuse;
+        needs plain-write kernel gradients: wgrads 'own' without accumulate, or 'wide'); self.adam_fused[key] lists those kernels.
+        The caller runs gan_adam_begin BEFORE this list and ParamSet.adam_rest_ops() for everything else after it, and must not
+        start a layer's wgrad before every dgrad of the step that reads the layer's weights has been enqueued (staged order).
         Backward op list.  Wherever the launch shape allows it, the dgrad that produces the gradient w.r.t. a layer's
         activation starts that layer's backward in its epilogue (dz + partial sums; `fused` = chunk count) and the layer is
         finished by finalize + apply; otherwise the three-launch normalisation backward / act_bwd follows."""
@@ -654,13 +695,21 @@ class GenCall:
         W = (lambda b_: b_.wide()) if wgrads == 'wide' else (lambda b_: b_)
         wacc = accumulate and wgrads != 'wide'
 
-        def wgrad(*a_):
-            if wgrads != 'none':
-                ops.append(bd.wgrad(*a_, wacc))
+        fused_names = []
+        if adam is not None and wacc:
+            raise ValueError("adam fusion needs plain-write kernel gradients")
+
+        def wgrad(big_v, small_v, kname, big_c, small_c, stride):
+            if wgrads == 'none':
+                return
+            af = P.adam_fuse_desc(kname, adam[0], adam[1]) if adam is not None else None
+            ops.append(bd.wgrad(big_v, small_v, P.ptr(kname, 'grad'), big_c, small_c, stride, wacc, adam_fuse=af))
+            if af is not None and bd.last_adam_fused:
+                fused_names.append(kname)
         ops = []
         ops.append(bd.act_bwd(self.out.view(), self.dgen.view(), self.dgen2.view() if use_dgen2 else None,
                               self.dpre.view(), 'tanh'))
-        wgrad(W(self.dpre).view(), W(self.cat[6]).view(), P.ptr('last.kernel', 'grad'), C_, 128, 2)
+        wgrad(W(self.dpre).view(), W(self.cat[6]).view(), 'last.kernel', C_, 128, 2)
         ops.append(bd.bias_grad(self.dpre.view(), P.ptr('last.bias', 'grad'), accumulate))
 
         def up_spec(j):         # backward of up j (ReLU [+ dropout] after the norm) on the leading G_UP[j] channels of dcat[j]
@@ -687,7 +736,7 @@ class GenCall:
             xin = self.a7 if j == 0 else self.cat[j - 1]
             dxin = self.da7 if j == 0 else self.dcat[j - 1]
             cin = xin.c
-            wgrad(W(self.dy_up[j]).view(), W(xin).view(), P.ptr(name + '.kernel', 'grad'), G_UP[j], cin, 2)
+            wgrad(W(self.dy_up[j]).view(), W(xin).view(), name + '.kernel', G_UP[j], cin, 2)
             if j > 0:
                 spec, nfz = up_spec(j - 1), bd.bwd_norm_fuse(f'up{j - 1}', self.dy_up[j - 1].view(), True, accumulate)
             else:               # da7: gradient w.r.t. the bottleneck activation = down7's backward
@@ -730,7 +779,7 @@ class GenCall:
             else:
                 jj = 6 - (i - 1)
                 xin, cin_real = W(self.cat[jj]).view(G_UP[jj], G_DOWN[i - 1]), G_DOWN[i - 1]
-            wgrad(xin, W(dyi).view(), P.ptr(name + '.kernel', 'grad'), cin_real, G_DOWN[i], 2)
+            wgrad(xin, W(dyi).view(), name + '.kernel', cin_real, G_DOWN[i], 2)
             fused, full = 0, False
             if i > 0:
                 jb = 6 - (i - 1)                                     # layer below: down i-1, its skip gradient sits in dcat[jb]
@@ -747,6 +796,7 @@ class GenCall:
             elif need_dx:
                 ops.append(bd.conv('conv_dgrad', dyi.view(), self.dxin.view(0, C_),
                                    P.nat[name + '.kernel'].data_ptr(), C_, 2))
+        self.adam_fused[(use_dgen2, need_dx, accumulate, wgrads, adam)] = tuple(fused_names)
         return ops
 
     # public API ------------------------------------------------------------------------------
@@ -785,9 +835,12 @@ class GenCall:
         """Samples [n0, n0 + n) of this call as a call-like object (CycleGAN batches two logical calls of one generator)."""
         return CallSlice(self, n0, n)
 
-    def backward(self, use_dgen2=False, need_dx=False, accumulate=False, defer_wgrads=False, wgrads='own'):
-        """Upstream gradient(s) w.r.t. the tanh output must be in self.dgen (and self.dgen2).  wgrads: see _build_bwd."""
-        key = (use_dgen2, need_dx, accumulate) if wgrads == 'own' else (use_dgen2, need_dx, accumulate, wgrads)
+    def _bwd_key(self, use_dgen2, need_dx, accumulate, wgrads, adam):
+        return (use_dgen2, need_dx, accumulate) if wgrads == 'own' and adam is None else (use_dgen2, need_dx, accumulate, wgrads, adam)
+
+    def backward(self, use_dgen2=False, need_dx=False, accumulate=False, defer_wgrads=False, wgrads='own', adam=None):
+        """Upstream gradient(s) w.r.t. the tanh output must be in self.dgen (and self.dgen2).  wgrads / adam: see _build_bwd."""
+        key = self._bwd_key(use_dgen2, need_dx, accumulate, wgrads, adam)
         if key not in self._bwd_cache:
             self._bwd_cache[key] = self._build_bwd(*key)
         ops = self._bwd_cache[key]
@@ -808,18 +861,18 @@ class GenCall:
         else:
             self.ctx.run(ops)
 
-    def bwd_ops(self, use_dgen2=False, need_dx=False, accumulate=False, wgrads='own'):
-        """The (cached) backward op list; building it also settles self.dy0_in_dA."""
-        key = (use_dgen2, need_dx, accumulate) if wgrads == 'own' else (use_dgen2, need_dx, accumulate, wgrads)
+    def bwd_ops(self, use_dgen2=False, need_dx=False, accumulate=False, wgrads='own', adam=None):
+        """The (cached) backward op list; building it also settles self.dy0_in_dA and self.adam_fused."""
+        key = self._bwd_key(use_dgen2, need_dx, accumulate, wgrads, adam)
         if key not in self._bwd_cache:
             self._bwd_cache[key] = self._build_bwd(*key)
         return self._bwd_cache[key]
 
-    def bwd_stages(self, cuts, use_dgen2=False, need_dx=False, accumulate=False, wgrads='own'):
+    def bwd_stages(self, cuts, use_dgen2=False, need_dx=False, accumulate=False, wgrads='own', adam=None):
         """The backward op list cut into coarse stages at the wgrad indices `cuts` (the same cuts as the 'staged'
         mode): [(main-chain ops, wgrad ops)] per stage.  The wgrad GEMMs of a stage only feed Adam, so a caller may
         run them beside the NEXT stage's main chain (gan_amd/steps.py data-parallel schedule)."""
-        key = (use_dgen2, need_dx, accumulate) if wgrads == 'own' else (use_dgen2, need_dx, accumulate, wgrads)
+        key = self._bwd_key(use_dgen2, need_dx, accumulate, wgrads, adam)
         if key not in self._bwd_cache:
             self._bwd_cache[key] = self._build_bwd(*key)
         ops = self._bwd_cache[key]

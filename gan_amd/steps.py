@@ -78,8 +78,12 @@ class _StepBase:
         if ctx.ls is not None:        # fp16: a non-finite gradient anywhere skips the whole step (every network), then the scale adapts
             for net in self.nets():
                 ctx.run(net.params.grads_check_ops())
+        wfused = getattr(self, '_adam_wfused', None) or {}
         for net in self.nets():
             if net in done:        # updated at the end of its own backward chain
+                continue
+            if net in wfused:      # its big kernels were updated by their own wgrad launches (GanAdamFuse): the rest + the vectors
+                ctx.run(net.params.adam_rest_ops(wfused[net], self.b1, self.b2))
                 continue
             if net is early:       # some kernel segments were updated beside the backward pass: the rest + the vectors
                 rest = [k for k in range(len(net.params._segments)) if k not in self._early_segs]
@@ -91,7 +95,15 @@ class _StepBase:
                 net.params.adam(self.lr, self.b1, self.b2, grad_scale=gs, wire_ptr=wp(net))
         if ctx.ls is not None:
             L.check(ctx.lib.gan_loss_scale_update(ctx.ls_ptr, ctx.ls_growth_interval, ctx.ls_max, ctx.stream()), "loss_scale_update")
-        self._early_adam, self._adam_done = None, ()
+        self._early_adam, self._adam_done, self._adam_wfused = None, (), None
+
+    def _wgrad_adam_ok(self):
+        """GanAdamFuse schedules: one GPU, no loss scaling, 16-bit storage, lanes on."""
+        return bool(getattr(self, 'fused_wgrad_adam', False) and self.sync is None and self.ctx.ls is None and self.ctx.lanes
+                    and self.ctx.dtype != 'f32')
+
+    def _prebuild_fused_adam(self):
+        pass
 
     # ---- hipGraph capture of a whole step --------------------------------------------------------
     def capture(self, training=True):
@@ -110,9 +122,15 @@ class _StepBase:
             return self._capture_bucketed()          # (fp16: the whole-step inf/nan check precedes every Adam -> phased schedule)
         if split:
             return self._capture_phased(training)
+        if training:
+            self._prebuild_fused_adam()         # (op lists and device tables of the captured schedule: no uploads inside the capture)
         g1 = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g1, capture_error_mode=CAPTURE_MODE):
-            self._run(*self._static_in, training=training)
+            self._capturing = True          # (schedules that leave no fp32 gradients behind are for the replayed step only)
+            try:
+                self._run(*self._static_in, training=training)
+            finally:
+                self._capturing = False
             self.ctx.assert_lanes_joined()
         self._graphs = (g1, None, None)
 
@@ -204,6 +222,7 @@ class _StepBase:
 class Pix2PixStep(_StepBase):
     # schedule constants (measured); attributes so that an experiment can change them per object
     dreal_on_side_lane = True    # D(real)'s forward on lane 2 beside the generator's launch-bound inner layers (+0.8 %)
+    fused_wgrad_adam = True      # captured one-GPU step: the un-split wgrad launches apply Adam to their kernels themselves (GanAdamFuse)
     early_adam = False           # Adam + NK refresh of a stage's kernels on lane 4 as soon as its wgrads are done: +1.5 % in round 2,
     adam_lane = 4                # -0.5 % since the step became work-bound (round 3; adam_lane 3 = behind the wgrads on their lane: same)
     wgrad_cuts = (4, 8, 12)      # G's wgrad GEMMs in four coarse stages: up7..up4 | up3..up0 | down7..4 | down3..0 (finer: -3 %)
@@ -231,6 +250,12 @@ class Pix2PixStep(_StepBase):
 
     def nets(self):
         return (self.G, self.D)
+
+    def _prebuild_fused_adam(self):
+        if self._wgrad_adam_ok() and not self.early_adam:
+            adam = (self.b1, self.b2)
+            self.g.bwd_ops(True, False, False, 'own', adam)
+            self.G.params.adam_rest_ops(self.g.adam_fused[(True, False, False, 'own', adam)], self.b1, self.b2)
 
     def _example_inputs(self):
         sh = (self.B, self.S, self.S, self.C)
@@ -329,7 +354,16 @@ class Pix2PixStep(_StepBase):
                         self._early_segs.add(2 - k)
                     g.stage_hook = hook
                     self._early_adam = self.G
-                g.backward(use_dgen2=True, defer_wgrads='staged')
+                wf = self._wgrad_adam_ok() and getattr(self, '_capturing', False) and getattr(self, '_updating', False) and not self.early_adam
+                if wf:
+                    # lr_t of this step must exist before the first fused wgrad; a stage's wgrads start after every dgrad of its
+                    # layers has been enqueued (staged order), so rewriting those layers' weights there is safe
+                    adam = (self.b1, self.b2)
+                    self.ctx.run(self.G.params.adam_begin_ops(self.lr, self.b1, self.b2))
+                    g.backward(use_dgen2=True, defer_wgrads='staged', adam=adam)
+                    self._adam_wfused = {self.G: g.adam_fused[(True, False, False, 'own', adam)]}
+                else:
+                    g.backward(use_dgen2=True, defer_wgrads='staged')
                 g.stage_hook = None
                 self.ctx.join(main, lane2)
                 self.ctx.join(main, lane3)
@@ -501,6 +535,7 @@ class CycleGANStep(_StepBase):
     ddp_buckets = False
     two_chains = True            # one-GPU step: the G_g-side and the G_f-side chains on two lanes (_forward_backward_merged)
     early_adam = True            # ... and every network's Adam where its gradients complete, inside the chains
+    fused_wgrad_adam = True      # ... whose un-split launches apply Adam to their kernels themselves (captured step; GanAdamFuse)
     wide_wgrads = True           # ... one wgrad GEMM per layer over a generator's three invocations (host + guest call)
     adam_delay = (0, 0)          # ... stages by which chain A / B hold a segment's Adam back (measured: no offset is best)
 
@@ -560,6 +595,13 @@ class CycleGANStep(_StepBase):
 
     def nets(self):
         return (self.Gg, self.Gf, self.Dx, self.Dy)
+
+    def _prebuild_fused_adam(self):
+        if self._wgrad_adam_ok() and self.merged and self.two_chains and self.early_adam and self.wide_wgrads and self._wide:
+            adam = (self.b1, self.b2)
+            for call, net in ((self.gA, self.Gg), (self.gB, self.Gf)):
+                call.bwd_ops(True, False, True, 'wide', adam)
+                net.params.adam_rest_ops(call.adam_fused[(True, False, True, 'wide', adam)], self.b1, self.b2)
 
     def gen_calls(self):
         return dict(fake_y=self.fy, cycled_x=self.cx, fake_x=self.fx, cycled_y=self.cy, same_x=self.sx, same_y=self.sy)
@@ -704,15 +746,27 @@ class CycleGANStep(_StepBase):
                 wide = self._wide and self.wide_wgrads
                 w1, w2 = ('none', 'wide') if wide else ('own', 'own')
 
+                wf = bool(fused_adam and wide and self._wgrad_adam_ok() and getattr(self, '_capturing', False))
+
                 def second_backward(call, net, delay):
-                    """call.backward(use_dgen2, accumulate) with the Adam step of a kernel segment (decoder | down7..4 | down3..0)
-                    enqueued on the chain itself `delay` stages after its last wgrad GEMM: HBM-bound work of one chain beside
-                    the launch-bound kernels of the other (side lanes forked from lane 2 end the capture with "unjoined work"
-                    on this runtime, and wgrad GEMMs on side lanes lose here: measured, profiles/r03_experiments_not_kept.txt)."""
+                    """call.backward(use_dgen2, accumulate) with the network's Adam inside the chain: HBM-bound work of one chain
+                    beside the launch-bound kernels of the other.  With wide wgrads in the captured step the un-split wgrad
+                    launches apply Adam to their kernels themselves (GanAdamFuse; a stage's wgrads follow every dgrad of its
+                    layers) and one small launch pair updates the rest; otherwise a kernel segment (decoder | down7..4 | down3..0)
+                    is updated `delay` stages after its last wgrad GEMM.  Returns True when the vectors have been updated too.
+                    (Side lanes forked from lane 2 end the capture with "unjoined work" on this runtime, and wgrad GEMMs on side
+                    lanes lose here: profiles/r03_experiments_not_kept.txt.)"""
                     if not fused_adam:
                         call.backward(use_dgen2=True, accumulate=True, wgrads=w2)
-                        return
+                        return False
                     P = net.params
+                    if wf:
+                        adam = (self.b1, self.b2)
+                        self.ctx.run(P.adam_begin_ops(self.lr, self.b1, self.b2))
+                        for ops, wops in call.bwd_stages([8, 12], use_dgen2=True, accumulate=True, wgrads='wide', adam=adam):
+                            self.ctx.run(ops + wops)
+                        self.ctx.run(P.adam_rest_ops(call.adam_fused[(True, False, True, 'wide', adam)], self.b1, self.b2))
+                        return True
                     if P._segments is None or len(P._segments) != 3:
                         P.split_kernels_at('down4.kernel', 'up0.kernel')
                     adam = lambda k: self.ctx.run((P.adam_begin_ops(self.lr, self.b1, self.b2) if k == 0 else []) +
@@ -724,6 +778,7 @@ class CycleGANStep(_StepBase):
                             adam(k - delay)
                     for k in range(max(len(stages) - delay, 0), len(stages)):
                         adam(k)
+                    return False
 
                 cx.backward(need_dx=True, accumulate=False, wgrads=w1)    # G_f grads (cycle_x), d/d fake_y
                 dy.backward_input(1, dst=fy.dgen_view())              # adversarial term through D_y(fake_y)
@@ -735,17 +790,19 @@ class CycleGANStep(_StepBase):
                 ea, eb = torch.cuda.Event(), torch.cuda.Event()
                 ea.record(main); eb.record(l2)
                 main.wait_event(eb); l2.wait_event(ea)
-                second_backward(gA, self.Gg, self.adam_delay[0])      # G_g
+                vdone = second_backward(gA, self.Gg, self.adam_delay[0])      # G_g
                 dy.backward_params()
                 if fused_adam:
                     self.Dy.params.adam(self.lr, self.b1, self.b2, stream=main)
-                    self.ctx.run(self.Gg.params.adam_segment_ops(0, self.b1, self.b2, vectors=True, kernels=False))
+                    if not vdone:
+                        self.ctx.run(self.Gg.params.adam_segment_ops(0, self.b1, self.b2, vectors=True, kernels=False))
                 with chain_b():
-                    second_backward(gB, self.Gf, self.adam_delay[1])      # G_f
+                    vdone = second_backward(gB, self.Gf, self.adam_delay[1])      # G_f
                     dx.backward_params()
                     if fused_adam:
                         self.Dx.params.adam(self.lr, self.b1, self.b2, stream=l2)
-                        self.ctx.run(self.Gf.params.adam_segment_ops(0, self.b1, self.b2, vectors=True, kernels=False))
+                        if not vdone:
+                            self.ctx.run(self.Gf.params.adam_segment_ops(0, self.b1, self.b2, vectors=True, kernels=False))
                 if fused_adam:
                     self._adam_done = self.nets()
                 self.ctx.join(main, l2)

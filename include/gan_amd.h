@@ -130,6 +130,22 @@ size_t gan_conv_workspace_bytes(const GanConvDesc* d, int op /*0 conv_fwd,1 conv
  * finishes the layer) */
 int gan_conv_plan_info(const GanConvDesc* d, int op, int32_t* info);
 
+/* Optional: the wgrad launch itself applies the optimiser step (TF-form Adam, base_gan.py:247-252 / pix2pix.py:213-216) to the
+ * kernel it has just differentiated and refreshes its typed NK copies - the fp32 gradient is then neither written nor read back
+ * (dw stays untouched).  Bit-identical to gan_conv_wgrad followed by gan_adam_prepare_multi.  gan_adam_begin must have run for
+ * this step (lr_t).  Not for fp16 steps with dynamic loss scaling (their update waits for the whole-step inf/nan check and
+ * un-scales).  Honoured only when gan_wgrad_adam_fused() returns 1 for the descriptor (un-split launch of the 16-bit
+ * LDS-DMA kernel, accumulate == 0, channel counts multiples of 8); otherwise the launch behaves as without it. */
+typedef struct GanAdamFuse {
+  float* master;             /* fp32 [16][big_c][small_c]: the layout of dw */
+  float* m;
+  float* v;
+  void* nk_native;           /* [16][big_c][small_c] dtype, or NULL */
+  void* nk_transposed;       /* [16][small_c][big_c] dtype, or NULL */
+  const float* lr_t;         /* device scalar written by gan_adam_begin */
+  float beta1, beta2, eps;
+} GanAdamFuse;
+
 typedef struct GanWgradDesc {
   uint32_t struct_size;  /* sizeof(GanWgradDesc) of the caller's build */
   int32_t dtype;
@@ -145,12 +161,14 @@ typedef struct GanWgradDesc {
                             captured step): the planner then prefers fewer, longer blocks (less slab traffic; the other streams get
                             the rest of the chip).  2 = beside a MIRROR chain doing the same work (the two-chain CycleGAN step):
                             the K-split target is halved as well. */
+  const GanAdamFuse* adam_fuse; /* optional, see above */
 } GanWgradDesc;
 /* Kernel gradient of Conv2D / Conv2DTranspose (GradientTape.gradient w.r.t. trainable_variables,
  * pix2pix.py:210-211, cycle_gan.py:252-260). */
 int gan_conv_wgrad(const GanWgradDesc* d, gan_stream_t stream);
 size_t gan_wgrad_workspace_bytes(const GanWgradDesc* d);
 int gan_wgrad_plan_info(const GanWgradDesc* d, int32_t* info /* {TA, TB, splitM, fold} */);
+int gan_wgrad_adam_fused(const GanWgradDesc* d);   /* 1: d->adam_fuse will be honoured, 0: not, < 0: error code */
 
 /* Produce typed NK copies from a fp32 Keras-layout master [16][A][B]:
  * nk_native [16][A][pad8(B)] and nk_transposed [16][B][pad8(A)] (either may be NULL). */

@@ -632,6 +632,50 @@ def test_wgrad_pingpong_128_columns_matches_128_tile_kernel(ctx, planner_options
     assert np.abs(out[1]).max() > 100 and np.array_equal(out[0], out[1])
 
 
+def test_wgrad_with_fused_adam_equals_wgrad_then_adam(ctx):
+    """GanAdamFuse: an un-split wgrad launch that applies TF-form Adam to its kernel and refreshes both NK copies leaves exactly
+    (bit for bit) what gan_conv_wgrad followed by gan_adam_prepare_multi leaves, over two steps; a split launch declines."""
+    from gan_amd import _lib as L
+    from gan_amd.nets import Buf, ParamSet
+    if ctx.dtype != 'bf16':
+        pytest.skip("bf16 only: fp32 has no LDS-DMA 16-bit epilogue, fp16 steps keep the whole-step inf/nan check before any update")
+    N, H, ci, co = 2, 8, 512, 512
+    rng = np.random.default_rng(17)
+    x, dy = q(ctx, rng.standard_normal((N, H, H, ci))), q(ctx, 0.1 * rng.standard_normal((N, H // 2, H // 2, co)))
+    xb, xv = dev(ctx, x)
+    dyb, dyv = dev(ctx, dy)
+    w0 = (0.05 * rng.standard_normal((4, 4, ci, co))).astype(np.float32)
+    sets = []
+    for fused in (False, True):
+        P = ParamSet(ctx, [('k.kernel', (4, 4, ci, co), True), ('k.beta', (co,), True)])
+        P.load_numpy({'k.kernel': w0, 'k.beta': np.zeros(co, np.float32)})
+        for step in range(2):
+            if fused:
+                ctx.run(P.adam_begin_ops(2e-4, 0.5, 0.999))
+                af = P.adam_fuse_desc('k.kernel', 0.5, 0.999)
+                d = L.GanWgradDesc(ctx.dt, 2, xv, dyv, P.ptr('k.kernel', 'grad'), ci, co, 0, ctx.ws_ptr, ctx.ws_bytes, 0, C.addressof(af))
+                assert ctx.lib.gan_wgrad_adam_fused(C.byref(d)) == 1
+                assert ctx.lib.gan_conv_wgrad(C.byref(d), ctx.stream()) == 0
+                ctx.run(P.adam_rest_ops(['k.kernel'], 0.5, 0.999))
+            else:
+                d = L.GanWgradDesc(ctx.dt, 2, xv, dyv, P.ptr('k.kernel', 'grad'), ci, co, 0, ctx.ws_ptr, ctx.ws_bytes)
+                assert ctx.lib.gan_conv_wgrad(C.byref(d), ctx.stream()) == 0
+                P.adam(2e-4, 0.5, 0.999)
+        torch.cuda.synchronize()
+        sets.append([t.clone() for t in (P.master, P.m, P.v, P.nat['k.kernel'], P.tr['k.kernel'], P.step)])
+        if fused:
+            assert float(P.grad[:16 * ci * co].abs().max()) == 0.0          # the fused launch leaves dw alone
+    for a, b in zip(*sets):
+        assert torch.equal(a, b)
+    assert float((sets[0][0][:16 * ci * co] - torch.from_numpy(w0).to(ctx.device).flatten()).abs().max()) > 1e-4      # it did move
+    # a launch that splits its reduction (big map, few channels) keeps the gradient in dw and leaves the update to the caller
+    xs, dys = Buf(ctx, 4, 64, 64, 64), Buf(ctx, 4, 32, 32, 64)
+    P2 = ParamSet(ctx, [('s.kernel', (4, 4, 64, 64), True)])
+    af = P2.adam_fuse_desc('s.kernel', 0.5, 0.999)
+    d = L.GanWgradDesc(ctx.dt, 2, xs.view(), dys.view(), P2.ptr('s.kernel', 'grad'), 64, 64, 0, ctx.ws_ptr, ctx.ws_bytes, 0, C.addressof(af))
+    assert ctx.lib.gan_wgrad_adam_fused(C.byref(d)) == 0
+
+
 @pytest.mark.parametrize("kind,groups_of", [('batchnorm', lambda n: 1), ('batchnorm', lambda n: 2), ('instancenorm', lambda n: n)])
 @pytest.mark.parametrize("act,drop", [('lrelu', False), ('relu', True)])
 def test_norm_act_fwd_bwd(ctx, kind, groups_of, act, drop):
