@@ -440,6 +440,7 @@ def _rccl_one_rank_worker(port, q, model):
         for ddp in (False, True):
             ctx = Ctx('cuda:0', 'bf16')
             st = Pix2PixStep(ctx, 2, 256, 1, lam=100.0, seed=123) if model == 'pix2pix' else CycleGANStep(ctx, 1, 256, 1, lam=10.0, seed=123)
+            st.fused_wgrad_adam = False   # (the one-GPU default leaves no fp32 gradient of the big kernels behind: this test reads them)
             st.wide_wgrads = False        # (CycleGAN one-GPU default: one wgrad GEMM over a generator's three invocations - another summation
             if ddp:                       # order than the write + accumulate pair of the phased schedule; compared in its own test)
                 st.sync = GradSync([n.params.grad for n in st.nets()], compress_bf16=(wire == 'bf16'), lib=ctx.lib, rehearse=True)
