@@ -331,11 +331,7 @@ static int plan_wgrad(const GanWgradDesc* d, WgradPlan* pl, bool allow_swap = tr
   const int wtarget = gan_opt("wgrad.split_target");
   // fold mode streams the SMALL tensor once: HBM-bound, wants many blocks; beside a mirror chain (concurrent == 2) half the chip is the target
   const long long target = p.fold ? 1024 : (d->concurrent >= 2 ? (wtarget + 1) / 2 : wtarget);
-  // a launch that could carry the optimiser step (GanAdamFuse) and covers the chip with one block per CU stays un-split: the
-  // slab round trip, the reduce launch AND the gradient round trip of the stand-alone Adam pass go away
-  const bool adam_unsplit = d->adam_fuse && allow_swap && !p.fold && !p.swap && !d->accumulate && d->dtype != GAN_F32 && taps == 16 &&
-                            TA == 128 && TB == 128 && blocks >= 256;
-  if (blocks < target && !adam_unsplit) {
+  if (blocks < target) {
     splits = (int)((target + blocks - 1) / blocks);
     int maxs = p.kchunks / 4; if (maxs < 1) maxs = 1;
     if (splits > maxs) splits = maxs;

@@ -98,9 +98,8 @@ class _StepBase:
         self._early_adam, self._adam_done, self._adam_wfused = None, (), None
 
     def _wgrad_adam_ok(self):
-        """GanAdamFuse schedules: one GPU, no loss scaling, 16-bit storage, lanes on."""
-        return bool(getattr(self, 'fused_wgrad_adam', False) and self.sync is None and self.ctx.ls is None and self.ctx.lanes
-                    and self.ctx.dtype != 'f32')
+        """GanAdamFuse schedules: one GPU, no loss scaling, 16-bit storage."""
+        return bool(getattr(self, 'fused_wgrad_adam', False) and self.sync is None and self.ctx.ls is None and self.ctx.dtype != 'f32')
 
     def _prebuild_fused_adam(self):
         pass
@@ -369,6 +368,14 @@ class Pix2PixStep(_StepBase):
                 self.ctx.join(main, lane3)
                 if self._early_adam is not None and self.adam_lane != 3:
                     self.ctx.join(main, self.ctx.lane_stream(self.adam_lane))
+            elif self._wgrad_adam_ok() and getattr(self, '_capturing', False) and getattr(self, '_updating', False) and not self.early_adam:
+                # one stream (profiling runs): the same fused-Adam wgrad launches, a stage's wgrads behind its dgrad chain
+                adam = (self.b1, self.b2)
+                self.ctx.run(self.G.params.adam_begin_ops(self.lr, self.b1, self.b2))
+                for ops, wops in g.bwd_stages(list(self.wgrad_cuts), use_dgen2=True, adam=adam):
+                    self.ctx.run(ops + wops)
+                self._adam_wfused = {self.G: g.adam_fused[(True, False, False, 'own', adam)]}
+                d.backward_params()
             else:
                 g.backward(use_dgen2=True)
                 d.backward_params()
