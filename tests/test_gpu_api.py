@@ -75,6 +75,35 @@ def test_pix2pix_cli_data_parallel_two_ranks(tmp_path):
     assert sorted(os.listdir(os.path.join(run, 'training_checkpoints'))) == ['checkpoint', 'ckpt-1.data-00000-of-00001', 'ckpt-1.index']
 
 
+def test_cyclegan_cli_data_parallel_two_ranks(tmp_path):
+    """`torchrun --nproc-per-node 2 cycle_gan.py --train`: two ranks on the one GPU over gloo through the phased schedule (both
+    generators' exchanges after the two chains' second backward, both discriminators' after their parameter passes); rank 0
+    alone writes the run directory; main() checks that the four networks of both replicas end bit-identical."""
+    import socket
+    import subprocess
+    import sys
+    rng = np.random.default_rng(2)
+    dx, dy = str(tmp_path / 'X'), str(tmp_path / 'Y')
+    _make_singles(dx, 7, rng)                      # 1 test + 1 validation + 5 training images -> 2 per rank
+    _make_singles(dy, 7, rng)
+    out = str(tmp_path / 'out')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(root, 'cycle_gan.py'), '--input-images', dx, '--target-images', dy, '--output', out,
+           '--train', '--epochs', '1', '--batch-size', '1', '--test-img', '1', '--validation-size', '0.2', '--logging', 'false',
+           '--dist-backend', 'gloo']
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    assert 'data-parallel run: 2 ranks, replicas in sync.' in r.stdout
+    runs = os.listdir(out)
+    assert len(runs) == 1                                        # rank 1 created nothing
+    tm = json.load(open(os.path.join(out, runs[0], 'logs', 'train_metrics.json')))
+    assert len(tm) == 7 and all(len(v) == 1 and np.isfinite(v[0]) for v in tm.values())
+
+
 def test_pix2pix_class_surface_and_checkpoint_roundtrip(tmp_path):
     from gan_amd.checkpoint import Checkpoint, CheckpointManager, latest_checkpoint
     from gan_amd.pix2pix import Pix2Pix
