@@ -212,9 +212,12 @@ class ParamSet:
     def split_kernels_at(self, *cut_names):
         """Update segments of the kernel tensors, cut before each of `cut_names` (own tables), so that a segment can be
         updated as soon as ITS gradients are complete."""
-        names = list(self.nat)
-        ks = [0] + [names.index(n) for n in cut_names] + [len(names)]
-        self._segments = [self._kernel_table(names[a:b]) for a, b in zip(ks[:-1], ks[1:])]
+        cache = self.__dict__.setdefault('_segment_tables', {})   # kept for good: captured graphs of several step objects (batch
+        if cut_names not in cache:                                # sizes) hold the device pointers of these tables
+            names = list(self.nat)
+            ks = [0] + [names.index(n) for n in cut_names] + [len(names)]
+            cache[cut_names] = [self._kernel_table(names[a:b]) for a, b in zip(ks[:-1], ks[1:])]
+        self._segments = cache[cut_names]
 
     def adam_begin_ops(self, lr, b1, b2):
         return [(self.ctx.lib.gan_adam_begin, (self.step.data_ptr(), self.lr_t.data_ptr(), lr, b1, b2, self.ctx.ls_ptr), "adam_begin")]
@@ -246,14 +249,16 @@ class ParamSet:
         """Adam of everything the wgrad launches did NOT update themselves: the other kernels (own table) and the vectors.
         gan_adam_begin must already have run this step (before the first fused wgrad)."""
         key = frozenset(fused_names)
-        if getattr(self, '_rest_key', None) != key:
+        cache = self.__dict__.setdefault('_rest_tables', {})      # one device table per fused set, kept for good: captured graphs
+        if key not in cache:                                      # of several step objects (batch sizes) hold their pointers
             names = [n_ for n_ in self.nat if n_ not in key]
-            self._rest_key, self._rest = key, (self._kernel_table(names) if names else None)
+            cache[key] = self._kernel_table(names) if names else None
+        rest = cache[key]
         lib = self.ctx.lib
         ptrs = (self.master.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), self.grad.data_ptr())
         ops = []
-        if self._rest is not None:
-            ops.append((lib.gan_adam_prepare_multi, self._rest[1] + ptrs + (self.lr_t.data_ptr(), b1, b2, eps, 1.0, self.ctx.ls_ptr, 0), "adam_prepare_multi"))
+        if rest is not None:
+            ops.append((lib.gan_adam_prepare_multi, rest[1] + ptrs + (self.lr_t.data_ptr(), b1, b2, eps, 1.0, self.ctx.ls_ptr, 0), "adam_prepare_multi"))
         nvec = self.total - self.vec_start
         if nvec > 0:
             vptrs = tuple(p_ + 4 * self.vec_start for p_ in ptrs)

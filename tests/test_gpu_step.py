@@ -122,6 +122,35 @@ def test_pix2pix_graph_replay_matches_eager():
     assert torch.allclose(w_eager, st2.G.params.master, atol=1e-6)
 
 
+def test_two_batch_sizes_share_the_networks_captured():
+    """A run whose last batch is smaller captures a second step object on the same networks (Pix2Pix._step_for): the graphs of
+    both must stay valid side by side - device tables of the optimiser launches (per fused-kernel set, per segment cut) are kept
+    for good, not rebuilt per step object - and interleaved replays must equal the same sequence of eager steps."""
+    from gan_amd.steps import Pix2PixStep
+    ctx, stA, Gp, Dp, inp, tar, masks = _setup_p2p('bf16', B=4)
+    stB = Pix2PixStep(ctx, 2, 256, 1, lam=100.0, seed=123, nets=(stA.G, stA.D))
+    stB.g.set_dropmasks(O.dropout_masks(2, 256, seed=6))
+    stA.g.set_dropmasks(O.dropout_masks(4, 256, seed=5))
+    xa = [torch.from_numpy(t).to(ctx.device) for t in O.synthetic_pair(4, 256, 1, seed=31)]
+    xb = [torch.from_numpy(t).to(ctx.device) for t in O.synthetic_pair(2, 256, 1, seed=32)]
+
+    def reset():
+        stA.G.params.load_numpy(Gp); stA.D.params.load_numpy(Dp)
+        for ps in (stA.G.params, stA.D.params):
+            ps.m.zero_(); ps.v.zero_(); ps.step.zero_()
+            for k, t in ps.state.items():
+                t.fill_(0.0 if 'mean' in k else 1.0)
+    reset()
+    l_eager = [st.train_step(*x, True).cpu().numpy().copy() for st, x in ((stA, xa), (stB, xb), (stA, xa), (stB, xb))]
+    w_eager = [stA.G.params.master.clone(), stA.D.params.master.clone()]
+    ra = stA.capture(training=True)
+    rb = stB.capture(training=True)               # (captured after A: A's graph must survive B's tables)
+    reset()
+    l_graph = [r(*x)[:4].cpu().numpy().copy() for r, x in ((ra, xa), (rb, xb), (ra, xa), (rb, xb))]
+    assert np.allclose(l_eager, l_graph, rtol=1e-5), (l_eager, l_graph)
+    assert torch.allclose(w_eager[0], stA.G.params.master, atol=1e-6) and torch.allclose(w_eager[1], stA.D.params.master, atol=1e-6)
+
+
 @pytest.mark.parametrize("dtype", ['f32', 'bf16'])
 def test_cyclegan_train_step_parity(dtype):
     from gan_amd.nets import Ctx
