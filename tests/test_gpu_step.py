@@ -151,6 +151,36 @@ def test_two_batch_sizes_share_the_networks_captured():
     assert torch.allclose(w_eager[0], stA.G.params.master, atol=1e-6) and torch.allclose(w_eager[1], stA.D.params.master, atol=1e-6)
 
 
+def test_cyclegan_graph_replay_matches_eager():
+    """The captured CycleGAN step (two chains, wide wgrads, Adam inside the un-split wgrad launches) against the same steps run
+    eagerly (two chains, wide wgrads, separate Adam passes): same losses, same weights of all four networks after two steps."""
+    from gan_amd.nets import Ctx
+    from gan_amd.steps import CycleGANStep
+    rx, ry = O.synthetic_pair(1, 256, 1, seed=41)
+    res = []
+    for graph in (False, True):
+        ctx = Ctx('cuda:0', 'bf16')
+        st = CycleGANStep(ctx, 1, 256, 1, lam=10.0, seed=7)
+        w0 = [n.params.master.clone() for n in st.nets()]
+        x = [torch.from_numpy(rx).to(ctx.device), torch.from_numpy(ry).to(ctx.device)]
+        run = st.capture(training=True) if graph else (lambda a, b: st.train_step(a, b, True))
+        for n_, w_ in zip(st.nets(), w0):          # (capture ran warm-up steps)
+            n_.params.master.copy_(w_); n_.params.prepare()
+            n_.params.m.zero_(); n_.params.v.zero_(); n_.params.step.zero_()
+        for call in vars(st).values():
+            if hasattr(call, 'mask_draws'):
+                call.mask_draws.zero_()
+        losses = [run(*x)[:7].cpu().numpy().copy() for _ in range(2)]
+        torch.cuda.synchronize()
+        res.append((losses, [n.params.master.clone() for n in st.nets()]))
+        if graph:
+            assert st._wide is True and any(len(c.adam_fused) and any(c.adam_fused.values()) for c in (st.gA, st.gB))     # the fused launches were in it
+    (le, we), (lg, wg) = res
+    assert np.allclose(le, lg, rtol=1e-5), (le, lg)
+    for a, b in zip(we, wg):
+        assert torch.allclose(a, b, atol=1e-6), float((a - b).abs().max())
+
+
 @pytest.mark.parametrize("dtype", ['f32', 'bf16'])
 def test_cyclegan_train_step_parity(dtype):
     from gan_amd.nets import Ctx
