@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Two independent runs of N graph-replayed steps (all lanes on, auto dropout masks) must end in bit-identical losses and
-weights: the multi-lane schedule is race-free and every reduction has a fixed order.  python tools/soak_determinism.py [N] [model]"""
+weights: the multi-lane schedule is race-free and every reduction has a fixed order.  python tools/soak_determinism.py [N] [model] [batch]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -9,10 +9,11 @@ from gan_amd.steps import Pix2PixStep, CycleGANStep
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
 model = sys.argv[2] if len(sys.argv) > 2 else 'pix2pix'
+batch = int(sys.argv[3]) if len(sys.argv) > 3 else (16 if model == 'pix2pix' else 4)
 res = []
 for run in range(2):
     ctx = Ctx('cuda:0', 'bf16')
-    st = Pix2PixStep(ctx, 16, 256, 1, lam=100.0, seed=123) if model == 'pix2pix' else CycleGANStep(ctx, 4, 256, 1, lam=10.0, seed=123)
+    st = Pix2PixStep(ctx, batch, 256, 1, lam=100.0, seed=123) if model == 'pix2pix' else CycleGANStep(ctx, batch, 256, 1, lam=10.0, seed=123)
     g = torch.Generator(device='cpu').manual_seed(7)
     x = [(torch.randint(0, 256, (st.B, 256, 256, 1), generator=g).float() / 127.5 - 1.0).to(ctx.device) for _ in range(2)]
     w0 = [n.params.master.clone() for n in st.nets()]
