@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get("GAN_AMD_LIB") or os.path.join(_HERE, "libgan_amd.so")
 
 F32, BF16, F16 = 0, 1, 2
 ACT_NONE, ACT_LRELU, ACT_RELU, ACT_TANH = 0, 1, 2, 3
+E_ARG, E_SHAPE, E_WORKSPACE = -1, -2, -3
 ACTS = {None: ACT_NONE, 'none': ACT_NONE, 'lrelu': ACT_LRELU, 'relu': ACT_RELU, 'tanh': ACT_TANH}
 
 

@@ -1618,6 +1618,9 @@ static int run_gemm(const GanConvDesc* d, int op, gan_stream_t stream) {
   hipStream_t st = (hipStream_t)stream;
   const int fam = thin_family(d, op, pl.p);
   if (pl.bf_requested && (fam || !pl.p.bf_mode)) return GAN_E_SHAPE;   // the caller must consult gan_conv_plan_info()[4] first
+  // ... and likewise for GanNormFuse: the caller drops its follow-up normalisation launches on the strength of plan_info()[4] == -1,
+  // so a request this launch's plan cannot honour (a planner option changed since, another shape) must fail, not silently skip
+  if (d->norm_fuse && (fam || !pl.p.skn)) return GAN_E_SHAPE;
   if (!fam && pl.p.stats && pl.stats_chunks > 0 && (size_t)d->stats_groups * pl.stats_chunks * pl.p.stats_C * 2 * sizeof(float) > d->stats_partial_bytes)
     return GAN_E_WORKSPACE;                                            // the caller's partial-sums region is too small for this plan
   if (fam) return thin_launch(fam, d, pl.p, st);   // <= 8-channel streaming layers

@@ -559,7 +559,9 @@ __global__ __launch_bounds__(64 * WAVES_A * WAVES_B) void wgrad_dma_kernel(const
     // adam_prep_multi_kernel does: straight from the accumulator layout it was 64-byte pieces of 16 rows per instruction and
     // the launch took twice as long as the stand-alone pass), writes the native NK rows, leaves the UPDATED weights in LDS and
     // transposes them into the other NK copy.  Same per-element arithmetic as the stand-alone kernels (gan_adam1); dw is not written.
-    if constexpr (sizeof(T) == 2 && TA == 128 && TB == 128 && WAVES_A == 2 && WAVES_B == 2) {
+    if constexpr (!(sizeof(T) == 2 && TA == 128 && TB == 128 && WAVES_A == 2 && WAVES_B == 2)) {
+      __builtin_trap();                                      // launch_wdma refuses p.adam for every other instantiation (GAN_E_SHAPE)
+    } else {
       constexpr int LP = 129;                                // padded row of the 64 x 128 fp32 half tile
       float* tile = (float*)smem;
       const float lr = *p.alr;
@@ -650,6 +652,7 @@ static int launch_wdma(const WgradPlan& pl, unsigned bigbytes, unsigned smallbyt
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
+  if (pl.p.adam && !(sizeof(T) == 2 && TA == 128 && TB == 128 && WA == 2 && WB == 2)) return GAN_E_SHAPE;   // only that epilogue carries GanAdamFuse
   hipLaunchKernelGGL(kern, pl.grid, dim3(64 * WA * WB), smem, st, pl.p, bigbytes, smallbytes);
   GAN_CHECK_LAUNCH();
   return 0;
@@ -907,6 +910,9 @@ int gan_conv_wgrad(const GanWgradDesc* d, gan_stream_t stream) {
   int rc = plan_wgrad(d, &pl, dma_ok);         // the role-swapped plan exists only in the LDS-DMA kernel
   if (rc) return rc;
   if (pl.slab_bytes > d->workspace_bytes || (pl.slab_bytes && !d->workspace)) return GAN_E_WORKSPACE;
+  // the caller skips its own optimiser pass for this kernel on the strength of gan_wgrad_adam_fused() == 1: a request this
+  // launch's plan cannot honour (a planner option changed since the query) must fail, not leave the kernel without its update
+  if (d->adam_fuse && !(pl.p.adam && !pl.pp)) return GAN_E_SHAPE;
   if (pl.p.swap) { const size_t t = bb; bb = sb; sb = t; }
   if (pl.pp) rc = d->dtype == GAN_F16 ? launch_wpp<f16_t>(pl, (unsigned)bb, (unsigned)sb, st) : launch_wpp<bf16_t>(pl, (unsigned)bb, (unsigned)sb, st);
   else if (dma_ok) rc = d->dtype == GAN_F32 ? launch_wgrad_dma<float>(pl, (unsigned)bb, (unsigned)sb, st)

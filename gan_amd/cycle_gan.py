@@ -242,9 +242,12 @@ def main(opt):
                 if info.world > 1:
                     print(f"data-parallel run: {info.world} ranks, replicas in sync.")
         print("Done.")
-    finally:
+    except BaseException:
         run.close()
-        ddp.shutdown(info)
+        ddp.shutdown(info, failed=True)      # no barrier on the way out of an exception: the peers are inside other collectives
+        raise
+    run.close()
+    ddp.shutdown(info)
 
 
 if __name__ == '__main__':

@@ -213,10 +213,22 @@ def assert_replicas_in_sync(param_sets, info: DistInfo):
         raise RuntimeError(f"data-parallel replicas diverged: weight checksums differ across ranks ({lo.tolist()} .. {hi.tolist()})")
 
 
-def shutdown(info: DistInfo):
-    """Leave the process group together (a rank that exits early makes its peers' pending collectives fail)."""
-    if info is not None and info.world > 1 and dist.is_initialized():
+def shutdown(info: DistInfo, failed: bool = False):
+    """Leave the process group.  Success path: together, behind a barrier (a rank that exits early makes its peers' pending
+    collectives fail).  failed=True (this rank is unwinding an exception): NO barrier - its peers sit in a gradient exchange of
+    another size and a mismatched collective hangs RCCL until the watchdog fires; the group is torn down (aborted where the
+    backend can) and the exception propagates, so the launcher sees a non-zero exit and ends the other ranks."""
+    if info is None or info.world <= 1 or not dist.is_initialized():
+        return
+    if failed:
+        abort = getattr(dist.distributed_c10d, '_abort_process_group', None)     # (torch >= 2.6: ncclCommAbort, does not wait for peers)
         try:
-            dist.barrier()
-        finally:
-            dist.destroy_process_group()
+            if abort is not None:
+                abort()
+        except Exception:
+            pass                      # the process is on its way out with the original exception either way
+        return
+    try:
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()

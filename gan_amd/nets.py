@@ -98,10 +98,47 @@ class Ctx:
 
     def assert_lanes_joined(self):
         bad = [i + 1 for i, s in enumerate(self.side) if s.open_in_capture]
-        for s in self.side:
-            s.open_in_capture = False
-        if bad:
+        if bad:      # (the flags stay set: capture_graph() joins exactly these lanes before the capture ends)
             raise L.GanAmdError(f"step schedule bug: lane(s) {bad} were forked during graph capture and never joined")
+
+    def join_open_lanes(self):
+        """Join every lane that is still forked into the running capture back into the capturing stream (best effort: a capture
+        that a HIP error has already invalidated refuses further calls)."""
+        cur = torch.cuda.current_stream(self.device)
+        for s in self.side:
+            if s.open_in_capture:
+                try:
+                    cur.wait_stream(s)
+                except Exception:
+                    pass
+                s.open_in_capture = False
+
+    def capture_graph(self, fn, error_mode="thread_local"):
+        """fn() captured into a hipGraph.  ROCm 7.2 ends a capture that still has a forked, unjoined lane with a crash inside
+        hipStreamEndCapture (or hipErrorStreamCaptureUnjoined) instead of a clean error, so NO path may leave the capture block
+        with open lanes: an exception raised inside fn() - a kernel entry point's error code, the lane guard itself - is caught
+        here, the open lanes are joined, the capture is ended and the exception comes back as GanAmdError."""
+        gr = torch.cuda.CUDAGraph()
+        err = None
+        try:
+            with torch.cuda.graph(gr, capture_error_mode=error_mode):
+                try:
+                    fn()
+                    self.assert_lanes_joined()
+                except BaseException as e:      # noqa: BLE001 - re-raised below, after the capture has been closed safely
+                    err = e
+                    self.join_open_lanes()
+        except Exception as e2:                 # capture_end itself failed (the capture had been invalidated)
+            if err is None:
+                raise
+            raise L.GanAmdError(f"graph capture failed: {err!r}; ending the capture then reported: {e2!r}") from err
+        if err is not None:
+            if isinstance(err, L.GanAmdError):
+                raise err
+            if not isinstance(err, Exception):
+                raise err                       # KeyboardInterrupt / SystemExit pass through unchanged
+            raise L.GanAmdError(f"graph capture failed: {err!r}") from err
+        return gr
 
     def lane_stream(self, lane):
         return torch.cuda.current_stream(self.device) if lane == 0 else self.side[lane - 1]
@@ -448,6 +485,8 @@ class _Builder:
         self.lib.gan_conv_plan_info(C.byref(d), opi, info)
         self.last_bwd_fused = 0
         self.last_full = info[4] == -1       # GanNormFuse honoured: the launch finishes the layer (no norm ops follow)
+        if not self.last_full:               # a request is either honoured or dropped HERE: the library refuses one it cannot honour
+            d.norm_fuse = None
         if bwd_fuse is not None:
             self.last_stats_chunks = 0
             self.last_bwd_fused = max(info[4], 0)

@@ -123,14 +123,13 @@ class _StepBase:
             return self._capture_phased(training)
         if training:
             self._prebuild_fused_adam()         # (op lists and device tables of the captured schedule: no uploads inside the capture)
-        g1 = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g1, capture_error_mode=CAPTURE_MODE):
+        def body():
             self._capturing = True          # (schedules that leave no fp32 gradients behind are for the replayed step only)
             try:
                 self._run(*self._static_in, training=training)
             finally:
                 self._capturing = False
-            self.ctx.assert_lanes_joined()
+        g1 = self.ctx.capture_graph(body, CAPTURE_MODE)      # (an exception inside leaves no forked lane behind: Ctx.capture_graph)
         self._graphs = (g1, None, None)
 
         def replay(*inputs):
@@ -158,11 +157,7 @@ class _StepBase:
         lane4 = ctx.lane_stream(4)
 
         def graph(fn):
-            gr = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gr, capture_error_mode=CAPTURE_MODE):
-                fn()
-                ctx.assert_lanes_joined()
-            return gr
+            return ctx.capture_graph(fn, CAPTURE_MODE)
 
         G = [graph(lambda pid=pid: self._forward_backward(*self._static_in, training, phase=pid)) for pid, _ in phases]
         if fp16:
@@ -417,11 +412,7 @@ class Pix2PixStep(_StepBase):
         torch.cuda.synchronize()
 
         def graph(fn):
-            gr = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gr, capture_error_mode=CAPTURE_MODE):
-                fn()
-                ctx.assert_lanes_joined()
-            return gr
+            return ctx.capture_graph(fn, CAPTURE_MODE)
 
         def fork_join(side_ops, side_stream, main_fn, bucket=None):
             """side_ops (a stage's wgrad GEMMs) and then the cast of `bucket` to the wire format on the side stream,

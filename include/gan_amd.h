@@ -72,8 +72,11 @@ typedef struct GanBwdFuse {
  * Forward entry points (with GanConvDesc.stats_groups): y = conv output as usual, out = act(dropout(gamma*(y-mean)*rstd+beta))
  * (Conv -> BN|IN -> [Dropout] -> act of base_gan.py:77-87, :106-120); mean / rstd / moving averages are written as
  * gan_norm_stats would.  dgrad entry points (with GanConvDesc.bwd_fuse, which names the layer below): out = dy of that layer,
- * dgamma / dbeta accumulated; the first bwd_fuse->cols channels of GanConvDesc.y then receive dz as usual.
- * Honoured only when gan_conv_plan_info()[4] == -1; otherwise the launch behaves as without it. */
+ * dgamma / dbeta accumulated; the first bwd_fuse->cols channels of GanConvDesc.y are then NOT written (dz stays in registers;
+ * channels >= cols receive the plain gradient as usual).
+ * Honoured only when gan_conv_plan_info()[4] == -1: the caller asks first and passes norm_fuse = NULL otherwise - a launch
+ * whose plan cannot honour a non-NULL norm_fuse returns GAN_E_SHAPE (the caller would have dropped the layer's own
+ * normalisation launches on the strength of the query). */
 typedef struct GanNormFuse {
   GanTensor out;
   const float* gamma;
@@ -134,8 +137,9 @@ int gan_conv_plan_info(const GanConvDesc* d, int op, int32_t* info);
  * kernel it has just differentiated and refreshes its typed NK copies - the fp32 gradient is then neither written nor read back
  * (dw stays untouched).  Bit-identical to gan_conv_wgrad followed by gan_adam_prepare_multi.  gan_adam_begin must have run for
  * this step (lr_t).  Not for fp16 steps with dynamic loss scaling (their update waits for the whole-step inf/nan check and
- * un-scales).  Honoured only when gan_wgrad_adam_fused() returns 1 for the descriptor (un-split launch of the 16-bit
- * LDS-DMA kernel, accumulate == 0, channel counts multiples of 8); otherwise the launch behaves as without it. */
+ * un-scales).  Honoured only when gan_wgrad_adam_fused() returns 1 for the descriptor (16-bit storage, accumulate == 0,
+ * channel counts multiples of 8, a plan whose last kernel can carry it); the caller asks first and passes adam_fuse = NULL
+ * otherwise - gan_conv_wgrad returns GAN_E_SHAPE for a non-NULL adam_fuse its plan cannot honour. */
 typedef struct GanAdamFuse {
   float* master;             /* fp32 [16][big_c][small_c]: the layout of dw */
   float* m;
@@ -349,8 +353,8 @@ const char* gan_version(void);
  * GAN_E_ARG.  Keys (default): conv.big_tiles (1), conv.q128 (55), conv.q256n (80), conv.big_min_blocks (128),
  * conv.tall64 (1), conv.pingpong (1), conv.parity_patch (1), conv.parity_patch_max_n (64),
  * conv.parity_patch_min_blocks (192), conv.split_target (256), conv.split_target_skinny (1024),
- * conv.split_target_big (256), conv.split_min_ktiles (4), conv.split_max (64), conv.bwd_fuse_tile (3: the fused backward
- * epilogue rides on 64-column tile epilogues only; 0 never, 1 on every tile, 2 not on 64-column tiles), conv.thin (7: bit 0
+ * conv.split_target_big (256), conv.split_min_ktiles (4), conv.split_max (64), conv.bwd_fuse_tile (1: the fused backward
+ * epilogue rides on every tile epilogue; 0 never, 2 not on 64-column tiles, 3 on 64-column tiles only), conv.thin (7: bit 0
  * streaming kernels for the <= 8-channel layers, bit 1 thin-N, bit 2 thin-K), conv.norm_fuse (1), conv.thin_fused (1), wgrad.tile256 (0), wgrad.pingpong (1),
  * wgrad.pingpong_min_rows (0 = automatic), wgrad.pingpong_128 (1), wgrad.pingpong_min_gflop (30),
  * wgrad.split_target (512). */

@@ -180,6 +180,40 @@ def _ddp_worker(rank, world, port, q):
     ddp.shutdown(info)
 
 
+def _ddp_failing_worker(rank, world, port):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from gan_amd import ddp
+    info = ddp.DistInfo(rank, world, 'cpu')
+    try:
+        if rank == 1:
+            raise ValueError("bad input file on this rank")
+        dist.all_reduce(torch.ones(1 << 16))          # the healthy rank sits in a gradient exchange
+    except BaseException:
+        ddp.shutdown(info, failed=True)               # (what pix2pix.main / cycle_gan.main do on the way out of an exception)
+        raise
+    ddp.shutdown(info)
+
+
+def test_failing_rank_leaves_without_a_barrier():
+    """A rank that raises must not issue a barrier while its peers sit in another collective (a mismatched collective hangs RCCL
+    until the watchdog fires): it exits non-zero at once and the launcher tears the job down."""
+    import time
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    port = 29300 + os.getpid() % 500
+    procs = [ctx.Process(target=_ddp_failing_worker, args=(r, 2, port)) for r in range(2)]
+    t0 = time.time()
+    for p in procs:
+        p.start()
+    procs[1].join(timeout=90)
+    assert procs[1].exitcode not in (None, 0) and time.time() - t0 < 90      # left promptly, with the error
+    procs[0].join(timeout=90)                          # gloo notices the lost peer; torchrun would have killed it anyway
+    if procs[0].exitcode is None:
+        procs[0].kill()
+
+
 def test_gradsync_world2_gloo():
     import torch.multiprocessing as mp
     ctx = mp.get_context('spawn')

@@ -508,6 +508,9 @@ def test_split_k_layer_finished_by_its_slab_reduce(ctx, case, planner_options):
         assert ctx.lib.gan_conv_plan_info(C.byref(d), opi, info) == 0
         assert info[2] > 1, "shape chosen to be split-K"
         assert (info[4] == -1) == bool(fuse), list(info)
+        if not fuse:          # a request the plan cannot honour is refused (the caller would otherwise skip the layer's normalisation)
+            assert fn(C.byref(d), ctx.stream()) == L.E_SHAPE
+            d.norm_fuse = None
         assert fn(C.byref(d), ctx.stream()) == 0
         if not fuse:
             nd = L.GanNormDesc(ctx.dt, yb.view(), ab.view(8, co), G, 1e-3, gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
@@ -573,6 +576,9 @@ def test_split_k_dgrad_finishes_the_layer_below(ctx, case, planner_options):
                           part.data_ptr(), G, part.numel() * 4, C.addressof(bf), C.addressof(nf))
         assert ctx.lib.gan_conv_plan_info(C.byref(d), opi, info) == 0
         assert info[2] > 1 and (info[4] == -1) == bool(fuse) and info[4] != 0, list(info)
+        if not fuse:
+            assert fn(C.byref(d), ctx.stream()) == L.E_SHAPE
+            d.norm_fuse = None
         assert fn(C.byref(d), ctx.stream()) == 0
         if not fuse:
             fd = L.GanNormBwdDesc(ctx.dt, refv, dzb.view(0, cols), z, outb.view(), G, gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(),

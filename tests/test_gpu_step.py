@@ -118,6 +118,7 @@ def test_pix2pix_graph_replay_matches_eager():
     for ps in (st2.G.params, st2.D.params):
         ps.m.zero_(); ps.v.zero_(); ps.step.zero_()
     l_graph = [replay(ti, tt)[:4].cpu().numpy().copy() for _ in range(2)]
+    assert any(st2.g.adam_fused.values())      # the captured schedule carried Adam inside wgrad launches (GanAdamFuse); the eager one cannot
     assert np.allclose(l_eager, l_graph, rtol=1e-5)
     assert torch.allclose(w_eager, st2.G.params.master, atol=1e-6)
 
@@ -354,7 +355,7 @@ def test_generator_output_on_reference_example_pairs(dtype):
             v = (gG if nm.startswith('G.') else gD)[nm[2:]]
             assert abs(np.abs(v).sum() - sa) <= 2e-2 * sa + 1e-12, nm       # checksum of |grad| per tensor
     else:
-        assert err < 0.15 and np.allclose(losses, gold['losses'], rtol=5e-2)
+        assert err < 0.04 and np.allclose(losses, gold['losses'], rtol=5e-3)      # (measured 1.4e-2 / ~1e-3: the gates of its siblings)
 
 
 class _FakeSync:
@@ -484,7 +485,7 @@ def test_ddp_two_ranks_equal_sharded_single_process(bf16_wire):
     assert np.abs(res[0][1] - ref).max() <= (1e-2 if bf16_wire else 1e-5) * np.abs(ref).max()
 
 
-def _rccl_one_rank_worker(port, q, model):
+def _rccl_one_rank_worker(port, q, model, exchange='allreduce'):
     import os
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1')
@@ -502,7 +503,7 @@ def _rccl_one_rank_worker(port, q, model):
             st.fused_wgrad_adam = False   # (the one-GPU default leaves no fp32 gradient of the big kernels behind: this test reads them)
             st.wide_wgrads = False        # (CycleGAN one-GPU default: one wgrad GEMM over a generator's three invocations - another summation
             if ddp:                       # order than the write + accumulate pair of the phased schedule; compared in its own test)
-                st.sync = GradSync([n.params.grad for n in st.nets()], compress_bf16=(wire == 'bf16'), lib=ctx.lib, rehearse=True)
+                st.sync = GradSync([n.params.grad for n in st.nets()], compress_bf16=(wire == 'bf16'), lib=ctx.lib, rehearse=True, exchange=exchange)
                 assert st.sync.active and st.sync.world == 1
             g = torch.Generator(device='cpu').manual_seed(5)
             x = [(torch.rand(st.B, 256, 256, 1, generator=g) * 2 - 1).to(ctx.device) for _ in range(2)]
@@ -531,8 +532,8 @@ def _rccl_one_rank_worker(port, q, model):
     q.put(out)
 
 
-@pytest.mark.parametrize("model", ['pix2pix', 'cyclegan'])
-def test_ddp_schedule_over_rccl_with_one_rank(model):
+@pytest.mark.parametrize("model,exchange", [('pix2pix', 'allreduce'), ('cyclegan', 'allreduce'), ('pix2pix', 'rs_ag')])
+def test_ddp_schedule_over_rccl_with_one_rank(model, exchange):
     """The whole data-parallel path over the real backend on the one GPU of the test box: RCCL communicator of ONE rank
     (all-reduce = identity), graphs captured while its watchdog thread is alive, asynchronous bucket collectives on the
     communicator's stream between graph replays, Adam graphs behind `work.wait()` on a side stream, both wire formats.
@@ -543,7 +544,7 @@ def test_ddp_schedule_over_rccl_with_one_rank(model):
     import torch.multiprocessing as mp
     mpc = mp.get_context('spawn')
     q = mpc.Queue()
-    p = mpc.Process(target=_rccl_one_rank_worker, args=(29900 + os.getpid() % 1000 + (7 if model == 'cyclegan' else 0), q, model))
+    p = mpc.Process(target=_rccl_one_rank_worker, args=(29900 + os.getpid() % 1000 + (7 if model == 'cyclegan' else 0) + (13 if exchange == 'rs_ag' else 0), q, model, exchange))
     p.start()
     out = q.get(timeout=900)
     p.join(timeout=120)
@@ -644,3 +645,140 @@ def test_capture_guard_reports_an_unjoined_lane():
     g.replay()
     torch.cuda.synchronize()
     assert float(buf[0]) == 1.0
+
+
+def _plans_of(ops):
+    return [o[3]['kernel'] for o in ops if len(o) > 3 and isinstance(o[3], dict)]
+
+
+def test_benchmarked_pix2pix_graph_equals_eager_steps():
+    """The object bench.py times - Pix2Pix bf16 batch 16, default multi-lane schedule captured into a hipGraph, Adam inside the
+    wgrad launches / slab reduces, parity-patch and ping-pong kernels, D(real) on its side lane - against two EAGER steps from
+    the same state (separate Adam passes, fp32 gradients written): losses, every master weight of both networks, BatchNorm
+    moving statistics."""
+    ctx, st, Gp, Dp, inp, tar, masks = _setup_p2p('bf16', B=16)
+    ti, tt = torch.from_numpy(inp).to(ctx.device), torch.from_numpy(tar).to(ctx.device)
+
+    def reset(s_):
+        s_.G.params.load_numpy(Gp); s_.D.params.load_numpy(Dp)
+        for ps in (s_.G.params, s_.D.params):
+            ps.m.zero_(); ps.v.zero_(); ps.step.zero_()
+            for k, t in ps.state.items():
+                t.fill_(0.0 if 'mean' in k else 1.0)
+    l_eager = [st.train_step(ti, tt, True).cpu().numpy().copy() for _ in range(2)]
+    w_eager = [st.G.params.master.clone(), st.D.params.master.clone()]
+    s_eager = {k: v.clone() for ps in (st.G.params, st.D.params) for k, v in ps.state.items()}
+    ctx2, st2, *_ = _setup_p2p('bf16', B=16)
+    replay = st2.capture(training=True)
+    reset(st2)
+    l_graph = [replay(ti, tt)[:4].cpu().numpy().copy() for _ in range(2)]
+    torch.cuda.synchronize()
+    fused = [v for v in st2.g.adam_fused.values() if v]
+    assert fused and len(fused[0]) >= 7, st2.g.adam_fused                       # Adam ran inside wgrad launches
+    bwd = [ops for key, ops in st2.g._bwd_cache.items() if len(key) == 5 and key[4] is not None][0]
+    kernels = set(_plans_of(bwd) + _plans_of(st2.g.fwd_ops) + _plans_of(st2.d.params_ops()))
+    assert 'wgrad<bf16,256,256>' in kernels and 'conv_gemm<bf16,1024,64>' in kernels and 'conv_gemm<bf16,256,128>' in kernels, kernels
+    assert np.allclose(l_eager, l_graph, rtol=1e-5), (l_eager, l_graph)
+    assert torch.allclose(w_eager[0], st2.G.params.master, atol=1e-6), float((w_eager[0] - st2.G.params.master).abs().max())
+    assert torch.allclose(w_eager[1], st2.D.params.master, atol=1e-6), float((w_eager[1] - st2.D.params.master).abs().max())
+    got = {k: v for ps in (st2.G.params, st2.D.params) for k, v in ps.state.items()}
+    for k, v in s_eager.items():
+        assert torch.allclose(v, got[k], rtol=1e-5, atol=1e-7), k
+
+
+def test_benchmarked_cyclegan_graph_equals_eager_steps():
+    """CycleGAN bf16 batch 4 (BASELINE config 3's utilisation point): the captured two-chain step with wide wgrads and fused Adam
+    against the same two steps run eagerly; losses and all master weights of the four networks."""
+    from gan_amd.nets import Ctx
+    from gan_amd.steps import CycleGANStep
+    rx, ry = O.synthetic_pair(4, 256, 1, seed=43)
+    res = []
+    for graph in (False, True):
+        ctx = Ctx('cuda:0', 'bf16')
+        st = CycleGANStep(ctx, 4, 256, 1, lam=10.0, seed=7)
+        w0 = [n.params.master.clone() for n in st.nets()]
+        x = [torch.from_numpy(rx).to(ctx.device), torch.from_numpy(ry).to(ctx.device)]
+        run = st.capture(training=True) if graph else (lambda a, b: st.train_step(a, b, True))
+        for n_, w_ in zip(st.nets(), w0):
+            n_.params.master.copy_(w_); n_.params.prepare()
+            n_.params.m.zero_(); n_.params.v.zero_(); n_.params.step.zero_()
+        for call in vars(st).values():
+            if hasattr(call, 'mask_draws'):
+                call.mask_draws.zero_()
+        losses = [run(*x)[:7].cpu().numpy().copy() for _ in range(2)]
+        torch.cuda.synchronize()
+        res.append((losses, [n.params.master.clone() for n in st.nets()]))
+        if graph:
+            assert st._wide is True and any(any(c.adam_fused.values()) for c in (st.gA, st.gB))
+    (le, we), (lg, wg) = res
+    assert np.allclose(le, lg, rtol=1e-5), (le, lg)
+    for a, b in zip(we, wg):
+        assert torch.allclose(a, b, atol=1e-6), float((a - b).abs().max())
+
+
+def test_exception_inside_a_capture_with_a_forked_lane_comes_back_as_python_error():
+    """An exception raised inside a capture while a lane is forked (a kernel entry point's error code, the lane guard) used to reach
+    capture_end with the lane still open - the condition that takes the process down inside hipStreamEndCapture on ROCm 7.2
+    (gpurun_out/r3/cg3_b.log).  Ctx.capture_graph joins the open lanes, ends the capture and re-raises GanAmdError.  Run in a child
+    process (tools/capture_fork_probe.py raise): a crash would otherwise take the whole test run with it."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, 'tools', 'capture_fork_probe.py'), 'raise'], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert '[raise] rc=0' in p.stdout and 'RESULT raise: GanAmdError' in p.stdout, p.stdout + p.stderr
+
+
+def _rccl_two_rank_worker(rank, port, q):
+    import os
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE='2', LOCAL_RANK=str(rank))
+    torch.cuda.set_device(rank)
+    dist.init_process_group('nccl', rank=rank, world_size=2, device_id=torch.device(f'cuda:{rank}'))
+    from gan_amd import ddp
+    from gan_amd.ddp import GradSync
+    from gan_amd import _lib as L
+    dev = torch.device(f'cuda:{rank}')
+    g = torch.Generator().manual_seed(3)
+    full = torch.randn(1 << 20, generator=g)
+    mine = (full * (rank + 1)).to(dev)
+    out = {}
+    for exchange in ('allreduce', 'rs_ag'):
+        for compress in (False, True):
+            buf = mine.clone()
+            sync = GradSync([buf], compress_bf16=compress, lib=L.load(), exchange=exchange)
+            sync.pack(0)
+            sync.wait(sync.start(0))
+            torch.cuda.synchronize()
+            out[(exchange, compress)] = ((sync.wire[0].float() if compress else buf) / 2).cpu()
+
+    class PS:
+        master = out[('rs_ag', False)].to(dev)
+    ddp.assert_replicas_in_sync([PS], ddp.DistInfo(rank, 2, str(dev)))
+    q.put((rank, {k: v.numpy() for k, v in out.items()}, (full * 1.5).numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: the multi-rank RCCL path of the 'rs_ag' exchange")
+def test_rs_ag_equals_allreduce_over_rccl_two_ranks():
+    """The in-place reduce_scatter_tensor / all_gather_into_tensor path of the 'rs_ag' exchange over a real two-rank RCCL group
+    (one-GPU boxes skip it: there the exchange has only ever run over gloo's all-reduce stand-in and a one-rank communicator, and
+    'allreduce' stays the default): the same means as the all-reduce exchange, both wire formats, replicas in sync."""
+    import os
+    import torch.multiprocessing as mp
+    mpc = mp.get_context('spawn')
+    q = mpc.Queue()
+    port = 29100 + os.getpid() % 500
+    procs = [mpc.Process(target=_rccl_two_rank_worker, args=(r, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, out, mean in res:
+        for (exchange, compress), v in out.items():
+            assert np.allclose(v, mean, rtol=1e-2 if compress else 1e-6, atol=1e-2 if compress else 1e-6), (rank, exchange, compress)
+    assert np.array_equal(res[0][1][('rs_ag', True)], res[1][1][('rs_ag', True)])
