@@ -149,6 +149,7 @@ def main():
     ap.add_argument('--model', default='pix2pix', choices=['pix2pix', 'cyclegan'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true', help='skip the eager instrumented passes (profiler runs: only the replayed step in the trace)')
     ap.add_argument('--fp32-allreduce', action='store_true', help='exchange gradients as fp32 instead of bf16')
     ap.add_argument('--repeats', type=int, default=5, help='the K-step timed region is run this many times; the median is reported')
     ap.add_argument('--sustain', type=float, default=3.0, help='seconds of back-to-back steps for the "sustained" key (0: skip)')
@@ -308,6 +309,9 @@ def main():
         # which puts non-GEMM work inside some launches of the dominant class.  The roofline figure is about the GEMM: it is timed
         # on a second step object (same networks) built under conv.bwd_fuse_tile = 3 - the same kernels with plain epilogues - and
         # the as-shipped per-class times are reported beside it ("kernels_as_shipped").
+        if args.no_roofline and world == 1 and not rehearse:
+            print(json.dumps(out), flush=True)
+            return
         prof_shipped = gemm_profile(step, inputs)
         prof = prof_shipped
         if args.model == 'pix2pix' and not step.sync:

@@ -48,6 +48,8 @@ Opt g_opts[] = {
     {"wgrad.pingpong_128", {1}},       // 128-channel SMALL tensors on the 256-column ping-pong tile (half the columns dropped): +0.5 % on the step
     {"wgrad.pingpong_min_gflop", {30}},
     {"wgrad.split_target", {512}},
+    {"wgrad.reduce_adam_min_params", {1 << 20}},
+    {"wgrad.reduce_adam", {1}},     // GanAdamFuse on split launches: the slab reduce ends in the optimiser step
 };
 Opt* find_opt(const char* key) {
   if (!key) return nullptr;

@@ -248,7 +248,123 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* slab, fl
   }
 }
 
+// The same slab sum that ENDS in the optimiser step (GanAdamFuse on a split launch): a block owns a 64 x 64 tile of one tap of
+// dW[tap][a][b], sums the splits of its elements in exactly wgrad_reduce_kernel's order (SG interleaved partial sums, each taken
+// sequentially, added in order), applies TF-form Adam (gan_adam1: bit-identical to reduce -> fp32 gradient -> gan_adam_prepare_multi)
+// and refreshes both typed NK copies - adam_prep_multi_kernel's access pattern: whole 256-byte row segments of master / m / v per
+// 16 lanes, the transposed copy through LDS.  The fp32 gradient is never written.  A % 8 == 0, B % 8 == 0.
+template <typename T>
+__global__ __launch_bounds__(256) void wgrad_reduce_adam_kernel(const float* __restrict__ slab, size_t per_split, int splits, int log2sg, int A, int B,
+                                                                float* __restrict__ aw, float* __restrict__ am, float* __restrict__ av,
+                                                                T* __restrict__ nat, T* __restrict__ tr, const float* __restrict__ lr_t,
+                                                                float omb1, float omb2, float eps) {
+  __shared__ float tile[64][65];
+  const int tiles_b = (B + 63) / 64, tiles_a = (A + 63) / 64;
+  int t = blockIdx.x;
+  const int tb = t % tiles_b; t /= tiles_b;
+  const int ta = t % tiles_a, tap = t / tiles_a;
+  const int b0 = tb * 64, a0 = ta * 64;
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const float lr = *lr_t;
+  const int SG = 1 << log2sg;
+  const int b = b0 + tx * 4;
+  // phase 1: every load of the thread's 4 rows (slab sums, master, m, v) before the first store: 4 rows' worth in flight
+  f32x4 g[4];
+  float4 pp[4], mm[4], vv[4];
+  size_t o[4];
+  bool ok[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int a = a0 + ty + 16 * i;
+    ok[i] = a < A && b < B;
+    o[i] = ok[i] ? ((size_t)tap * A + a) * B + b : 0;
+    pp[i] = *(const float4*)(aw + o[i]); mm[i] = *(const float4*)(am + o[i]); vv[i] = *(const float4*)(av + o[i]);
+    g[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  if (SG == 1) {                                                 // the common case: one sequential sum per element, 4 rows interleaved
+    int k = 0;
+    for (; k + 3 < splits; k += 4) {
+      f32x4 x[4][4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) x[u][i] = *(const f32x4*)(slab + (size_t)(k + u) * per_split + o[i]);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) g[i] += x[u][i];
+    }
+    for (; k < splits; ++k)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) g[i] += *(const f32x4*)(slab + (size_t)k * per_split + o[i]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float* src = slab + o[i];
+      for (int j = 0; j < SG; ++j) {                             // split group j of wgrad_reduce_kernel: k = j, j + SG, ...
+        f32x4 sacc = f32x4{0.f, 0.f, 0.f, 0.f};
+        int k = j;
+        for (; k + 3 * SG < splits; k += 4 * SG) {
+          const f32x4 x0 = *(const f32x4*)(src + (size_t)k * per_split), x1 = *(const f32x4*)(src + (size_t)(k + SG) * per_split);
+          const f32x4 x2 = *(const f32x4*)(src + (size_t)(k + 2 * SG) * per_split), x3 = *(const f32x4*)(src + (size_t)(k + 3 * SG) * per_split);
+          sacc += x0; sacc += x1; sacc += x2; sacc += x3;
+        }
+        for (; k < splits; k += SG) sacc += *(const f32x4*)(src + (size_t)k * per_split);
+        if (j == 0) g[i] = sacc; else g[i] += sacc;
+      }
+    }
+  }
+  // phase 2: the optimiser step, the native NK rows, the updated weights into LDS for the transposed copy
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float w[4] = {0.f, 0.f, 0.f, 0.f};
+    if (ok[i]) {
+      gan_adam1(pp[i].x, mm[i].x, vv[i].x, g[i][0], 1.f, omb1, omb2, lr, eps);
+      gan_adam1(pp[i].y, mm[i].y, vv[i].y, g[i][1], 1.f, omb1, omb2, lr, eps);
+      gan_adam1(pp[i].z, mm[i].z, vv[i].z, g[i][2], 1.f, omb1, omb2, lr, eps);
+      gan_adam1(pp[i].w, mm[i].w, vv[i].w, g[i][3], 1.f, omb1, omb2, lr, eps);
+      *(float4*)(aw + o[i]) = pp[i]; *(float4*)(am + o[i]) = mm[i]; *(float4*)(av + o[i]) = vv[i];
+      w[0] = pp[i].x; w[1] = pp[i].y; w[2] = pp[i].z; w[3] = pp[i].w;
+      if (nat) *(uint2*)(nat + o[i]) = make_uint2(pack2<T>(w[0], w[1]), pack2<T>(w[2], w[3]));
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) tile[ty + 16 * i][tx * 4 + k] = w[k];
+  }
+  __syncthreads();
+  if (tr) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int bb = b0 + ty + 16 * i, a = a0 + tx * 4;          // 4 consecutive a per thread
+      if (bb < B && a < A)
+        *(uint2*)(tr + ((size_t)tap * B + bb) * A + a) = make_uint2(pack2<T>(tile[tx * 4][ty + 16 * i], tile[tx * 4 + 1][ty + 16 * i]),
+                                                                    pack2<T>(tile[tx * 4 + 2][ty + 16 * i], tile[tx * 4 + 3][ty + 16 * i]));
+    }
+  }
+}
+
+static int wgrad_reduce_log2sg(long long count4, int splits) {
+  int log2sg = 0;
+  while (log2sg < 6 && (count4 << log2sg) < 65536 && (8 << log2sg) <= splits) ++log2sg;
+  return log2sg;
+}
+
 struct WgradPlan { WgradParams p; int TA, TB; dim3 grid; size_t slab_bytes; bool pp; };
+
+// GanAdamFuse on a SPLIT launch: the slab reduce ends in the optimiser step (wgrad_reduce_adam_kernel), p.adam = 2
+static void plan_reduce_adam(const GanWgradDesc* d, WgradParams& p) {
+  const GanAdamFuse* af = d->adam_fuse;
+  // (tensors under 2^20 parameters stay on the flat reduce + the caller's multi-tensor pass: 64 x 64 tiles of a small kernel are too few
+  // blocks to stream at HBM rate - measured 4.2 TB/s over all split layers of the generator against 5.4 TB/s for the separate passes)
+  const int min_params = gan_opt("wgrad.reduce_adam_min_params");
+  if (!af || !gan_opt("wgrad.reduce_adam") || p.splits <= 1 || p.fold || p.swap || d->accumulate || d->dtype == GAN_F32 || p.CaReal % 8 || p.CbReal % 8 ||
+      (long long)16 * p.CaReal * p.CbReal < (long long)min_params ||
+      !af->master || !af->m || !af->v || !af->lr_t ||
+      (((uintptr_t)af->master | (uintptr_t)af->m | (uintptr_t)af->v | (uintptr_t)af->nk_native | (uintptr_t)af->nk_transposed) & 15))
+    return;
+  p.adam = 2;
+  p.aw = af->master; p.am = af->m; p.av = af->v; p.anat = af->nk_native; p.atr = af->nk_transposed; p.alr = af->lr_t;
+  p.omb1 = 1.f - af->beta1; p.omb2 = 1.f - af->beta2; p.aeps = af->eps;
+}
 
 static int plan_wgrad(const GanWgradDesc* d, WgradPlan* pl, bool allow_swap = true) {
   if (!d || d->struct_size != sizeof(GanWgradDesc) || !d->big.ptr || !d->small.ptr || !d->dw) return GAN_E_ARG;
@@ -319,6 +435,7 @@ static int plan_wgrad(const GanWgradDesc* d, WgradPlan* pl, bool allow_swap = tr
       if (sp >= 8) sp &= ~7LL;                     // whole groups of 8 splits: one per XCD (wgrad_pp_kernel's block mapping)
       pl->grid = dim3((unsigned)(tiles * sp), 1, 1);
       pl->slab_bytes = sp > 1 ? (size_t)sp * 16 * p.CaReal * p.CbReal * sizeof(float) : 0;
+      plan_reduce_adam(d, p);
       return 0;
     }
   }
@@ -338,6 +455,7 @@ static int plan_wgrad(const GanWgradDesc* d, WgradPlan* pl, bool allow_swap = tr
     if (splits > 1024) splits = 1024;
   }
   p.splits = splits;
+  plan_reduce_adam(d, p);
   if (const GanAdamFuse* af = d->adam_fuse; af && allow_swap && splits == 1 && !p.fold && !p.swap && !d->accumulate && d->dtype != GAN_F32 &&
       taps == 16 && TA == 128 && TB == 128 && p.CaReal % 8 == 0 && p.CbReal % 8 == 0 && af->master && af->m && af->v && af->lr_t &&
       !(((uintptr_t)af->master | (uintptr_t)af->m | (uintptr_t)af->v | (uintptr_t)af->nk_native | (uintptr_t)af->nk_transposed) & 15)) {
@@ -912,7 +1030,9 @@ int gan_conv_wgrad(const GanWgradDesc* d, gan_stream_t stream) {
   if (pl.slab_bytes > d->workspace_bytes || (pl.slab_bytes && !d->workspace)) return GAN_E_WORKSPACE;
   // the caller skips its own optimiser pass for this kernel on the strength of gan_wgrad_adam_fused() == 1: a request this
   // launch's plan cannot honour (a planner option changed since the query) must fail, not leave the kernel without its update
-  if (d->adam_fuse && !(pl.p.adam && !pl.pp)) return GAN_E_SHAPE;
+  if (d->adam_fuse && !(pl.p.adam == 2 || (pl.p.adam == 1 && !pl.pp))) return GAN_E_SHAPE;
+  const int reduce_adam = pl.p.adam == 2;
+  if (reduce_adam) pl.p.adam = 0;                      // (the GEMM kernels' own epilogue switch: they write plain slabs)
   if (pl.p.swap) { const size_t t = bb; bb = sb; sb = t; }
   if (pl.pp) rc = d->dtype == GAN_F16 ? launch_wpp<f16_t>(pl, (unsigned)bb, (unsigned)sb, st) : launch_wpp<bf16_t>(pl, (unsigned)bb, (unsigned)sb, st);
   else if (dma_ok) rc = d->dtype == GAN_F32 ? launch_wgrad_dma<float>(pl, (unsigned)bb, (unsigned)sb, st)
@@ -922,10 +1042,22 @@ int gan_conv_wgrad(const GanWgradDesc* d, gan_stream_t stream) {
   else if (d->dtype == GAN_F16) rc = launch_wgrad<f16_t, true>(pl, st);
   else rc = launch_wgrad<bf16_t, true>(pl, st);
   if (rc) return rc;
-  if (pl.p.splits > 1) {
+  if (pl.p.splits > 1 && reduce_adam) {
+    const WgradParams& q = pl.p;
+    const long long count4 = (long long)4 * q.CaReal * q.CbReal;
+    const int log2sg = wgrad_reduce_log2sg(count4, q.splits);
+    const unsigned tiles = 16u * (unsigned)((q.CaReal + 63) / 64) * (unsigned)((q.CbReal + 63) / 64);
+    const size_t per_split = (size_t)16 * q.CaReal * q.CbReal;
+    if (d->dtype == GAN_F16)
+      hipLaunchKernelGGL(wgrad_reduce_adam_kernel<f16_t>, dim3(tiles), dim3(256), 0, st, (const float*)q.slab, per_split, q.splits, log2sg, q.CaReal,
+                         q.CbReal, q.aw, q.am, q.av, (f16_t*)q.anat, (f16_t*)q.atr, q.alr, q.omb1, q.omb2, q.aeps);
+    else
+      hipLaunchKernelGGL(wgrad_reduce_adam_kernel<bf16_t>, dim3(tiles), dim3(256), 0, st, (const float*)q.slab, per_split, q.splits, log2sg, q.CaReal,
+                         q.CbReal, q.aw, q.am, q.av, (bf16_t*)q.anat, (bf16_t*)q.atr, q.alr, q.omb1, q.omb2, q.aeps);
+    GAN_CHECK_LAUNCH();
+  } else if (pl.p.splits > 1) {
     const long long count4 = (long long)4 * pl.p.CaReal * pl.p.CbReal;     // 16 taps * Ca * Cb floats, as float4
-    int log2sg = 0;
-    while (log2sg < 6 && (count4 << log2sg) < 65536 && (8 << log2sg) <= pl.p.splits) ++log2sg;
+    const int log2sg = wgrad_reduce_log2sg(count4, pl.p.splits);
     const int EV = 256 >> log2sg;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((count4 + EV - 1) / EV)), dim3(256), 0, st,
                        (const float*)pl.p.slab, pl.p.dw, count4, pl.p.splits, pl.p.accumulate, log2sg);
@@ -953,7 +1085,7 @@ int gan_wgrad_adam_fused(const GanWgradDesc* d) {
   WgradPlan pl;
   const int rc = plan_wgrad(d, &pl, dma_ok);
   if (rc) return rc;
-  return pl.p.adam && !pl.pp ? 1 : 0;
+  return (pl.p.adam == 2 || (pl.p.adam == 1 && !pl.pp)) ? 1 : 0;
 }
 size_t gan_wgrad_workspace_bytes(const GanWgradDesc* d) {
   WgradPlan pl;

@@ -137,8 +137,11 @@ int gan_conv_plan_info(const GanConvDesc* d, int op, int32_t* info);
  * kernel it has just differentiated and refreshes its typed NK copies - the fp32 gradient is then neither written nor read back
  * (dw stays untouched).  Bit-identical to gan_conv_wgrad followed by gan_adam_prepare_multi.  gan_adam_begin must have run for
  * this step (lr_t).  Not for fp16 steps with dynamic loss scaling (their update waits for the whole-step inf/nan check and
- * un-scales).  Honoured only when gan_wgrad_adam_fused() returns 1 for the descriptor (16-bit storage, accumulate == 0,
- * channel counts multiples of 8, a plan whose last kernel can carry it); the caller asks first and passes adam_fuse = NULL
+ * un-scales).  Two carriers: the epilogue of an un-split launch of the 128x128 LDS-DMA kernel, and - for every launch that
+ * splits its reduction, the ping-pong kernel included - the slab-reduce kernel, which then ends in the optimiser step instead of
+ * writing the fp32 gradient (option wgrad.reduce_adam, default 1; kernels of at least
+ * wgrad.reduce_adam_min_params parameters).  Honoured only when gan_wgrad_adam_fused() returns 1 for the
+ * descriptor (16-bit storage, accumulate == 0, channel counts multiples of 8, no tap folding); the caller asks first and passes adam_fuse = NULL
  * otherwise - gan_conv_wgrad returns GAN_E_SHAPE for a non-NULL adam_fuse its plan cannot honour. */
 typedef struct GanAdamFuse {
   float* master;             /* fp32 [16][big_c][small_c]: the layout of dw */
@@ -357,7 +360,8 @@ const char* gan_version(void);
  * epilogue rides on every tile epilogue; 0 never, 2 not on 64-column tiles, 3 on 64-column tiles only), conv.thin (7: bit 0
  * streaming kernels for the <= 8-channel layers, bit 1 thin-N, bit 2 thin-K), conv.norm_fuse (1), conv.thin_fused (1), wgrad.tile256 (0), wgrad.pingpong (1),
  * wgrad.pingpong_min_rows (0 = automatic), wgrad.pingpong_128 (1), wgrad.pingpong_min_gflop (30),
- * wgrad.split_target (512). */
+ * wgrad.split_target (512), wgrad.reduce_adam (1),
+ * wgrad.reduce_adam_min_params (1048576: smaller kernels keep the flat slab reduce and the caller's multi-tensor Adam pass). */
 int gan_set_option(const char* key, int32_t value);
 int gan_get_option(const char* key, int32_t* value);
 

@@ -638,19 +638,24 @@ def test_wgrad_pingpong_128_columns_matches_128_tile_kernel(ctx, planner_options
     assert np.abs(out[1]).max() > 100 and np.array_equal(out[0], out[1])
 
 
-def test_wgrad_with_fused_adam_equals_wgrad_then_adam(ctx):
-    """GanAdamFuse: an un-split wgrad launch that applies TF-form Adam to its kernel and refreshes both NK copies leaves exactly
-    (bit for bit) what gan_conv_wgrad followed by gan_adam_prepare_multi leaves, over two steps; a split launch declines."""
+@pytest.mark.parametrize("case", [(2, 8, 512, 512, 'epilogue'), (4, 64, 64, 64, 'reduce'), (4, 128, 256, 256, 'reduce-pp'), (16, 32, 512, 128, 'reduce')])
+def test_wgrad_with_fused_adam_equals_wgrad_then_adam(ctx, case, planner_options):
+    """GanAdamFuse: a wgrad launch that applies TF-form Adam to its kernel and refreshes both NK copies - in its own epilogue
+    (un-split 128x128 launch) or at the end of its slab reduce (split launches, ping-pong kernel included; the reduce of the small
+    tensor sums interleaved split groups) - leaves exactly (bit for bit) what gan_conv_wgrad followed by gan_adam_prepare_multi
+    leaves, over two steps, and does not write dw."""
     from gan_amd import _lib as L
     from gan_amd.nets import Buf, ParamSet
     if ctx.dtype != 'bf16':
-        pytest.skip("bf16 only: fp32 has no LDS-DMA 16-bit epilogue, fp16 steps keep the whole-step inf/nan check before any update")
-    N, H, ci, co = 2, 8, 512, 512
+        pytest.skip("bf16 only: fp32 has no 16-bit epilogue, fp16 steps keep the whole-step inf/nan check (and the un-scaling) before any update")
+    N, H, ci, co, how = case
+    planner_options('wgrad.reduce_adam_min_params', 0)        # (the default leaves kernels under 2^20 parameters to the separate passes)
     rng = np.random.default_rng(17)
     x, dy = q(ctx, rng.standard_normal((N, H, H, ci))), q(ctx, 0.1 * rng.standard_normal((N, H // 2, H // 2, co)))
     xb, xv = dev(ctx, x)
     dyb, dyv = dev(ctx, dy)
     w0 = (0.05 * rng.standard_normal((4, 4, ci, co))).astype(np.float32)
+    info = (C.c_int32 * 4)()
     sets = []
     for fused in (False, True):
         P = ParamSet(ctx, [('k.kernel', (4, 4, ci, co), True), ('k.beta', (co,), True)])
@@ -661,6 +666,8 @@ def test_wgrad_with_fused_adam_equals_wgrad_then_adam(ctx):
                 af = P.adam_fuse_desc('k.kernel', 0.5, 0.999)
                 d = L.GanWgradDesc(ctx.dt, 2, xv, dyv, P.ptr('k.kernel', 'grad'), ci, co, 0, ctx.ws_ptr, ctx.ws_bytes, 0, C.addressof(af))
                 assert ctx.lib.gan_wgrad_adam_fused(C.byref(d)) == 1
+                assert ctx.lib.gan_wgrad_plan_info(C.byref(d), info) == 0
+                assert (info[2] == 1) == (how == 'epilogue') and (info[0] == 256) == (how == 'reduce-pp'), list(info)
                 assert ctx.lib.gan_conv_wgrad(C.byref(d), ctx.stream()) == 0
                 ctx.run(P.adam_rest_ops(['k.kernel'], 0.5, 0.999))
             else:
@@ -674,12 +681,12 @@ def test_wgrad_with_fused_adam_equals_wgrad_then_adam(ctx):
     for a, b in zip(*sets):
         assert torch.equal(a, b)
     assert float((sets[0][0][:16 * ci * co] - torch.from_numpy(w0).to(ctx.device).flatten()).abs().max()) > 1e-4      # it did move
-    # a launch that splits its reduction (big map, few channels) keeps the gradient in dw and leaves the update to the caller
-    xs, dys = Buf(ctx, 4, 64, 64, 64), Buf(ctx, 4, 32, 32, 64)
-    P2 = ParamSet(ctx, [('s.kernel', (4, 4, 64, 64), True)])
+    # a request the plan cannot honour is refused: an accumulating launch keeps the gradient in dw (the caller's optimiser pass follows)
+    P2 = ParamSet(ctx, [('s.kernel', (4, 4, ci, co), True)])
     af = P2.adam_fuse_desc('s.kernel', 0.5, 0.999)
-    d = L.GanWgradDesc(ctx.dt, 2, xs.view(), dys.view(), P2.ptr('s.kernel', 'grad'), 64, 64, 0, ctx.ws_ptr, ctx.ws_bytes, 0, C.addressof(af))
+    d = L.GanWgradDesc(ctx.dt, 2, xv, dyv, P2.ptr('s.kernel', 'grad'), ci, co, 1, ctx.ws_ptr, ctx.ws_bytes, 0, C.addressof(af))
     assert ctx.lib.gan_wgrad_adam_fused(C.byref(d)) == 0
+    assert ctx.lib.gan_conv_wgrad(C.byref(d), ctx.stream()) == L.E_SHAPE
 
 
 @pytest.mark.parametrize("kind,groups_of", [('batchnorm', lambda n: 1), ('batchnorm', lambda n: 2), ('instancenorm', lambda n: n)])
