@@ -65,7 +65,8 @@ class GanAdamFuse(C.Structure):
 class GanWgradDesc(_Desc):
     _fields_ = [("struct_size", C.c_uint32), ("dtype", C.c_int32), ("stride", C.c_int32), ("big", GanTensor), ("small", GanTensor),
                 ("dw", C.c_void_p), ("big_c", C.c_int32), ("small_c", C.c_int32), ("accumulate", C.c_int32),
-                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("concurrent", C.c_int32), ("adam_fuse", C.c_void_p)]
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("concurrent", C.c_int32), ("adam_fuse", C.c_void_p),
+                ("dw_wire", C.c_void_p)]
 
 
 class GanNormDesc(_Desc):
@@ -102,6 +103,7 @@ SYMBOLS = {
     "gan_conv_wgrad": (C.c_int, [C.POINTER(GanWgradDesc), C.c_void_p]),
     "gan_wgrad_workspace_bytes": (C.c_size_t, [C.POINTER(GanWgradDesc)]),
     "gan_wgrad_adam_fused": (C.c_int, [C.POINTER(GanWgradDesc)]),
+    "gan_wgrad_wire_direct": (C.c_int, [C.POINTER(GanWgradDesc)]),
     "gan_weights_prepare": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gan_weights_prepare_multi": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "gan_adam_prepare_multi": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -16,6 +16,22 @@
 #include "common.h"
 #include <type_traits>
 
+#ifdef GAN_DIAG   // diagnostic build only (tools/diag_build.sh): in-kernel stamps of the ping-pong kernel, as in conv_gemm.hip
+static unsigned long long* g_wdiag = nullptr;
+extern "C" void gan_wdiag_set(void* ptr) { g_wdiag = (unsigned long long*)ptr; }
+#define WDIAG_STAMP(i) do { if (p.diag && tid == 0) p.diag[(size_t)blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define WSEG_DECL unsigned long long seg_t = 0, seg_sum[6] = {0, 0, 0, 0, 0, 0}
+#define WSEG_T0 do { if (p.diag) { __builtin_amdgcn_sched_barrier(0); seg_t = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#define WSEG_ADD(k) do { if (p.diag) { __builtin_amdgcn_sched_barrier(0); const unsigned long long n_ = __builtin_amdgcn_s_memtime(); seg_sum[k] += n_ - seg_t; seg_t = n_; __builtin_amdgcn_sched_barrier(0); } } while (0)
+#define WSEG_STORE do { if (p.diag && tid == 0) for (int k_ = 0; k_ < 6; ++k_) p.diag[(size_t)blockIdx.x * 16 + 8 + k_] = seg_sum[k_]; } while (0)
+#else
+#define WDIAG_STAMP(i) do {} while (0)
+#define WSEG_DECL
+#define WSEG_T0 do {} while (0)
+#define WSEG_ADD(k) do {} while (0)
+#define WSEG_STORE do {} while (0)
+#endif
+
 struct WgradParams {
   const void* big; const void* small; float* dw; float* slab;
   int Hb, Wb, bpitch, Ca;
@@ -31,6 +47,10 @@ struct WgradParams {
   int adam;
   float* aw; float* am; float* av; void* anat; void* atr; const float* alr;
   float omb1, omb2, aeps;
+  void* wire;                // GanWgradDesc.dw_wire honoured: the result goes out as bfloat16 into the exchange's wire buffer, dw untouched
+#ifdef GAN_DIAG
+  unsigned long long* diag;
+#endif
 };
 
 template <typename T, int TA, int TB, int WAVES_A, int WAVES_B, bool TR>
@@ -220,7 +240,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
 // loads), the SG partial sums meet in LDS and are added in a fixed order: deterministic.  SG is chosen on the
 // host so that small tensors with hundreds of slabs still spread over >= 64K threads.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* slab, float* dw, long long count4, int splits,
-                                                           int accumulate, int log2sg) {
+                                                           int accumulate, int log2sg, void* wire) {
   __shared__ f32x4 red[256];
   const int EV = 256 >> log2sg, SG = 1 << log2sg;
   const int ev = threadIdx.x & (EV - 1), sg = threadIdx.x >> (8 - log2sg);
@@ -243,6 +263,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* slab, fl
     for (int j = 1; j < SG; ++j) s += red[ev + EV * j];
   }
   if (e < count4) {
+    if (wire) { ((uint2*)wire)[e] = make_uint2(pack_bf2(s[0], s[1]), pack_bf2(s[2], s[3])); return; }      // bf16 wire format (gan_grad_pack's rounding)
     f32x4* o = (f32x4*)dw + e;
     *o = accumulate ? *o + s : s;
   }
@@ -350,6 +371,16 @@ static int wgrad_reduce_log2sg(long long count4, int splits) {
 
 struct WgradPlan { WgradParams p; int TA, TB; dim3 grid; size_t slab_bytes; bool pp; };
 
+__device__ __forceinline__ uint2 wire_bf16x4(const f32x4& v) { return make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])); }
+
+// GanWgradDesc.dw_wire (data-parallel steps): the launch's last kernel - slab reduce, or the epilogue of an un-split LDS-DMA / ping-pong
+// launch - writes the gradient as bfloat16 straight into the exchange's wire buffer (same element offsets as dw): no fp32 gradient,
+// no gan_grad_pack pass.  `lds_dma`: the launch runs on the LDS-DMA kernels (the register-staged fallback has no such epilogue).
+static void plan_wire(const GanWgradDesc* d, WgradParams& p, bool lds_dma) {
+  if (!d->dw_wire || d->adam_fuse || d->accumulate || p.fold || p.swap || p.CbReal % 4 || ((uintptr_t)d->dw_wire & 7)) return;
+  if (p.splits > 1 || lds_dma) p.wire = d->dw_wire;
+}
+
 // GanAdamFuse on a SPLIT launch: the slab reduce ends in the optimiser step (wgrad_reduce_adam_kernel), p.adam = 2
 static void plan_reduce_adam(const GanWgradDesc* d, WgradParams& p) {
   const GanAdamFuse* af = d->adam_fuse;
@@ -383,7 +414,10 @@ static int plan_wgrad(const GanWgradDesc* d, WgradPlan* pl, bool allow_swap = tr
   p.S = d->stride; p.M = (int)M; p.divW = make_fastdiv(s.w); p.divH = make_fastdiv(s.h);
   p.CaReal = d->big_c; p.CbReal = d->small_c; p.accumulate = d->accumulate;
   p.fold = (b.c == 8) ? 1 : 0;
-  p.swap = 0; p.shift = 0; p.adam = 0;
+  p.swap = 0; p.shift = 0; p.adam = 0; p.wire = nullptr;
+#ifdef GAN_DIAG
+  p.diag = g_wdiag;
+#endif
   int TA, TB, tilesA, taps;
   if (allow_swap && !p.fold && d->stride == 1 && s.c == 8 && b.c >= 64) {
     // Thin SMALL tensor (the logits layer's dy): iterate over the BIG grid instead and fold the 16 taps of the thin
@@ -436,6 +470,7 @@ static int plan_wgrad(const GanWgradDesc* d, WgradPlan* pl, bool allow_swap = tr
       pl->grid = dim3((unsigned)(tiles * sp), 1, 1);
       pl->slab_bytes = sp > 1 ? (size_t)sp * 16 * p.CaReal * p.CbReal * sizeof(float) : 0;
       plan_reduce_adam(d, p);
+      plan_wire(d, p, true);
       return 0;
     }
   }
@@ -456,6 +491,7 @@ static int plan_wgrad(const GanWgradDesc* d, WgradPlan* pl, bool allow_swap = tr
   }
   p.splits = splits;
   plan_reduce_adam(d, p);
+  plan_wire(d, p, allow_swap);
   if (const GanAdamFuse* af = d->adam_fuse; af && allow_swap && splits == 1 && !p.fold && !p.swap && !d->accumulate && d->dtype != GAN_F32 &&
       taps == 16 && TA == 128 && TB == 128 && p.CaReal % 8 == 0 && p.CbReal % 8 == 0 && af->master && af->m && af->v && af->lr_t &&
       !(((uintptr_t)af->master | (uintptr_t)af->m | (uintptr_t)af->v | (uintptr_t)af->nk_native | (uintptr_t)af->nk_transposed) & 15)) {
@@ -741,7 +777,9 @@ __global__ __launch_bounds__(64 * WAVES_A * WAVES_B) void wgrad_dma_kernel(const
       const int cb = cb0 + wb * WTB + j * 16 + q * 4;
       if (vec4) {
         if (cb < p.CbReal) {
-          f32x4* o = (f32x4*)(out + ((size_t)otap * p.CaReal + oc) * p.CbReal + cb);
+          const size_t oo = ((size_t)otap * p.CaReal + oc) * p.CbReal + cb;
+          if (p.wire && p.splits == 1) { *(uint2*)((unsigned short*)p.wire + oo) = wire_bf16x4(acc[i][j]); continue; }
+          f32x4* o = (f32x4*)(out + oo);
           *o = (p.splits == 1 && p.accumulate) ? *o + acc[i][j] : acc[i][j];
         }
       } else {
@@ -822,6 +860,7 @@ __global__ __launch_bounds__(512) void wgrad_pp_kernel(const WgradParams p, unsi
   constexpr int PANEL = 64 * 128, STAGE = 8 * PANEL, NB = 2, PH = 4, PP = 2, DP = 6, VMW = 6, QS = 8;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
+  WDIAG_STAMP(0);
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
   const int r = lane & 15, q = lane >> 4;
@@ -906,6 +945,7 @@ __global__ __launch_bounds__(512) void wgrad_pp_kernel(const WgradParams p, unsi
   const unsigned swl = (unsigned)(((r >> 3) & 1) | ((q & 1) << 1));
   const unsigned lrow_off = (unsigned)((8 * q + (r >> 2)) * 128 + (((r >> 1) & 1) << 4) + 8 * (r & 1));
 
+  WDIAG_STAMP(1);
   // prologue: slots of phases -6 .. -1 = all of K tile 0 and A0, B, B of K tile 1
   rowinfo(0);
   issue_slots(std::integral_constant<int, 0>{}, std::integral_constant<int, 8>{}, 0);
@@ -913,9 +953,12 @@ __global__ __launch_bounds__(512) void wgrad_pp_kernel(const WgradParams p, unsi
   issue_slots(std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{}, 1);
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VMW) : "memory");
   __builtin_amdgcn_s_barrier();
+  WDIAG_STAMP(2);
   if (wr == 1) __builtin_amdgcn_s_barrier();
 
   s16x4 alo[2][4], ahi[2][4], b0lo[2][2], b0hi[2][2], b1lo[2][2], b1hi[2][2];
+  WSEG_DECL;
+  WSEG_T0;
   for (int t = 0; t < nk; ++t) {
     const unsigned so = lds_base + (unsigned)((t & 1) * STAGE) + lrow_off;
     unsigned bt[4];
@@ -928,6 +971,7 @@ __global__ __launch_bounds__(512) void wgrad_pp_kernel(const WgradParams p, unsi
       constexpr int x0 = PP * (ph + DP);                   // 12, 14, 16, 18 -> (tile t+1: slots 4,5 | 6,7), (tile t+2: 0,1 | 2,3)
       if constexpr (ph == 2) rowinfo(t + 2);
       issue_slots(std::integral_constant<int, x0 % QS>{}, std::integral_constant<int, PP>{}, t + x0 / QS);
+      WSEG_ADD(5);                                         // row decode + LDS-DMA issue
       if constexpr (ph == 0 || ph == 1) {
         wg_static_for<2>([&](auto Jc) {
           constexpr int j = decltype(Jc)::value;
@@ -949,8 +993,11 @@ __global__ __launch_bounds__(512) void wgrad_pp_kernel(const WgradParams p, unsi
           });
         });
       }
+      WSEG_ADD(0);                                         // fragment read issue
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VMW) : "memory");
+      WSEG_ADD(1);                                         // waiting for older pieces
       __builtin_amdgcn_s_barrier();
+      WSEG_ADD(2);                                         // waiting for the partner group's MATH segment
       // ---- MATH segment ----
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
@@ -969,11 +1016,15 @@ __global__ __launch_bounds__(512) void wgrad_pp_kernel(const WgradParams p, unsi
           }
         }
       __builtin_amdgcn_s_setprio(0);
+      WSEG_ADD(3);                                         // fragment wait + MFMAs
       __builtin_amdgcn_s_barrier();
+      WSEG_ADD(4);                                         // waiting for the partner group's LOAD segment
     });
   }
+  WSEG_STORE;
   if (wr == 0) __builtin_amdgcn_s_barrier();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  WDIAG_STAMP(3);
 
   // acc[i][j][e] = dW[tile row wr*128 + i*16 + r][column wc*64 + j*16 + q*4 + e]
   const size_t per_split = (size_t)16 * p.CaReal * p.CbReal;
@@ -989,7 +1040,10 @@ __global__ __launch_bounds__(512) void wgrad_pp_kernel(const WgradParams p, unsi
       const int cb = cb0 + wc * 64 + j * 16 + q * 4;
       float* o = out + ((size_t)tap * p.CaReal + ca) * p.CbReal + cb;
       if (vec4) {
-        if (cb < p.CbReal) *(f32x4*)o = (p.splits == 1 && p.accumulate) ? *(f32x4*)o + acc[i][j] : acc[i][j];
+        if (cb < p.CbReal) {
+          if (p.wire && p.splits == 1) *(uint2*)((unsigned short*)p.wire + (o - out)) = wire_bf16x4(acc[i][j]);
+          else *(f32x4*)o = (p.splits == 1 && p.accumulate) ? *(f32x4*)o + acc[i][j] : acc[i][j];
+        }
       } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e)
@@ -997,6 +1051,10 @@ __global__ __launch_bounds__(512) void wgrad_pp_kernel(const WgradParams p, unsi
       }
     }
   }
+#ifdef GAN_DIAG
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (the slab stores have been acknowledged: the stamp closes the epilogue)
+#endif
+  WDIAG_STAMP(4);
 #endif
 }
 
@@ -1031,6 +1089,7 @@ int gan_conv_wgrad(const GanWgradDesc* d, gan_stream_t stream) {
   // the caller skips its own optimiser pass for this kernel on the strength of gan_wgrad_adam_fused() == 1: a request this
   // launch's plan cannot honour (a planner option changed since the query) must fail, not leave the kernel without its update
   if (d->adam_fuse && !(pl.p.adam == 2 || (pl.p.adam == 1 && !pl.pp))) return GAN_E_SHAPE;
+  if (d->dw_wire && !pl.p.wire) return GAN_E_SHAPE;        // (as for adam_fuse: the caller asks gan_wgrad_wire_direct() first)
   const int reduce_adam = pl.p.adam == 2;
   if (reduce_adam) pl.p.adam = 0;                      // (the GEMM kernels' own epilogue switch: they write plain slabs)
   if (pl.p.swap) { const size_t t = bb; bb = sb; sb = t; }
@@ -1060,7 +1119,7 @@ int gan_conv_wgrad(const GanWgradDesc* d, gan_stream_t stream) {
     const int log2sg = wgrad_reduce_log2sg(count4, pl.p.splits);
     const int EV = 256 >> log2sg;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((count4 + EV - 1) / EV)), dim3(256), 0, st,
-                       (const float*)pl.p.slab, pl.p.dw, count4, pl.p.splits, pl.p.accumulate, log2sg);
+                       (const float*)pl.p.slab, pl.p.dw, count4, pl.p.splits, pl.p.accumulate, log2sg, pl.p.wire);
     GAN_CHECK_LAUNCH();
   }
   return 0;
@@ -1086,6 +1145,17 @@ int gan_wgrad_adam_fused(const GanWgradDesc* d) {
   const int rc = plan_wgrad(d, &pl, dma_ok);
   if (rc) return rc;
   return (pl.p.adam == 2 || (pl.p.adam == 1 && !pl.pp)) ? 1 : 0;
+}
+int gan_wgrad_wire_direct(const GanWgradDesc* d) {
+  if (!d || d->struct_size != sizeof(GanWgradDesc)) return GAN_E_ARG;
+  const size_t es = d->dtype == GAN_F32 ? 4 : 2;
+  const size_t bb = (((size_t)d->big.n * d->big.h * d->big.w - 1) * d->big.pitch + d->big.c) * es;
+  const size_t sb = (((size_t)d->small.n * d->small.h * d->small.w - 1) * d->small.pitch + d->small.c) * es;
+  const bool dma_ok = bb < 0x7fffffffull && sb < 0x7fffffffull && !(((uintptr_t)d->big.ptr | (uintptr_t)d->small.ptr) & 15);
+  WgradPlan pl;
+  const int rc = plan_wgrad(d, &pl, dma_ok);
+  if (rc) return rc;
+  return pl.p.wire ? 1 : 0;
 }
 size_t gan_wgrad_workspace_bytes(const GanWgradDesc* d) {
   WgradPlan pl;

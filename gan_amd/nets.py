@@ -510,13 +510,23 @@ class _Builder:
                     shape=f"{op} M{M}{'x4' if info[3] == 4 else ''} N{y.c} K{T * x.c} s{info[2]}")
         return (fn, (self._desc(d),), op, meta)
 
-    def wgrad(self, big, small, dw_ptr, big_c, small_c, stride, accumulate, adam_fuse=None):
-        """adam_fuse: a GanAdamFuse - ask the launch to apply the optimiser step itself; self.last_adam_fused tells whether it will."""
+    def wgrad(self, big, small, dw_ptr, big_c, small_c, stride, accumulate, adam_fuse=None, wire_ptr=None):
+        """adam_fuse: a GanAdamFuse - ask the launch to apply the optimiser step itself; self.last_adam_fused tells whether it will.
+        wire_ptr: this kernel's place in the bf16 wire buffer of the data-parallel exchange - ask the launch to write the gradient
+        there (GanWgradDesc.dw_wire); self.last_wire_direct tells whether it will (then dw stays untouched)."""
         if adam_fuse is not None:
             self.keep.append(adam_fuse)
         d = L.GanWgradDesc(self.ctx.dt, stride, big, small, dw_ptr, big_c, small_c, int(accumulate),
                            self.ws_side_ptr, self.ws_bytes, int(self.wgrad_concurrent),
-                           C.addressof(adam_fuse) if adam_fuse is not None else None)
+                           C.addressof(adam_fuse) if adam_fuse is not None else None, wire_ptr if (wire_ptr and not accumulate and adam_fuse is None) else None)
+        self.last_wire_direct = False
+        if d.dw_wire:
+            rc = self.lib.gan_wgrad_wire_direct(C.byref(d))
+            if rc < 0:
+                L.check(rc, "wgrad_wire_direct")
+            self.last_wire_direct = rc == 1
+            if not self.last_wire_direct:
+                d.dw_wire = None
         self.last_adam_fused = False
         if adam_fuse is not None:
             rc = self.lib.gan_wgrad_adam_fused(C.byref(d))
@@ -721,13 +731,17 @@ class GenCall:
         self.dxin = Buf(ctx, B, S, S, 8)
         self._bwd_cache = {}
         self.adam_fused = {}
+        self.wire_direct = {}
 
-    def _build_bwd(self, use_dgen2, need_dx, accumulate, wgrads='own', adam=None):
+    def _build_bwd(self, use_dgen2, need_dx, accumulate, wgrads='own', adam=None, wire=None):
         """wgrads: 'own' - this call's kernel gradients (accumulate as the other gradients do); 'none' - a guest call whose host
         takes them; 'wide' - a host call: one wgrad GEMM per layer over its own AND its guest's samples, plain write (the guest's
         saved activations and output gradients must be in place: its forward and its backward(wgrads='none') have run).
         adam = (beta_1, beta_2): every wgrad launch that can applies this step's Adam update to its kernel itself (GanAdamFuse;
         needs plain-write kernel gradients: wgrads 'own' without accumulate, or 'wide'); self.adam_fused[key] lists those kernels.
+        wire = data pointer of this network's bf16 wire buffer (data-parallel exchange, ParamSet offsets): every wgrad launch that can
+        writes its gradient there in the wire format instead of the fp32 buffer (GanWgradDesc.dw_wire); self.wire_direct[key] lists
+        those kernels - the caller casts (gan_grad_pack) only the rest of a bucket.
         The caller runs gan_adam_begin BEFORE this list and ParamSet.adam_rest_ops() for everything else after it, and must not
         start a layer's wgrad before every dgrad of the step that reads the layer's weights has been enqueued (staged order).
         Backward op list.  Wherever the launch shape allows it, the dgrad that produces the gradient w.r.t. a layer's
@@ -739,7 +753,7 @@ class GenCall:
         W = (lambda b_: b_.wide()) if wgrads == 'wide' else (lambda b_: b_)
         wacc = accumulate and wgrads != 'wide'
 
-        fused_names = []
+        fused_names, wire_names = [], []
         if adam is not None and wacc:
             raise ValueError("adam fusion needs plain-write kernel gradients")
 
@@ -747,9 +761,12 @@ class GenCall:
             if wgrads == 'none':
                 return
             af = P.adam_fuse_desc(kname, adam[0], adam[1]) if adam is not None else None
-            ops.append(bd.wgrad(big_v, small_v, P.ptr(kname, 'grad'), big_c, small_c, stride, wacc, adam_fuse=af))
+            wp = wire + 2 * P.entries[kname][0] if wire else None
+            ops.append(bd.wgrad(big_v, small_v, P.ptr(kname, 'grad'), big_c, small_c, stride, wacc, adam_fuse=af, wire_ptr=wp))
             if af is not None and bd.last_adam_fused:
                 fused_names.append(kname)
+            if bd.last_wire_direct:
+                wire_names.append(kname)
         ops = []
         ops.append(bd.act_bwd(self.out.view(), self.dgen.view(), self.dgen2.view() if use_dgen2 else None,
                               self.dpre.view(), 'tanh'))
@@ -841,6 +858,7 @@ class GenCall:
                 ops.append(bd.conv('conv_dgrad', dyi.view(), self.dxin.view(0, C_),
                                    P.nat[name + '.kernel'].data_ptr(), C_, 2))
         self.adam_fused[(use_dgen2, need_dx, accumulate, wgrads, adam)] = tuple(fused_names)
+        self.wire_direct[(use_dgen2, need_dx, accumulate, wgrads, adam, wire)] = tuple(wire_names)
         return ops
 
     # public API ------------------------------------------------------------------------------
@@ -879,7 +897,9 @@ class GenCall:
         """Samples [n0, n0 + n) of this call as a call-like object (CycleGAN batches two logical calls of one generator)."""
         return CallSlice(self, n0, n)
 
-    def _bwd_key(self, use_dgen2, need_dx, accumulate, wgrads, adam):
+    def _bwd_key(self, use_dgen2, need_dx, accumulate, wgrads, adam, wire=None):
+        if wire:
+            return (use_dgen2, need_dx, accumulate, wgrads, adam, wire)
         return (use_dgen2, need_dx, accumulate) if wgrads == 'own' and adam is None else (use_dgen2, need_dx, accumulate, wgrads, adam)
 
     def backward(self, use_dgen2=False, need_dx=False, accumulate=False, defer_wgrads=False, wgrads='own', adam=None):
@@ -912,13 +932,13 @@ class GenCall:
             self._bwd_cache[key] = self._build_bwd(*key)
         return self._bwd_cache[key]
 
-    def bwd_stages(self, cuts, use_dgen2=False, need_dx=False, accumulate=False, wgrads='own', adam=None):
+    def bwd_stages(self, cuts, use_dgen2=False, need_dx=False, accumulate=False, wgrads='own', adam=None, wire=None):
         """The backward op list cut into coarse stages at the wgrad indices `cuts` (the same cuts as the 'staged'
         mode): [(main-chain ops, wgrad ops)] per stage.  The wgrad GEMMs of a stage only feed Adam, so a caller may
         run them beside the NEXT stage's main chain (gan_amd/steps.py data-parallel schedule)."""
-        key = self._bwd_key(use_dgen2, need_dx, accumulate, wgrads, adam)
+        key = self._bwd_key(use_dgen2, need_dx, accumulate, wgrads, adam, wire)
         if key not in self._bwd_cache:
-            self._bwd_cache[key] = self._build_bwd(*key)
+            self._bwd_cache[key] = self._build_bwd(use_dgen2, need_dx, accumulate, wgrads, adam, wire)
         ops = self._bwd_cache[key]
         is_w = lambda o: len(o) > 4 and o[4]
         idx = [i for i, o in enumerate(ops) if is_w(o)]
@@ -1063,17 +1083,24 @@ class DiscCall:
         per = self.B * self.dlogits.h * self.dlogits.w * 8
         return self.dlogits.t.data_ptr() + call * per * self.dlogits.t.element_size()
 
-    def _chain(self, n0, n, groups, stat_off, wgrads, need_dx, accumulate, dx_dst=None, dx_c0=0):
+    def _chain(self, n0, n, groups, stat_off, wgrads, need_dx, accumulate, dx_dst=None, dx_c0=0, wire=None):
         """Backward over samples [n0, n0+n).  Scratch gradients always live at samples [0, n) of the dA/dy
         buffers; saved forward tensors are read at [n0, n0+n)."""
         bd, P = (self._bd2 if wgrads else self._bd), self.net.params
         ops = []
+        wire_names = []
+
+        def wg(big_v, small_v, kname, big_c, small_c, stride):
+            ops.append(bd.wgrad(big_v, small_v, P.ptr(kname, 'grad'), big_c, small_c, stride, accumulate,
+                                wire_ptr=wire + 2 * P.entries[kname][0] if wire else None))
+            if bd.last_wire_direct:
+                wire_names.append(kname)
         sv = lambda buf: buf.view(0, None, n0, n)          # saved forward tensors
         gv = lambda buf: buf.view(0, None, 0, n)           # gradient scratch
         dl = self.dlogits.view(0, None, n0, n) if wgrads else self.dlogits_b.view()
         # last: conv s1 with bias, no activation
         if wgrads:
-            ops.append(bd.wgrad(sv(self.a['conv']), dl, P.ptr('last.kernel', 'grad'), 512, 1, 1, accumulate))
+            wg(sv(self.a['conv']), dl, 'last.kernel', 512, 1, 1)
             ops.append(bd.bias_grad(dl, P.ptr('last.bias', 'grad'), accumulate))
         def spec_for(layer):          # backward of `layer` started in the epilogue of the dgrad that produces dA[layer]
             if layer == 'down0':
@@ -1101,7 +1128,7 @@ class DiscCall:
                                        mean.data_ptr() + 4 * stat_off * c, rstd.data_ptr() + 4 * stat_off * c, 'lrelu', None,
                                        wgrads, accumulate))
             if wgrads:
-                ops.append(bd.wgrad(sv(self.a[prev]), gv(self.dy[name]), P.ptr(name + '.kernel', 'grad'), cprev, c, stride, accumulate))
+                wg(sv(self.a[prev]), gv(self.dy[name]), name + '.kernel', cprev, c, stride)
             ops.append(bd.conv('conv_dgrad', gv(self.dy[name]), gv(self.dA[prev]), P.nat[name + '.kernel'].data_ptr(), cprev, stride,
                                bwd_fuse=spec_for(prev),
                                norm_fuse=bd.bwd_norm_fuse(prev, gv(self.dy[prev]), wgrads, accumulate) if prev != 'down0' else None))
@@ -1110,7 +1137,7 @@ class DiscCall:
         if not fused:
             ops.append(bd.act_bwd(sv(self.a0), gv(self.dA['down0']), None, gv(self.dy['down0']), 'lrelu'))
         if wgrads:
-            ops.append(bd.wgrad(sv(self.xin), gv(dy0), P.ptr('down0.kernel', 'grad'), self.net.cin, 64, 2, accumulate))
+            wg(sv(self.xin), gv(dy0), 'down0.kernel', self.net.cin, 64, 2)
         if need_dx:
             if dx_dst is not None:      # only channels [dx_c0, dx_c0 + dx_dst.c) of the input gradient, written where the caller wants them
                 wk = P.nat['down0.kernel']
@@ -1118,12 +1145,16 @@ class DiscCall:
             else:
                 ops.append(bd.conv('conv_dgrad', gv(dy0), self.dxin.view(0, self.net.cin, 0, n),
                                    P.nat['down0.kernel'].data_ptr(), self.net.cin, 2))
+        if wire:
+            self.wire_direct = tuple(wire_names)
         return ops
 
-    def params_ops(self, accumulate=False):
-        key = ('A', accumulate)
+    def params_ops(self, accumulate=False, wire=None):
+        """wire: data pointer of the network's bf16 wire buffer - wgrad launches that can write their gradient there directly
+        (GanWgradDesc.dw_wire); self.wire_direct then lists those kernels."""
+        key = ('A', accumulate, wire) if wire else ('A', accumulate)
         if key not in self._cache:
-            self._cache[key] = self._chain(0, self.N, self.groups, 0, True, False, accumulate)
+            self._cache[key] = self._chain(0, self.N, self.groups, 0, True, False, accumulate, wire=wire)
         return self._cache[key]
 
     def backward_params(self, accumulate=False):

@@ -223,6 +223,7 @@ class Pix2PixStep(_StepBase):
     ddp_buckets = True           # data parallel, bf16/f32: the bucketed schedule (False: the phased one)
     ddp_graphs = 4               # bucketed schedule: compute graphs per step (4, 3 or 2)
     ddp_late_comm = True         # a boundary's collectives are issued after the NEXT compute graph has been enqueued
+    ddp_wire_direct = True       # bf16 all-reduce exchange: wgrad launches write their gradients straight into the wire buffer
 
     def __init__(self, ctx: Ctx, batch, size, channels=1, lam=100.0, lr=2e-4, beta_1=0.5, beta_2=0.999,
                  seed=123, dropout=True, nets=None, mask_stream=0):
@@ -395,8 +396,32 @@ class Pix2PixStep(_StepBase):
         P.split_kernels_at('down4.kernel', 'up0.kernel')            # segments 0: down0..3 | 1: down4..7 | 2: up0..last
         o4, ou = P.entries['down4.kernel'][0], P.entries['up0.kernel'][0]
         self.buckets = [(0, ou, P.vec_start), (0, o4, ou), (0, 0, o4), (0, P.vec_start, P.total), (1, 0, PD.total)]
-        stages = g.bwd_stages([8, 12], use_dgen2=True)
+        # bf16 wire + all-reduce: the wgrad launches (their slab reduces / epilogues) write the wire format themselves - no fp32
+        # gradient, no cast pass for those kernels; gan_grad_pack then covers only what is left of a bucket (the tap-folded first /
+        # last layers and the vectors).  'rs_ag' reduces the fp32 gradients and keeps the cast of its own shard.
+        direct = bool(self.ddp_wire_direct and sync.compress and getattr(sync, 'wire', None) is not None
+                      and getattr(sync, 'exchange', 'allreduce') == 'allreduce')
+        wG = sync.wire[0].data_ptr() if direct else None
+        wD = sync.wire[1].data_ptr() if direct else None
+        stages = g.bwd_stages([8, 12], use_dgen2=True, wire=wG)
+        d_params = d.params_ops(wire=wD)
         assert len(stages) == 3
+        skip = {0: set(g.wire_direct[(True, False, False, 'own', None, wG)]) if direct else set(), 1: set(d.wire_direct) if direct else set()}
+        self._wire_direct_names = skip
+
+        def pack_bucket(b):
+            """Cast what the wgrad launches did not already write in the wire format: the bucket minus the direct kernels' ranges."""
+            i, lo, hi = self.buckets[b]
+            PS = (P, PD)[i]
+            cuts = sorted((o, o + (int(torch.tensor(shape).prod()) + PS.ALIGN - 1) // PS.ALIGN * PS.ALIGN)
+                          for n_, (o, shape) in PS.entries.items() if n_ in skip[i] and lo <= o < hi)
+            a = lo
+            for c0, c1 in cuts:
+                if c0 > a:
+                    sync.pack(i, a, c0)
+                a = max(a, c1)
+            if a < hi:
+                sync.pack(i, a, hi)
         main = torch.cuda.current_stream(ctx.device)
         lane2, lane3, lane4 = ctx.lane_stream(2), ctx.lane_stream(3), ctx.lane_stream(4)
         self._static_in = [torch.zeros_like(t) for t in self._example_inputs()]
@@ -407,7 +432,7 @@ class Pix2PixStep(_StepBase):
             self._forward_backward(*self._static_in, True, phase=1)
             self._forward_backward(*self._static_in, True, phase=2)
             for b in range(len(self.buckets)):
-                sync.pack(*self.buckets[b])
+                pack_bucket(b)
         main.wait_stream(s)
         torch.cuda.synchronize()
 
@@ -422,7 +447,7 @@ class Pix2PixStep(_StepBase):
             ctx.run_on(side_ops, side_stream)
             if bucket is not None:
                 with torch.cuda.stream(side_stream):
-                    sync.pack(*self.buckets[bucket])
+                    pack_bucket(bucket)
             main_fn()
             ctx.join(cur, side_stream)
 
@@ -432,9 +457,9 @@ class Pix2PixStep(_StepBase):
             # reads D's weights after this graph, so D's bucket is the first to leave
             cur = torch.cuda.current_stream(ctx.device)
             lane2.wait_stream(cur)
-            ctx.run_on(d.params_ops(), lane2)
+            ctx.run_on(d_params, lane2)
             with torch.cuda.stream(lane2):
-                sync.pack(*self.buckets[4])
+                pack_bucket(4)
             ctx.run(stages[0][0])
             ctx.join(cur, lane2)
 
@@ -447,7 +472,7 @@ class Pix2PixStep(_StepBase):
         def g4():
             ctx.run(stages[2][1])
             for b in (2, 3):
-                sync.pack(*self.buckets[b])
+                pack_bucket(b)
 
         # Adam per bucket.  bf16 wire: Adam reads the exchanged gradient straight from the wire buffer (x 1/world) - no
         # unpack pass, and the fp32 gradient buffer keeps this rank's own gradient; fp32 wire: reduced in place, x 1/world

@@ -169,6 +169,11 @@ typedef struct GanWgradDesc {
                             the rest of the chip).  2 = beside a MIRROR chain doing the same work (the two-chain CycleGAN step):
                             the K-split target is halved as well. */
   const GanAdamFuse* adam_fuse; /* optional, see above */
+  void* dw_wire;         /* optional (data-parallel steps, no counterpart in the single-device reference): the bfloat16 wire buffer of the
+                            gradient exchange at this kernel's offset ([16][big_c][small_c], 8-byte aligned).  When gan_wgrad_wire_direct()
+                            returns 1 the launch writes the gradient there in the wire format (gan_grad_pack's rounding) and leaves dw
+                            untouched: no fp32 gradient, no cast pass.  Not together with adam_fuse / accumulate; a launch whose plan
+                            cannot honour a non-NULL dw_wire returns GAN_E_SHAPE. */
 } GanWgradDesc;
 /* Kernel gradient of Conv2D / Conv2DTranspose (GradientTape.gradient w.r.t. trainable_variables,
  * pix2pix.py:210-211, cycle_gan.py:252-260). */
@@ -176,6 +181,7 @@ int gan_conv_wgrad(const GanWgradDesc* d, gan_stream_t stream);
 size_t gan_wgrad_workspace_bytes(const GanWgradDesc* d);
 int gan_wgrad_plan_info(const GanWgradDesc* d, int32_t* info /* {TA, TB, splitM, fold} */);
 int gan_wgrad_adam_fused(const GanWgradDesc* d);   /* 1: d->adam_fuse will be honoured, 0: not, < 0: error code */
+int gan_wgrad_wire_direct(const GanWgradDesc* d);  /* 1: d->dw_wire will be honoured, 0: not, < 0: error code */
 
 /* Produce typed NK copies from a fp32 Keras-layout master [16][A][B]:
  * nk_native [16][A][pad8(B)] and nk_transposed [16][B][pad8(A)] (either may be NULL). */

@@ -689,6 +689,38 @@ def test_wgrad_with_fused_adam_equals_wgrad_then_adam(ctx, case, planner_options
     assert ctx.lib.gan_conv_wgrad(C.byref(d), ctx.stream()) == L.E_SHAPE
 
 
+@pytest.mark.parametrize("case", [(2, 8, 512, 512, 'epilogue'), (4, 64, 64, 64, 'reduce'), (4, 128, 256, 256, 'reduce-pp'), (2, 16, 1, 64, 'fold')])
+def test_wgrad_writes_the_wire_format_directly(ctx, case):
+    """GanWgradDesc.dw_wire (data-parallel steps): the launch's last kernel - epilogue of an un-split launch, slab reduce of a split
+    one, ping-pong kernel included - writes the gradient as bfloat16 into the exchange's wire buffer = gan_grad_pack of the fp32
+    gradient, bit for bit, and leaves dw alone; a tap-folded layer declines (the caller keeps its cast pass for it)."""
+    from gan_amd import _lib as L
+    N, H, ci, co, how = case
+    rng = np.random.default_rng(23)
+    x, dy = q(ctx, rng.standard_normal((N, H, H, ci))), q(ctx, 0.1 * rng.standard_normal((N, H // 2, H // 2, co)))
+    xb, xv = dev(ctx, x)
+    if ci < 8:
+        xv = xb.view()                                       # (the 8-channel zero-padded tensor the first layers are given)
+    dyb, dyv = dev(ctx, dy)
+    n = 16 * ci * co
+    dw = torch.zeros(n, dtype=torch.float32, device=ctx.device)
+    d = L.GanWgradDesc(ctx.dt, 2, xv, dyv, dw.data_ptr(), ci, co, 0, ctx.ws_ptr, ctx.ws_bytes)
+    assert ctx.lib.gan_conv_wgrad(C.byref(d), ctx.stream()) == 0
+    wire = torch.zeros(n, dtype=torch.bfloat16, device=ctx.device)
+    dw2 = torch.full((n,), 7.0, dtype=torch.float32, device=ctx.device)
+    d2 = L.GanWgradDesc(ctx.dt, 2, xv, dyv, dw2.data_ptr(), ci, co, 0, ctx.ws_ptr, ctx.ws_bytes, 0, None, wire.data_ptr())
+    honoured = ctx.lib.gan_wgrad_wire_direct(C.byref(d2))
+    assert honoured == (0 if how == 'fold' else 1)
+    if not honoured:
+        assert ctx.lib.gan_conv_wgrad(C.byref(d2), ctx.stream()) == L.E_SHAPE
+        return
+    assert ctx.lib.gan_conv_wgrad(C.byref(d2), ctx.stream()) == 0
+    torch.cuda.synchronize()
+    assert float(dw.abs().max()) > 0
+    assert torch.equal(wire, dw.to(torch.bfloat16))          # the cast pass's rounding (round to nearest even)
+    assert float((dw2 - 7.0).abs().max()) == 0.0             # dw untouched
+
+
 @pytest.mark.parametrize("kind,groups_of", [('batchnorm', lambda n: 1), ('batchnorm', lambda n: 2), ('instancenorm', lambda n: n)])
 @pytest.mark.parametrize("act,drop", [('lrelu', False), ('relu', True)])
 def test_norm_act_fwd_bwd(ctx, kind, groups_of, act, drop):
