@@ -284,6 +284,7 @@ def main():
                      "value": round(world * B * n_sus / ds, 2), "sclk_mhz_before": clk0, "sclk_mhz_under_load": clk_mid,
                      "sclk_mhz_after": read_sclk_mhz(local)}
     losses = step.losses.cpu().numpy()
+    ctx.assert_no_stack_timeout()          # (a persistent layer-stack kernel that timed out at a grid barrier raises a flag instead of hanging)
     if not np.all(np.isfinite(losses)):
         raise RuntimeError(f"non-finite losses {losses}")
 

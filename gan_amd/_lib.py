@@ -102,6 +102,11 @@ SYMBOLS = {
     "gan_wgrad_plan_info": (C.c_int, [C.POINTER(GanWgradDesc), C.POINTER(C.c_int32)]),
     "gan_conv_wgrad": (C.c_int, [C.POINTER(GanWgradDesc), C.c_void_p]),
     "gan_wgrad_workspace_bytes": (C.c_size_t, [C.POINTER(GanWgradDesc)]),
+    "gan_conv_stack_eligible": (C.c_int, [C.POINTER(GanConvDesc), C.c_int]),
+    "gan_conv_stack_plan_bytes": (C.c_size_t, [C.c_int32]),
+    "gan_conv_stack_plan": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_int32, C.c_void_p, C.c_size_t]),
+    "gan_conv_stack_launch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gan_conv_stack_barrier_bytes": (C.c_size_t, []),
     "gan_wgrad_adam_fused": (C.c_int, [C.POINTER(GanWgradDesc)]),
     "gan_wgrad_wire_direct": (C.c_int, [C.POINTER(GanWgradDesc)]),
     "gan_weights_prepare": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -174,6 +179,13 @@ def set_option(key, value):
     check(lib.gan_get_option(key.encode(), C.byref(old)), f"gan_get_option({key})")
     check(lib.gan_set_option(key.encode(), int(value)), f"gan_set_option({key})")
     return old.value
+
+
+def get_option(key):
+    lib = load()
+    v = C.c_int32()
+    check(lib.gan_get_option(key.encode(), C.byref(v)), f"gan_get_option({key})")
+    return v.value
 
 
 def check(rc, what):

@@ -127,13 +127,55 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned char* lds_wave
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+// Cross-workgroup exchange INSIDE one launch (conv_stack_kernel): the L2s of the 8 XCDs are not coherent with each other, so data
+// that another workgroup reads later in the same kernel is written through (sc0 sc1 stores) and read around the L2 (sc0 sc1 loads)
+// - measured coherent without any cache maintenance (tools/probes/gridbar_probe.hip).  Buffer instructions so that the compiler
+// tracks the stores' data registers (an inline-asm store re-used them too early).  COH = false: plain accesses.
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+struct CohBuf { __amdgpu_buffer_rsrc_t r; const unsigned char* base; };
+__device__ __forceinline__ CohBuf coh_buf(const void* base) {
+  CohBuf b;
+  b.r = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0xfffffff0u, 0x00020000);
+  b.base = (const unsigned char*)base;
+  return b;
+}
+template <bool COH> __device__ __forceinline__ f32x4 ld_f4(const CohBuf& b, const float* ptr) {
+  if constexpr (COH) {
+    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(b.r, (unsigned)((const unsigned char*)ptr - b.base), 0, 0x11);
+    return f32x4{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+  } else {
+    return *(const f32x4*)ptr;
+  }
+}
+template <bool COH> __device__ __forceinline__ void st_f4(const CohBuf& b, float* ptr, const f32x4& v) {
+  if constexpr (COH) {
+    const u32x4_t u = u32x4_t{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+    __builtin_amdgcn_raw_buffer_store_b128(u, b.r, (unsigned)((const unsigned char*)ptr - b.base), 0, 0x11);
+  } else {
+    *(f32x4*)ptr = v;
+  }
+}
+template <bool COH> __device__ __forceinline__ uint2 ld_u2(const CohBuf& b, const void* ptr) {
+  if constexpr (COH) {
+    const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(b.r, (unsigned)((const unsigned char*)ptr - b.base), 0, 0x11);
+    return make_uint2(v.x, v.y);
+  } else {
+    return *(const uint2*)ptr;
+  }
+}
+template <bool COH> __device__ __forceinline__ void st_u2(const CohBuf& b, void* ptr, const uint2& v) {
+  if constexpr (COH) __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{v.x, v.y}, b.r, (unsigned)((const unsigned char*)ptr - b.base), 0, 0x11);
+  else *(uint2*)ptr = v;
+}
+
 // Epilogue shared by the GEMM kernels.  The MFMAs ran with the weights as the "A" operand, so the accumulators hold
 // the transposed tile: acc[i][j][e] = Y[pixel row i*16 + (lane & 15)][channel j*16 + (lane >> 4)*4 + e] - four
 // consecutive channels of one pixel per lane, which pack into one 8-byte (bf16) / 16-byte (fp32) write.  SMEMB bytes of
 // LDS at `smem` are free for staging (the caller has passed a block barrier after its last LDS read).
 // PARCOLS (conv_par_kernel): the tile's BN = 4 x PCOLS columns are (output parity, channel) pairs - column block v / PCOLS
 // goes to the output pixel of parity v / PCOLS, channel bn0 + v % PCOLS; statistics partials come out as one chunk per parity.
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int SMEMB, bool PARCOLS = false>
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int SMEMB, bool PARCOLS = false, bool COH = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[BM / WAVES_M / 16][BN / WAVES_N / 16],
                                               unsigned char* smem, int bm0, int bn0, int par, int P, int split) {
   constexpr int VEC = VecOf<T>::N;
@@ -148,6 +190,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
   const int py = par >> 1, px = par & 1;
   if (p.splits > 1) {
     float* slab = p.slab + (size_t)(par * p.splits + split) * p.M * p.NslabPitch;
+    const CohBuf cb = coh_buf(p.slab);
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
       const int m = bm0 + wm * WTM + i * 16 + r;
@@ -156,8 +199,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
         for (int j = 0; j < NT; ++j) {
           const int col = bn0 + wn * WTN + j * 16 + q * 4;
           // (splitk_norm_kernel reads 8-channel slices of all rows: its slabs are laid out [slice][row][8] so that a slice is contiguous)
-          if (p.skn) *(f32x4*)(slab + ((size_t)(col >> 3) * p.M + m) * 8 + (col & 7)) = acc[i][j];
-          else *(f32x4*)(slab + (size_t)m * p.NslabPitch + col) = acc[i][j];
+          if (p.skn) st_f4<COH>(cb, slab + ((size_t)(col >> 3) * p.M + m) * 8 + (col & 7), acc[i][j]);
+          else st_f4<COH>(cb, slab + (size_t)m * p.NslabPitch + col, acc[i][j]);
         }
       }
     }
@@ -339,8 +382,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
 }
 
 // BKB: bytes of K per LDS row / pipeline step (128 or 64); NS: LDS stages (NS-1 tiles in flight)
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int BKB, int NS>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_gemm_kernel(const GemmParams p) {
+// One block tile of the tap-gather GEMM: logical block index bx (what blockIdx.x is for the stand-alone kernel) and K split `split`.
+// COH: the A operand was written earlier in the SAME launch by other workgroups (conv_stack_kernel): its LDS-DMA loads go around the
+// L2 (sc0 sc1) and the slabs are written through.
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int BKB, int NS, bool COH>
+__device__ __forceinline__ void conv_gemm_body(const GemmParams& p, unsigned char* smem, int bx, int split) {
 #if defined(__HIP_DEVICE_COMPILE__)   // body uses device-only buffer-descriptor builtins; the host pass only needs the stub
   constexpr int VEC = VecOf<T>::N;
   constexpr int NW = WAVES_M * WAVES_N, NTHREADS = 64 * NW;
@@ -353,7 +399,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_gemm_kernel(const
   static_assert(NS == 2 || (AINS % NW == 0 && BINS % NW == 0), "counted vmcnt needs equal pieces per wave");
   // slot swizzle so that the 16 rows of a ds_read_b128 fragment read hit 16 distinct 16-B bank groups
   auto fsw = [](int row) { return BKB == 128 ? (row & 7) : ((0 - (row >> 2)) & 3); };
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -366,13 +411,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_gemm_kernel(const
   // blockIdx.x enumerates (M tile, N tile, parity) with the parity fastest: the 4 parity sub-GEMMs of a tile
   // gather the same source rows, so they run next to each other on one XCD and share them in L2.
   const int P = p.parity ? 4 : 1;
-  int bid = blockIdx.x;
+  int bid = bx;
   const int nb = p.tilesM * p.tilesN * P;
   if ((nb & 7) == 0) bid = (bid & 7) * (nb >> 3) + (bid >> 3);
   const int par = bid % P;
   bid /= P;
   const int bm0 = (bid / p.tilesN) * BM, bn0 = (bid % p.tilesN) * BN;
-  const int split = blockIdx.z;
   const int py = par >> 1, px = par & 1;
   int dy0 = p.dy0, dx0 = p.dx0, wy0 = p.wy0, wx0 = p.wx0;
   if (p.parity) { dy0 = py; dx0 = px; wy0 = 1 - py; wx0 = 1 - px; }
@@ -443,7 +487,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_gemm_kernel(const
     if (idx < AI) {
       const int ia = wave + NW * idx;
       if (ia < AINS)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(As + ia * 1024), 16, va[idx], 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(As + ia * 1024), 16, va[idx], 0, 0, COH ? 0x11 : 0);
     } else {
       const int ib = wave + NW * (idx - AI);
       if (ib < BINS)
@@ -528,8 +572,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_gemm_kernel(const
   }
   __syncthreads();
 
-  gemm_epilogue<T, BM, BN, WAVES_M, WAVES_N, NS * STAGE + 16 * BM * 4>(p, acc, smem, bm0, bn0, par, P, split);
+  gemm_epilogue<T, BM, BN, WAVES_M, WAVES_N, NS * STAGE + 16 * BM * 4, false, COH>(p, acc, smem, bm0, bn0, par, P, split);
 #endif
+}
+
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int BKB, int NS>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_gemm_kernel(const GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  conv_gemm_body<T, BM, BN, WAVES_M, WAVES_N, BKB, NS, false>(p, smem, (int)blockIdx.x, (int)blockIdx.z);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1077,35 +1127,43 @@ __global__ __launch_bounds__(256) void splitk_reduce4_kernel(const GemmParams p,
 // Arithmetic per element = splitk_reduce4_kernel + stats_finalize / bwd_finalize + norm_act_fwd / norm_act_bwd (norm.hip); the
 // per-channel sums are taken in a different (fixed) order.  gridDim.y == groups: one group per workgroup; gridDim.y == 1: the
 // workgroup walks the groups in order (moving averages of successive BatchNormalization calls; dgamma / dbeta over the groups).
-template <typename T, int MODE, int KR>       // KR: rows per thread (1, 2, 4, 8): 128 * KR >= rows per group
-__global__ __launch_bounds__(256) void splitk_norm_kernel(const GemmParams p, int P) {
+// bx / by / gy: the block coordinates and the y extent of the grid of the stand-alone kernel.  COH (conv_stack_kernel): the slabs and the skip
+// gradient were written earlier in the same launch by other workgroups and the outputs are read later in it: loads around / stores through
+// the L2 (sc0 sc1).
+template <typename T, int MODE, int KR, bool COH>       // KR: rows per thread (1, 2, 4, 8): 128 * KR >= rows per group
+__device__ __forceinline__ void splitk_norm_body(const GemmParams& p, int P, int bx, int by, int gy) {
   constexpr int RS = 128, UNR = 16 / KR;         // 16 slab loads in flight per thread (a row at a time the kernel is latency-bound)
   __shared__ double red[4][8][2];
   __shared__ float bc[8][4];
   const int tid = threadIdx.x, cv = tid & 1, rs = tid >> 1, lane = tid & 63, wave = tid >> 6;
-  const int n = blockIdx.x * 8 + cv * 4;
+  const int n = bx * 8 + cv * 4;
   const int groups = p.skn_groups, Mg = p.M / groups, Rg = P * Mg;
   const size_t sstride = (size_t)p.M * p.NslabPitch;
-  const int g0 = gridDim.y > 1 ? blockIdx.y : 0, g1 = gridDim.y > 1 ? g0 + 1 : groups;
+  const int g0 = gy > 1 ? by : 0, g1 = gy > 1 ? g0 + 1 : groups;
+  const CohBuf cslab = coh_buf(p.slab), cout = coh_buf(p.skn_out), cy = coh_buf(p.y), cadd = coh_buf(p.bf_add);
   auto ld4 = [](const void* base, size_t off, float* out) {
     if constexpr (sizeof(T) == 4) { const f32x4 q = *(const f32x4*)((const float*)base + off); out[0] = q[0]; out[1] = q[1]; out[2] = q[2]; out[3] = q[3]; }
     else { float t8[8]; const uint2 q = *(const uint2*)((const T*)base + off); unpack16<T>(make_uint4(q.x, q.y, 0u, 0u), t8); out[0] = t8[0]; out[1] = t8[1]; out[2] = t8[2]; out[3] = t8[3]; }
   };
-  auto st4 = [](void* base, size_t off, const float* v, bool f32) {
-    if (f32 || sizeof(T) == 4) *(f32x4*)((float*)base + off) = f32x4{v[0], v[1], v[2], v[3]};
-    else *(uint2*)((T*)base + off) = make_uint2(pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]));
+  auto ld4c = [](const CohBuf& cbuf, const void* base, size_t off, float* out) {     // the same through the coherent path (COH)
+    if constexpr (sizeof(T) == 4) { const f32x4 q = ld_f4<COH>(cbuf, (const float*)base + off); out[0] = q[0]; out[1] = q[1]; out[2] = q[2]; out[3] = q[3]; }
+    else { float t8[8]; const uint2 q = ld_u2<COH>(cbuf, (const T*)base + off); unpack16<T>(make_uint4(q.x, q.y, 0u, 0u), t8); out[0] = t8[0]; out[1] = t8[1]; out[2] = t8[2]; out[3] = t8[3]; }
+  };
+  auto st4 = [](const CohBuf& cbuf, void* base, size_t off, const float* v, bool f32) {
+    if (f32 || sizeof(T) == 4) st_f4<COH>(cbuf, (float*)base + off, f32x4{v[0], v[1], v[2], v[3]});
+    else st_u2<COH>(cbuf, (T*)base + off, make_uint2(pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3])));
   };
   // slabs of this kernel's launches: [parity * splits + split][8-channel slice][row][8] (gemm_epilogue, p.skn)
   auto slab_sum = [&](int par, int m, float* v) {
-    const float* src = p.slab + (size_t)par * p.splits * sstride + ((size_t)blockIdx.x * p.M + m) * 8 + cv * 4;
+    const float* src = p.slab + (size_t)par * p.splits * sstride + ((size_t)bx * p.M + m) * 8 + cv * 4;
     f32x4 sacc = f32x4{0.f, 0.f, 0.f, 0.f};
     int k = 0;
     for (; k + 4 <= p.splits; k += 4) {
-      const f32x4 a = *(const f32x4*)(src + (size_t)k * sstride), b = *(const f32x4*)(src + (size_t)(k + 1) * sstride);
-      const f32x4 c = *(const f32x4*)(src + (size_t)(k + 2) * sstride), d = *(const f32x4*)(src + (size_t)(k + 3) * sstride);
+      const f32x4 a = ld_f4<COH>(cslab, src + (size_t)k * sstride), b = ld_f4<COH>(cslab, src + (size_t)(k + 1) * sstride);
+      const f32x4 c = ld_f4<COH>(cslab, src + (size_t)(k + 2) * sstride), d = ld_f4<COH>(cslab, src + (size_t)(k + 3) * sstride);
       sacc += a; sacc += b; sacc += c; sacc += d;
     }
-    for (; k < p.splits; ++k) sacc += *(const f32x4*)(src + (size_t)k * sstride);
+    for (; k < p.splits; ++k) sacc += ld_f4<COH>(cslab, src + (size_t)k * sstride);
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = (p.out_f32 || sizeof(T) == 4) ? sacc[e] : (float)(T)sacc[e];      // as stored
   };
@@ -1129,12 +1187,12 @@ __global__ __launch_bounds__(256) void splitk_norm_kernel(const GemmParams p, in
     *t1 = red[0][c][0] + red[1][c][0] + red[2][c][0] + red[3][c][0];
     *t2 = red[0][c][1] + red[1][c][1] + red[2][c][1] + red[3][c][1];
   };
-  if (MODE == 2 && blockIdx.x * 8 >= p.bf_cols) {             // skip half of a decoder concat: plain gradient
+  if (MODE == 2 && bx * 8 >= p.bf_cols) {                     // skip half of a decoder concat: plain gradient
     for (int row = rs; row < P * p.M; row += RS) {
       const int par = row / p.M, m = row - par * p.M;
       float v[4];
       slab_sum(par, m, v);
-      st4(p.y, out_pixel_index(p, m, par >> 1, par & 1) * (size_t)p.ypitch + n, v, p.out_f32);
+      st4(cy, p.y, out_pixel_index(p, m, par >> 1, par & 1) * (size_t)p.ypitch + n, v, p.out_f32);
     }
     return;
   }
@@ -1161,7 +1219,7 @@ __global__ __launch_bounds__(256) void splitk_norm_kernel(const GemmParams p, in
         if (row >= Rg) row = rs < Rg ? rs : 0;                 // (clamped: loaded, never used)
         const int par = row / Mg, m = g * Mg + (row - par * Mg);
         pix[k] = out_pixel_index(p, m, par >> 1, par & 1);
-        src[k] = p.slab + (size_t)par * p.splits * sstride + ((size_t)blockIdx.x * p.M + m) * 8 + cv * 4;
+        src[k] = p.slab + (size_t)par * p.splits * sstride + ((size_t)bx * p.M + m) * 8 + cv * 4;
       }
       f32x4 sacc[KR];
 #pragma unroll
@@ -1172,7 +1230,7 @@ __global__ __launch_bounds__(256) void splitk_norm_kernel(const GemmParams p, in
 #pragma unroll
         for (int u = 0; u < UNR; ++u)
 #pragma unroll
-          for (int k = 0; k < KR; ++k) t[u][k] = *(const f32x4*)(src[k] + (size_t)(sp + u) * sstride);
+          for (int k = 0; k < KR; ++k) t[u][k] = ld_f4<COH>(cslab, src[k] + (size_t)(sp + u) * sstride);
 #pragma unroll
         for (int u = 0; u < UNR; ++u)
 #pragma unroll
@@ -1180,7 +1238,7 @@ __global__ __launch_bounds__(256) void splitk_norm_kernel(const GemmParams p, in
       }
       for (; sp < p.splits; ++sp) {
 #pragma unroll
-        for (int k = 0; k < KR; ++k) sacc[k] += *(const f32x4*)(src[k] + (size_t)sp * sstride);
+        for (int k = 0; k < KR; ++k) sacc[k] += ld_f4<COH>(cslab, src[k] + (size_t)sp * sstride);
       }
 #pragma unroll
       for (int k = 0; k < KR; ++k)
@@ -1192,13 +1250,13 @@ __global__ __launch_bounds__(256) void splitk_norm_kernel(const GemmParams p, in
       const int row = rs + RS * k;
       if (row < Rg) {
         if (MODE == 1) {
-          st4(p.y, pix[k] * (size_t)p.ypitch + n, va[k], p.out_f32);
+          st4(cy, p.y, pix[k] * (size_t)p.ypitch + n, va[k], p.out_f32);
 #pragma unroll
           for (int e = 0; e < 4; ++e) { s1[e] += va[k][e]; s2[e] = fmaf(va[k][e], va[k][e], s2[e]); }
         } else {
           float rf[4], a2[4];
           if (p.bf_add) {
-            ld4(p.bf_add, pix[k] * (size_t)p.bf_addpitch + n, a2);
+            ld4c(cadd, p.bf_add, pix[k] * (size_t)p.bf_addpitch + n, a2);
 #pragma unroll
             for (int e = 0; e < 4; ++e) va[k][e] += a2[e];
           }
@@ -1224,7 +1282,7 @@ __global__ __launch_bounds__(256) void splitk_norm_kernel(const GemmParams p, in
     }
     double t1, t2;
     block_sums(s1, s2, &t1, &t2);
-    const int c = tid & 7, cn = blockIdx.x * 8 + c;
+    const int c = tid & 7, cn = bx * 8 + c;
     if (MODE == 1) {
       if (tid < 8) {
         const double rows = (double)Rg;
@@ -1260,7 +1318,7 @@ __global__ __launch_bounds__(256) void splitk_norm_kernel(const GemmParams p, in
             if (p.skn_mask) z *= mk[e];
             o[e] = apply_act(z, p.skn_act, p.skn_slope);
           }
-          st4(p.skn_out, pix[k] * (size_t)p.skn_outpitch + n, o, false);
+          st4(cout, p.skn_out, pix[k] * (size_t)p.skn_outpitch + n, o, false);
         }
       }
     } else {
@@ -1276,16 +1334,21 @@ __global__ __launch_bounds__(256) void splitk_norm_kernel(const GemmParams p, in
           float o[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) o[e] = fmaf(va[k][e], bc[cv * 4 + e][0], fmaf(vb[k][e], bc[cv * 4 + e][2], bc[cv * 4 + e][1]));
-          st4(p.skn_out, pix[k] * (size_t)p.skn_outpitch + n, o, false);
+          st4(cout, p.skn_out, pix[k] * (size_t)p.skn_outpitch + n, o, false);
         }
       }
     }
   }
   if (MODE == 2 && tid < 8) {
-    const int cn = blockIdx.x * 8 + tid;
+    const int cn = bx * 8 + tid;
     if (p.skn_dgamma) p.skn_dgamma[cn] = (p.skn_accumulate ? p.skn_dgamma[cn] : 0.f) + (float)tg;
     if (p.skn_dbeta) p.skn_dbeta[cn] = (p.skn_accumulate ? p.skn_dbeta[cn] : 0.f) + (float)tb;
   }
+}
+
+template <typename T, int MODE, int KR>
+__global__ __launch_bounds__(256) void splitk_norm_kernel(const GemmParams p, int P) {
+  splitk_norm_body<T, MODE, KR, false>(p, P, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.y);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1611,6 +1674,94 @@ static int launch_gemm(const GemmPlan& pl, hipStream_t st) {
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Layer stack (round 4): a run of consecutive SMALL split-K layers - each a GEMM into fp32 slabs plus the slab reduce that finishes
+// the layer (GanNormFuse: statistics + normalise + activation forward, dz / dy backward) - in ONE launch: a resident grid walks
+// the layers, GEMM tiles and finishing work units are dealt round-robin to the workgroups, and a grid barrier separates the phases
+// (2 per layer).  What crosses workgroups inside the launch (slabs, a layer's output = the next layer's GEMM operand, the skip
+// gradient) is written through / read around the per-XCD L2s (COH = true bodies above), so the barrier itself is atomics only:
+// hierarchical, 8 group counters (workgroup & 7 = its XCD under round-robin dispatch) -> a master counter -> 8 release words,
+// all monotonic (no reset, valid from one launch to the next as long as the grid size of a plan never changes).  Measured 2.2 us per
+// barrier at 256 workgroups (tools/probes/gridbar_probe.hip).  Every wait is bounded (~2 s): a grid that cannot become resident
+// sets *err and runs to completion instead of hanging the GPU.  LDS <= 78 KB and 256 threads per workgroup: two of these kernels
+// fit side by side on every CU (the two chains of the CycleGAN step).
+struct StackLayer {
+  GemmParams p;
+  int P, tile;               // parities; tile 0 = 64 x 128 (4 waves 2 x 2), 1 = 16 x 128 (4 waves 1 x 4)
+  int gx, items;             // GEMM work items = gx (block tiles) x splits
+  int fin_mode, fin_kr, fin_gx, fin_gy;      // finishing work units = fin_gx (8-channel slices) x fin_gy (groups, or 1)
+};
+struct StackBar { unsigned long long grp[8][16]; unsigned long long master[16]; unsigned long long rel[8][16]; };
+
+__device__ __forceinline__ void stack_barrier(StackBar* bar, unsigned nblocks, int* err) {
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");          // this wave's stores have been acknowledged
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned g = blockIdx.x & 7, per = nblocks >> 3;
+    const unsigned long long seen = __hip_atomic_load(&bar->rel[g][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long old = __hip_atomic_fetch_add(&bar->grp[g][0], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (old % per == per - 1) {                                         // last of its group
+      const unsigned long long m = __hip_atomic_fetch_add(&bar->master[0], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (m % 8 == 7)                                                   // last group: release everyone
+        for (int k = 0; k < 8; ++k) __hip_atomic_fetch_add(&bar->rel[k][0], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__hip_atomic_load(&bar->rel[g][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == seen) {
+      __builtin_amdgcn_s_sleep(1);
+      if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) { *err = 1; break; }      // 2 s at 100 MHz: give up, never hang
+    }
+  }
+  __syncthreads();
+}
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void conv_stack_kernel(const StackLayer* __restrict__ layers, int n, StackBar* bar, int* err) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int nb = (int)gridDim.x;
+  for (int l = 0; l < n; ++l) {
+    const StackLayer& L = layers[l];
+    // ---- GEMM phase: block tiles x K splits -> fp32 slabs ----
+    for (int item = (int)blockIdx.x; item < L.items; item += nb) {
+      const int bx = item % L.gx, split = item / L.gx;
+      if (L.tile == 0) conv_gemm_body<T, 64, 128, 2, 2, 128, 3, true>(L.p, smem, bx, split);
+      else conv_gemm_body<T, 16, 128, 1, 4, 128, 2, true>(L.p, smem, bx, split);
+      __syncthreads();                                                  // (the next item rebuilds the gather table in the same LDS)
+    }
+    stack_barrier(bar, (unsigned)nb, err);
+    // ---- finishing phase: slab sums + the layer's normalisation (forward) / dz, dy (backward) ----
+    for (int item = (int)blockIdx.x; item < L.fin_gx * L.fin_gy; item += nb) {
+      const int bx = item % L.fin_gx, by = item / L.fin_gx;
+#define SKN_BODY(MODE, KRV) splitk_norm_body<T, MODE, KRV, true>(L.p, L.P, bx, by, L.fin_gy)
+      // (groups of up to 512 rows only: the 1024-row variant needs ~350 registers, and this kernel is held to 256 so that two
+      // of its workgroups fit on a CU)
+      if (L.fin_mode == 1) { if (L.fin_kr == 1) SKN_BODY(1, 1); else if (L.fin_kr == 2) SKN_BODY(1, 2); else SKN_BODY(1, 4); }
+      else { if (L.fin_kr == 1) SKN_BODY(2, 1); else if (L.fin_kr == 2) SKN_BODY(2, 2); else SKN_BODY(2, 4); }
+#undef SKN_BODY
+      __syncthreads();
+    }
+    if (l + 1 < n) stack_barrier(bar, (unsigned)nb, err);
+  }
+#endif
+}
+
+struct StackHeader { uint32_t magic, n, grid, dtype; size_t smem; };
+static constexpr uint32_t STACK_MAGIC = 0x474e5334u;
+
+template <typename T>
+static int launch_stack(const StackHeader* h, const void* dev_plan, void* bar, int32_t* err, hipStream_t st) {
+  static size_t attr_smem = 0;
+  auto kern = conv_stack_kernel<T>;
+  if (h->smem > attr_smem) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smem);
+    if (e != hipSuccess) return (int)e;
+    attr_smem = h->smem;
+  }
+  hipLaunchKernelGGL(kern, dim3(h->grid), dim3(256), h->smem, st, (const StackLayer*)((const char*)dev_plan + 256), (int)h->n, (StackBar*)bar, (int*)err);
+  GAN_CHECK_LAUNCH();
+  return 0;
+}
+
 static int run_gemm(const GanConvDesc* d, int op, gan_stream_t stream) {
   GemmPlan pl;
   int rc = plan_gemm(d, op, &pl);
@@ -1652,6 +1803,72 @@ int gan_conv_plan_info(const GanConvDesc* d, int op, int32_t* info /*[5]: BM, BN
   if (const int fam = thin_family(&t, op, pl.p)) { info[0] = 0; info[1] = fam; info[2] = 1; info[4] = 0; }   // thin.hip kernels
   return 0;
 }
+/* ---- layer stack: plan on the host, launch from a device copy of the plan ---- */
+size_t gan_conv_stack_plan_bytes(int32_t n) { return n > 0 ? 256 + (size_t)n * sizeof(StackLayer) : 0; }
+
+// one layer's plan as a stack layer; GAN_E_SHAPE when the launch cannot join a stack
+static int stack_layer_plan(const GanConvDesc* d, int op, GemmPlan& pl, int* tile, long long* rg) {
+  if (!d || d->struct_size != sizeof(GanConvDesc) || op < 0 || op > 3) return GAN_E_ARG;
+  int rc = plan_gemm(d, op, &pl);
+  if (rc) return rc;
+  if (thin_family(d, op, pl.p) || !pl.p.skn || pl.p.splits <= 1 || pl.pp || pl.par_npw) return GAN_E_SHAPE;   // small split-K layers finished by their reduce only
+  if (pl.bf_requested && !pl.p.bf_mode) return GAN_E_SHAPE;
+  if (pl.BM == 64 && pl.BN == 128) *tile = 0; else if (pl.BM == 16 && pl.BN == 128) *tile = 1; else return GAN_E_SHAPE;
+  *rg = (long long)pl.P * (pl.p.M / pl.p.skn_groups);
+  if (*rg > 512) return GAN_E_SHAPE;                                  // (conv_stack_kernel: register budget of two workgroups per CU)
+  return 0;
+}
+
+int gan_conv_stack_eligible(const GanConvDesc* d, int op) {
+  if (!d || d->struct_size != sizeof(GanConvDesc)) return GAN_E_ARG;
+  GemmPlan pl;
+  GanConvDesc t = *d;
+  plan_only_desc(&t);
+  int tile; long long rg;
+  const int rc = stack_layer_plan(&t, op, pl, &tile, &rg);
+  return rc == 0 ? 1 : (rc == GAN_E_SHAPE ? 0 : rc);
+}
+
+int gan_conv_stack_plan(const GanConvDesc* const* descs, const int32_t* ops, int32_t n, void* host_plan, size_t plan_bytes) {
+  if (!descs || !ops || n <= 0 || n > 32 || !host_plan || plan_bytes < gan_conv_stack_plan_bytes(n)) return GAN_E_ARG;
+  StackHeader* h = (StackHeader*)host_plan;
+  StackLayer* L = (StackLayer*)((char*)host_plan + 256);
+  size_t smem = 0;
+  for (int i = 0; i < n; ++i) {
+    const GanConvDesc* d = descs[i];
+    if (!d || d->dtype != descs[0]->dtype) return GAN_E_ARG;
+    GemmPlan pl;
+    int tile; long long rg;
+    int rc = stack_layer_plan(d, ops[i], pl, &tile, &rg);
+    if (rc) return rc;
+    if (pl.slab_bytes > d->workspace_bytes || !d->workspace) return GAN_E_WORKSPACE;
+    StackLayer& s = L[i];
+    s.p = pl.p; s.P = pl.P; s.tile = tile;
+    s.gx = (int)pl.grid.x; s.items = (int)(pl.grid.x * pl.grid.z);
+    s.fin_mode = pl.p.skn;
+    s.fin_gx = pl.p.Cout / 8;
+    s.fin_gy = (pl.p.skn == 1 && !(pl.p.skn_mmean && pl.p.skn_groups > 1)) ? pl.p.skn_groups : 1;
+    s.fin_kr = rg <= 128 ? 1 : rg <= 256 ? 2 : 4;
+    const size_t sm = tile == 0 ? (size_t)3 * (64 + 128) * 128 + 16 * 64 * sizeof(int) : (size_t)2 * (16 + 128) * 128 + 16 * 16 * sizeof(int);
+    if (sm > smem) smem = sm;
+  }
+  h->magic = STACK_MAGIC; h->n = (uint32_t)n; h->dtype = (uint32_t)descs[0]->dtype; h->smem = smem;
+  int grid = gan_opt("conv.stack_blocks");
+  if (grid < 8) grid = 8;
+  h->grid = (uint32_t)(grid & ~7);
+  return 0;
+}
+
+int gan_conv_stack_launch(const void* host_plan, const void* dev_plan, void* barrier_state, int32_t* err_flag, gan_stream_t stream) {
+  const StackHeader* h = (const StackHeader*)host_plan;
+  if (!h || h->magic != STACK_MAGIC || !dev_plan || !barrier_state || !err_flag || ((uintptr_t)barrier_state & 127)) return GAN_E_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  return h->dtype == GAN_F32 ? launch_stack<float>(h, dev_plan, barrier_state, err_flag, st)
+       : h->dtype == GAN_F16 ? launch_stack<f16_t>(h, dev_plan, barrier_state, err_flag, st)
+                             : launch_stack<bf16_t>(h, dev_plan, barrier_state, err_flag, st);
+}
+size_t gan_conv_stack_barrier_bytes(void) { return sizeof(StackBar); }
+
 size_t gan_conv_workspace_bytes(const GanConvDesc* d, int op) {
   if (!d || d->struct_size != sizeof(GanConvDesc)) return 0;
   GemmPlan pl;

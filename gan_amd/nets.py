@@ -86,6 +86,9 @@ class Ctx:
         self.ws_ptr, self.ws_bytes = self.ws.data_ptr(), self.ws.numel()
         self.side = [LaneStream(device=self.device) for _ in range(4)]     # lanes 1..4 (4: early optimiser step)
         self.lanes = bool(lanes)
+        # layer stacks (gan_conv_stack_*): one timeout flag for all of them - a grid barrier that could not complete sets it
+        self.stack_err = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self.use_stacks = bool(L.get_option('conv.stack'))
 
     def stream(self):
         return torch.cuda.current_stream(self.device).cuda_stream
@@ -142,6 +145,12 @@ class Ctx:
 
     def lane_stream(self, lane):
         return torch.cuda.current_stream(self.device) if lane == 0 else self.side[lane - 1]
+
+    def assert_no_stack_timeout(self):
+        """Synchronising check: a persistent layer-stack kernel whose grid never became resident gives up after ~2 s and raises this
+        flag instead of hanging the GPU (its results are then garbage)."""
+        if int(self.stack_err.item()):
+            raise L.GanAmdError("a layer-stack kernel timed out at a grid barrier (more than two of them running at once?)")
 
     def run_on(self, ops, stream):
         """All ops in program order on one explicit stream."""
@@ -508,6 +517,9 @@ class _Builder:
             kname += "+splitK"          # two kernels per call (GEMM into fp32 slabs + the slab-reduce kernel): timed as their own class
         meta = dict(kind='gemm', kernel=kname, flops=flops, splits=info[2],
                     shape=f"{op} M{M}{'x4' if info[3] == 4 else ''} N{y.c} K{T * x.c} s{info[2]}")
+        # a launch that finishes its layer (GanNormFuse) on a small tile may join a layer stack (merge_stacks below)
+        if self.last_full and self.lib.gan_conv_stack_eligible(C.byref(d), opi) == 1:
+            meta['stack'] = (d, opi)
         return (fn, (self._desc(d),), op, meta)
 
     def wgrad(self, big, small, dw_ptr, big_c, small_c, stride, accumulate, adam_fuse=None, wire_ptr=None):
@@ -599,6 +611,57 @@ class _Builder:
         self.keep.append(dy)
         return (self.lib.gan_bias_grad, (self.ctx.dt, C.byref(dy), dbias_ptr, int(accumulate), self.ws_ptr,
                                          self.ws_bytes), "bias_grad")
+
+
+class _Stack:
+    """Host plan, its device copy and the barrier state of one layer stack (kept alive by the op list that launches it)."""
+
+    def __init__(self, ctx, items):
+        if torch.cuda.is_current_stream_capturing():
+            raise L.GanAmdError("a layer stack's plan is uploaded when its op list is built: build the op lists before the capture "
+                                "(steps.py: _prebuild_fused_adam / the warm-up step)")
+        lib, n = ctx.lib, len(items)
+        self.descs = [d for d, _ in items]
+        arr = (C.c_void_p * n)(*[C.addressof(d) for d in self.descs])
+        ops = (C.c_int32 * n)(*[o for _, o in items])
+        nbytes = lib.gan_conv_stack_plan_bytes(n)
+        self.host = C.create_string_buffer(nbytes)
+        self.rc = lib.gan_conv_stack_plan(arr, ops, n, self.host, nbytes)
+        if self.rc == 0:
+            self.dev = torch.frombuffer(bytearray(self.host.raw), dtype=torch.uint8).to(ctx.device)
+            self.bar = torch.zeros(lib.gan_conv_stack_barrier_bytes(), dtype=torch.uint8, device=ctx.device)
+            self.args = (C.addressof(self.host), self.dev.data_ptr(), self.bar.data_ptr(), ctx.stack_err.data_ptr())
+
+
+def merge_stacks(ctx, ops):
+    """Replace every run of >= 2 consecutive stack-eligible convolution launches (small split-K layers finished by their slab
+    reduce, each consuming what the one before it produced) by ONE persistent launch (gan_conv_stack_launch).  Adjacent ops only:
+    anything between two such launches ends the run."""
+    if not ctx.use_stacks:
+        return ops
+    out, run = [], []
+
+    def flush():
+        if len(run) >= 2:
+            st = _Stack(ctx, [o[3]['stack'] for o in run])
+            if st.rc:
+                L.check(st.rc, "conv_stack_plan")        # (every layer answered gan_conv_stack_eligible() == 1: a failure here is an error)
+            if st.rc == 0:
+                meta = dict(kind='gemm', kernel=f"conv_stack<{ctx.dtype},{len(run)} layers>", flops=sum(o[3]['flops'] for o in run), splits=0,
+                            shape="stack: " + " | ".join(o[3]['shape'] for o in run), keep=(st, list(run)))
+                out.append((ctx.lib.gan_conv_stack_launch, st.args, "conv_stack", meta))
+                run.clear()
+                return
+        out.extend(run)
+        run.clear()
+    for o in ops:
+        if len(o) > 3 and isinstance(o[3], dict) and 'stack' in o[3] and not (len(o) > 4 and o[4]):
+            run.append(o)
+        else:
+            flush()
+            out.append(o)
+    flush()
+    return out
 
 
 class GeneratorNet:
@@ -717,7 +780,9 @@ class GenCall:
                                    fused_chunks=bd.last_stats_chunks, fused_ptr=bd.last_stats_ptr)
         fwd.append(bd.conv('convT_fwd', self.cat[6].view(), self.out.view(0, C_), P.nat['last.kernel'].data_ptr(), C_, 2,
                            P.ptr('last.bias'), 'tanh'))
-        self.fwd_ops = fwd
+        head = merge_stacks(ctx, fwd[:self.fwd_inner_start])
+        self.fwd_ops = head + merge_stacks(ctx, fwd[self.fwd_inner_start:])
+        self.fwd_inner_start = len(head)
 
         # ---------------- backward ----------------
         self.dcat = [Buf(ctx, B, hs[6 - j], hs[6 - j], G_UP[j] + G_DOWN[6 - j]) for j in range(7)]
@@ -913,17 +978,17 @@ class GenCall:
             # layers before cut k start when the main dgrad/norm chain has passed cut k - per-op dependencies thrash
             # (two LDS-bound GEMMs on the same CUs), one stage at the very end leaves the tail serial
             main = self.ctx.lane_stream(0)
-            is_w = lambda o: len(o) > 4 and o[4]
-            idx = [i for i, o in enumerate(ops) if is_w(o)]
-            bounds = [0] + [idx[c] for c in self.wgrad_cuts if 0 < c < len(idx)] + [len(ops)]
-            for k, (lo, hi) in enumerate(zip(bounds[:-1], bounds[1:])):
-                self.ctx.run([o for o in ops[lo:hi] if not is_w(o)])
+            for k, (main_ops, w_ops) in enumerate(self.bwd_stages(self.wgrad_cuts, use_dgen2, need_dx, accumulate, wgrads, adam)):
+                self.ctx.run(main_ops)
                 self.wgrad_stream.wait_stream(main)
-                self.ctx.run_on([o for o in ops[lo:hi] if is_w(o)], self.wgrad_stream)
+                self.ctx.run_on(w_ops, self.wgrad_stream)
                 if getattr(self, 'stage_hook', None) is not None:
                     self.stage_hook(k)         # e.g. the optimiser step of the layers whose gradients are now complete
         else:
-            self.ctx.run(ops)
+            mkey = ('all', key)
+            if mkey not in self._bwd_cache:
+                self._bwd_cache[mkey] = merge_stacks(self.ctx, ops)      # (adjacent launches only: wgrads between two dgrads end a run)
+            self.ctx.run(self._bwd_cache[mkey])
 
     def bwd_ops(self, use_dgen2=False, need_dx=False, accumulate=False, wgrads='own', adam=None):
         """The (cached) backward op list; building it also settles self.dy0_in_dA and self.adam_fused."""
@@ -943,7 +1008,11 @@ class GenCall:
         is_w = lambda o: len(o) > 4 and o[4]
         idx = [i for i, o in enumerate(ops) if is_w(o)]
         bounds = [0] + [idx[c] for c in cuts if 0 < c < len(idx)] + [len(ops)]
-        return [([o for o in ops[lo:hi] if not is_w(o)], [o for o in ops[lo:hi] if is_w(o)]) for lo, hi in zip(bounds[:-1], bounds[1:])]
+        skey = ('stages', key, tuple(bounds))          # (cached: merged layer stacks hold device plans, built outside any capture)
+        if skey not in self._bwd_cache:
+            self._bwd_cache[skey] = [(merge_stacks(self.ctx, [o for o in ops[lo:hi] if not is_w(o)]), [o for o in ops[lo:hi] if is_w(o)])
+                                     for lo, hi in zip(bounds[:-1], bounds[1:])]
+        return self._bwd_cache[skey]
 
     def output_f32(self):
         o = torch.empty((self.B, self.S, self.S, self.C), dtype=torch.float32, device=self.ctx.device)
@@ -1035,7 +1104,7 @@ class DiscCall:
             prev = self.a[name]
         fwd.append(bd.conv('conv_fwd', prev.view(), self.logits.view(), P.tr['last.kernel'].data_ptr(), 1, 1,
                            P.ptr('last.bias'), None, 1))
-        self.fwd_ops = fwd
+        self.fwd_ops = merge_stacks(ctx, fwd)        # (runs start after down3: fwd_inner_start stays valid)
         # backward buffers (pass B reuses the first B samples' worth of them)
         self.dlogits = Buf(ctx, N, s5, s5, 8)        # pass A: all invocations (channel 0 real)
         self.dlogits_b = Buf(ctx, B, s5, s5, 8)      # pass B: one invocation
@@ -1071,7 +1140,7 @@ class DiscCall:
                 prev = self.a[name]
             ops.append(bd.conv('conv_fwd', sv(prev), sv(self.logits), P.tr['last.kernel'].data_ptr(), 1, 1,
                                P.ptr('last.bias'), None, 1))
-            self._cache[key] = ops
+            self._cache[key] = merge_stacks(self.ctx, ops)
         return self._cache[key]
 
     def logits_view(self, call):
@@ -1147,7 +1216,7 @@ class DiscCall:
                                    P.nat['down0.kernel'].data_ptr(), self.net.cin, 2))
         if wire:
             self.wire_direct = tuple(wire_names)
-        return ops
+        return merge_stacks(self.ctx, ops)       # (adjacent launches only: a wgrad between two dgrads ends a run)
 
     def params_ops(self, accumulate=False, wire=None):
         """wire: data pointer of the network's bf16 wire buffer - wgrad launches that can write their gradient there directly

@@ -159,6 +159,14 @@ class _StepBase:
         def graph(fn):
             return ctx.capture_graph(fn, CAPTURE_MODE)
 
+        # every phase once eagerly: op lists, device tables and layer-stack plans are built (and uploaded) outside the captures
+        s_ = torch.cuda.Stream(device=ctx.device)
+        s_.wait_stream(main)
+        with torch.cuda.stream(s_):
+            for pid, _ in phases:
+                self._forward_backward(*self._static_in, training, phase=pid)
+        main.wait_stream(s_)
+        torch.cuda.synchronize()
         G = [graph(lambda pid=pid: self._forward_backward(*self._static_in, training, phase=pid)) for pid, _ in phases]
         if fp16:
             A = [graph(self._update)]
@@ -249,7 +257,7 @@ class Pix2PixStep(_StepBase):
     def _prebuild_fused_adam(self):
         if self._wgrad_adam_ok() and not self.early_adam:
             adam = (self.b1, self.b2)
-            self.g.bwd_ops(True, False, False, 'own', adam)
+            self.g.bwd_stages(list(self.wgrad_cuts), use_dgen2=True, adam=adam)       # (op lists, layer-stack plans, device tables)
             self.G.params.adam_rest_ops(self.g.adam_fused[(True, False, False, 'own', adam)], self.b1, self.b2)
 
     def _example_inputs(self):
@@ -623,7 +631,7 @@ class CycleGANStep(_StepBase):
         if self._wgrad_adam_ok() and self.merged and self.two_chains and self.early_adam and self.wide_wgrads and self._wide:
             adam = (self.b1, self.b2)
             for call, net in ((self.gA, self.Gg), (self.gB, self.Gf)):
-                call.bwd_ops(True, False, True, 'wide', adam)
+                call.bwd_stages([8, 12], use_dgen2=True, accumulate=True, wgrads='wide', adam=adam)
                 net.params.adam_rest_ops(call.adam_fused[(True, False, True, 'wide', adam)], self.b1, self.b2)
 
     def gen_calls(self):

@@ -133,6 +133,31 @@ size_t gan_conv_workspace_bytes(const GanConvDesc* d, int op /*0 conv_fwd,1 conv
  * finishes the layer) */
 int gan_conv_plan_info(const GanConvDesc* d, int op, int32_t* info);
 
+/* ---- layer stack: a run of consecutive small split-K layers in ONE launch -------------------------------------------------
+ * The inner layers of the U-Net (base_gan.py:183-193: down5..down8, up1..up3 at batch 16; most of the generator at the reference's
+ * CycleGAN batch of 1) are latency chains: a GEMM into fp32 slabs plus the slab reduce that finishes the layer (GanNormFuse), each a
+ * few microseconds of work behind a launch.  gan_conv_stack_* runs such a run of layers from ONE persistent kernel: a resident grid
+ * walks the layers, a grid barrier separates the phases, and what crosses workgroups inside the launch is written through / read
+ * around the per-XCD L2s.  Eligible: a launch whose gan_conv_plan_info()[4] == -1 (norm_fuse honoured), tile 64x128 or 16x128, at
+ * most 512 rows per statistics group; layer i+1 must consume what layer i produced (the caller's op order), all one dtype.
+ *   plan   : host side, once per run of layers -> an opaque blob (gan_conv_stack_plan_bytes(n) bytes) that the caller ALSO copies
+ *            into device memory (256-byte aligned) - the library allocates nothing;
+ *   launch : enqueue-only (hipGraph-capturable).  barrier_state: gan_conv_stack_barrier_bytes() of ZEROED device memory, 128-byte
+ *            aligned, owned by this plan for good (monotonic counters); err_flag: device int32, set to 1 if a grid barrier timed out
+ *            (~2 s: the grid could not become resident) - results are then undefined, the kernel still terminates.
+ * Measured (round 4, tools/bench_stack.py, hipGraph replay on one stream): 5 layers at Pix2Pix batch 16 89.6 us as a stack against
+ * 79.3 us as ten launches; 9 layers at CycleGAN batch 1 141 against 122 us - two grid barriers (2.2 us each + the drain of the
+ * write-through stores) cost more than the two kernel boundaries of a replayed graph (~1.5 us each), and every layer keeps its four
+ * dependent global round trips.  The in-tree callers therefore use it only on request (option conv.stack).
+ * At most TWO stack launches may run concurrently on one GPU (two workgroups of it fit on every CU; a third resident grid could
+ * wait for CUs the other two hold while they wait for each other). */
+int gan_conv_stack_eligible(const GanConvDesc* d, int op);   /* 1: this launch can be a layer of a stack, 0: not, < 0: error code */
+size_t gan_conv_stack_plan_bytes(int32_t n);
+int gan_conv_stack_plan(const GanConvDesc* const* descs, const int32_t* ops /* as gan_conv_plan_info's op */, int32_t n, void* host_plan,
+                        size_t plan_bytes);
+int gan_conv_stack_launch(const void* host_plan, const void* dev_plan, void* barrier_state, int32_t* err_flag, gan_stream_t stream);
+size_t gan_conv_stack_barrier_bytes(void);
+
 /* Optional: the wgrad launch itself applies the optimiser step (TF-form Adam, base_gan.py:247-252 / pix2pix.py:213-216) to the
  * kernel it has just differentiated and refreshes its typed NK copies - the fp32 gradient is then neither written nor read back
  * (dw stays untouched).  Bit-identical to gan_conv_wgrad followed by gan_adam_prepare_multi.  gan_adam_begin must have run for
@@ -364,7 +389,7 @@ const char* gan_version(void);
  * conv.parity_patch_min_blocks (192), conv.split_target (256), conv.split_target_skinny (1024),
  * conv.split_target_big (256), conv.split_min_ktiles (4), conv.split_max (64), conv.bwd_fuse_tile (1: the fused backward
  * epilogue rides on every tile epilogue; 0 never, 2 not on 64-column tiles, 3 on 64-column tiles only), conv.thin (7: bit 0
- * streaming kernels for the <= 8-channel layers, bit 1 thin-N, bit 2 thin-K), conv.norm_fuse (1), conv.thin_fused (1), wgrad.tile256 (0), wgrad.pingpong (1),
+ * streaming kernels for the <= 8-channel layers, bit 1 thin-N, bit 2 thin-K), conv.norm_fuse (1), conv.stack (0: the callers in gan_amd/ merge eligible runs into layer stacks only when set), conv.stack_blocks (256), conv.thin_fused (1), wgrad.tile256 (0), wgrad.pingpong (1),
  * wgrad.pingpong_min_rows (0 = automatic), wgrad.pingpong_128 (1), wgrad.pingpong_min_gflop (30),
  * wgrad.split_target (512), wgrad.reduce_adam (1),
  * wgrad.reduce_adam_min_params (1048576: smaller kernels keep the flat slab reduce and the caller's multi-tensor Adam pass). */

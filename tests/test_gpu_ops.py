@@ -531,6 +531,79 @@ def test_split_k_layer_finished_by_its_slab_reduce(ctx, case, planner_options):
     assert np.all(a[6] == 0)
 
 
+@pytest.mark.parametrize("N,G", [(16, 1), (2, 2), (4, 4)])
+def test_layer_stack_equals_separate_launches(ctx, N, G):
+    """gan_conv_stack_*: three consecutive small split-K layers (conv s2 -> conv s2 -> transposed conv, each finished by its slab
+    reduce: statistics, moving averages, normalise, [dropout,] activation) from ONE persistent launch - grid barriers between the
+    phases, slabs and activations exchanged around the per-XCD L2s - against the same three layers as separate launches: y, the
+    activations, mean / rstd and the moving averages bit for bit (the same arithmetic in the same order).  BatchNorm over the batch
+    (G = 1), two BatchNorm invocations batched along N (G = 2), InstanceNorm (G = N)."""
+    from gan_amd import _lib as L
+    from gan_amd.nets import Buf
+    rng = np.random.default_rng(31)
+    c = 512
+    x = q(ctx, rng.standard_normal((N, 8, 8, c)))
+    ws = [q(ctx, 0.05 * rng.standard_normal((4, 4, c, c))) for _ in range(3)]
+    nk = [prep(ctx, w) for w in ws]
+    f32 = torch.float32
+    gam = [torch.from_numpy((1 + 0.2 * rng.standard_normal(c)).astype(np.float32)).to(ctx.device) for _ in range(3)]
+    bet = [torch.from_numpy((0.2 * rng.standard_normal(c)).astype(np.float32)).to(ctx.device) for _ in range(3)]
+    mask = torch.from_numpy((rng.random((N, 4, 4, c)) > 0.5).astype(np.uint8)).to(ctx.device)
+    shapes = [(8, 4, 'conv_fwd'), (4, 2, 'conv_fwd'), (2, 4, 'convT_fwd')]
+    results = []
+    for stacked in (False, True):
+        xb, xv = dev(ctx, x)
+        ybs = [Buf(ctx, N, ho, ho, c) for _, ho, _ in shapes]
+        abs_ = [Buf(ctx, N, ho, ho, c + 8) for _, ho, _ in shapes]
+        stats = [[torch.zeros(G * c, dtype=f32, device=ctx.device) for _ in range(2)] + [torch.zeros(c, dtype=f32, device=ctx.device),
+                                                                                      torch.ones(c, dtype=f32, device=ctx.device)] for _ in range(3)]
+        part = torch.zeros(1 << 20, dtype=f32, device=ctx.device)
+        descs, keep, opis = [], [], []
+        src = xv
+        for k, (hi, ho, op) in enumerate(shapes):
+            mean, rstd, mm, mv = stats[k]
+            nf = L.GanNormFuse(abs_[k].view(8, c), gam[k].data_ptr(), bet[k].data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                               mm.data_ptr() if G == 1 else None, mv.data_ptr() if G == 1 else None, 1e-3, 0.99,
+                               mask.data_ptr() if k == 2 else None, L.ACTS['relu' if k == 2 else 'lrelu'], 0.3, None, None, 0)
+            w = nk[k][1] if op == 'conv_fwd' else nk[k][0]
+            d = L.GanConvDesc(ctx.dt, 2, src, ybs[k].view(), w.data_ptr(), c, None, 0, 0.3, 0, ctx.ws_ptr, ctx.ws_bytes,
+                              part.data_ptr(), G, part.numel() * 4, None, C.addressof(nf))
+            opi = 0 if op == 'conv_fwd' else 2
+            info = (C.c_int32 * 5)()
+            assert ctx.lib.gan_conv_plan_info(C.byref(d), opi, info) == 0 and info[4] == -1 and info[2] > 1, list(info)
+            descs.append(d); keep.append(nf); opis.append(opi)
+            src = abs_[k].view(8, c)
+        if not stacked:
+            for d, opi in zip(descs, opis):
+                fn = ctx.lib.gan_conv2d_fwd if opi == 0 else ctx.lib.gan_convT2d_fwd
+                assert fn(C.byref(d), ctx.stream()) == 0
+        else:
+            n = len(descs)
+            nb = ctx.lib.gan_conv_stack_plan_bytes(n)
+            hplan = C.create_string_buffer(nb)
+            arr = (C.c_void_p * n)(*[C.addressof(d) for d in descs])
+            assert ctx.lib.gan_conv_stack_plan(arr, (C.c_int32 * n)(*opis), n, hplan, nb) == 0
+            devp = torch.frombuffer(bytearray(hplan.raw), dtype=torch.uint8).to(ctx.device)
+            bar = torch.zeros(ctx.lib.gan_conv_stack_barrier_bytes(), dtype=torch.uint8, device=ctx.device)
+            err = torch.zeros(1, dtype=torch.int32, device=ctx.device)
+            for rep in range(2):          # twice: the barrier state carries over from launch to launch (moving averages advance twice)
+                assert ctx.lib.gan_conv_stack_launch(C.addressof(hplan), devp.data_ptr(), bar.data_ptr(), err.data_ptr(), ctx.stream()) == 0
+            torch.cuda.synchronize()
+            assert int(err.item()) == 0
+        if not stacked:                  # (the same two passes for the reference)
+            for d, opi in zip(descs, opis):
+                fn = ctx.lib.gan_conv2d_fwd if opi == 0 else ctx.lib.gan_convT2d_fwd
+                assert fn(C.byref(d), ctx.stream()) == 0
+        torch.cuda.synchronize()
+        results.append([host(b) for b in ybs] + [host(b, 8, c) for b in abs_] + [t.cpu().numpy() for st_ in stats for t in st_] + [host(b, 0, 8) for b in abs_])
+    a, b = results
+    assert float(np.abs(a[5]).max()) > 0.1                    # the last activation is alive
+    for i, (u, v) in enumerate(zip(a, b)):
+        assert np.array_equal(u, v), i
+    for pad in b[-3:]:
+        assert np.all(pad == 0)                               # channel slices outside the views untouched
+
+
 @pytest.mark.parametrize("case", [('convT_dgrad', 16, 16, 512, 1024, 1, 'relu+mask', 512), ('convT_dgrad', 16, 4, 512, 1024, 1, 'relu', 512),
                                   ('conv_dgrad', 16, 4, 512, 512, 1, 'lrelu', 512), ('conv_dgrad', 2, 4, 512, 512, 2, 'lrelu', 512),
                                   ('convT_dgrad', 2, 16, 512, 512, 2, 'relu', 512)])

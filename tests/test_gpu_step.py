@@ -495,15 +495,18 @@ def _rccl_one_rank_worker(port, q, model, exchange='allreduce'):
     from gan_amd.nets import Ctx
     from gan_amd.steps import CycleGANStep, Pix2PixStep
     out = {}
-    for wire in ('f32', 'bf16'):
+    direct_pack = model == 'pix2pix' and exchange == 'allreduce'
+    for wire in ('f32', 'bf16') + (('bf16-pack',) if direct_pack else ()):
         res = []
-        for ddp in (False, True):
+        for ddp in ((True,) if wire == 'bf16-pack' else (False, True)):
             ctx = Ctx('cuda:0', 'bf16')
             st = Pix2PixStep(ctx, 2, 256, 1, lam=100.0, seed=123) if model == 'pix2pix' else CycleGANStep(ctx, 1, 256, 1, lam=10.0, seed=123)
             st.fused_wgrad_adam = False   # (the one-GPU default leaves no fp32 gradient of the big kernels behind: this test reads them)
             st.wide_wgrads = False        # (CycleGAN one-GPU default: one wgrad GEMM over a generator's three invocations - another summation
+            if wire == 'bf16-pack':       # the same exchange with the separate cast pass instead of wgrad launches that write the wire format
+                st.ddp_wire_direct = False
             if ddp:                       # order than the write + accumulate pair of the phased schedule; compared in its own test)
-                st.sync = GradSync([n.params.grad for n in st.nets()], compress_bf16=(wire == 'bf16'), lib=ctx.lib, rehearse=True, exchange=exchange)
+                st.sync = GradSync([n.params.grad for n in st.nets()], compress_bf16=(wire != 'f32'), lib=ctx.lib, rehearse=True, exchange=exchange)
                 assert st.sync.active and st.sync.world == 1
             g = torch.Generator(device='cpu').manual_seed(5)
             x = [(torch.rand(st.B, 256, 256, 1, generator=g) * 2 - 1).to(ctx.device) for _ in range(2)]
@@ -526,6 +529,8 @@ def _rccl_one_rank_worker(port, q, model, exchange='allreduce'):
             torch.cuda.synchronize()
             res.append(([n.params.master.cpu().numpy() for n in st.nets()], st.losses.cpu().numpy()[:9].copy(),   # (slots 9.. are scratch of the schedule)
                         len(getattr(st, '_graphs', ())), first))
+            if ddp and wire == 'bf16' and direct_pack:
+                out['direct_names'] = {k: sorted(v) for k, v in st._wire_direct_names.items()}
         out[wire] = res
     dist.barrier()
     dist.destroy_process_group()
@@ -549,6 +554,13 @@ def test_ddp_schedule_over_rccl_with_one_rank(model, exchange):
     out = q.get(timeout=900)
     p.join(timeout=120)
     assert p.exitcode == 0
+    if model == 'pix2pix' and exchange == 'allreduce':
+        # the wgrad launches wrote the wire format themselves (every kernel but the tap-folded first / last layers): the same wire
+        # buffers, bit for bit, and the same weights after three steps as with the separate gan_grad_pack pass
+        assert len(out['direct_names'][0]) >= 14 and len(out['direct_names'][1]) >= 3, out['direct_names']
+        (w_d, _, _, f_d), (w_p, _, _, f_p) = out['bf16'][1], out['bf16-pack'][0]
+        for a, b in zip(f_d[0] + f_d[1] + w_d, f_p[0] + f_p[1] + w_p):
+            assert np.array_equal(a, b)
     for wire in ('f32', 'bf16'):
         (w_one, l_one, n_one, f_one), (w_ddp, l_ddp, n_ddp, f_ddp) = out[wire]
         assert n_one == 3 and n_ddp == (8 if model == 'pix2pix' else 6)      # Pix2Pix bucketed: 4 compute + 4 Adam graphs; CycleGAN phased: 2 two-chain phases + 4 Adam graphs
@@ -782,3 +794,42 @@ def test_rs_ag_equals_allreduce_over_rccl_two_ranks():
         for (exchange, compress), v in out.items():
             assert np.allclose(v, mean, rtol=1e-2 if compress else 1e-6, atol=1e-2 if compress else 1e-6), (rank, exchange, compress)
     assert np.array_equal(res[0][1][('rs_ag', True)], res[1][1][('rs_ag', True)])
+
+
+@pytest.mark.parametrize("model", ['pix2pix', 'cyclegan'])
+def test_layer_stacks_in_the_captured_steps_change_nothing(model, planner_options):
+    """Option conv.stack = 1: every run of consecutive small split-K layers of the generators / discriminators (forward, the
+    input-gradient chains of the backward pass) runs as ONE persistent launch (gan_conv_stack_*, grid barriers inside).  Same
+    arithmetic in the same order: two replayed steps end in bit-identical losses and weights with and without, for the Pix2Pix
+    multi-lane graph and for CycleGAN's two chains (two stack kernels resident at the same time)."""
+    from gan_amd.nets import Ctx
+    from gan_amd.steps import CycleGANStep, Pix2PixStep
+    B = 4 if model == 'pix2pix' else 1
+    rx, ry = O.synthetic_pair(B, 256, 1, seed=47)
+    res = []
+    for stacks in (0, 1):
+        planner_options('conv.stack', stacks)
+        ctx = Ctx('cuda:0', 'bf16')
+        st = Pix2PixStep(ctx, B, 256, 1, lam=100.0, seed=7) if model == 'pix2pix' else CycleGANStep(ctx, B, 256, 1, lam=10.0, seed=7)
+        w0 = [n.params.master.clone() for n in st.nets()]
+        x = [torch.from_numpy(rx).to(ctx.device), torch.from_numpy(ry).to(ctx.device)]
+        run = st.capture(training=True)
+        for n_, w_ in zip(st.nets(), w0):
+            n_.params.master.copy_(w_); n_.params.prepare()
+            n_.params.m.zero_(); n_.params.v.zero_(); n_.params.step.zero_()
+            for k, t in n_.params.state.items():
+                t.fill_(0.0 if 'mean' in k else 1.0)
+        for call in vars(st).values():
+            if hasattr(call, 'mask_draws'):
+                call.mask_draws.zero_()
+        losses = [run(*x)[:7].cpu().numpy().copy() for _ in range(2)]
+        torch.cuda.synchronize()
+        ctx.assert_no_stack_timeout()
+        calls = [c for c in vars(st).values() if hasattr(c, 'fwd_ops')]
+        nstack = sum(1 for c in calls for o in c.fwd_ops if o[2] == 'conv_stack')
+        assert (nstack > 0) == bool(stacks), nstack
+        res.append((losses, [n.params.master.clone() for n in st.nets()], [t.clone() for n in st.nets() for t in n.params.state.values()]))
+    (l0, w0_, s0), (l1, w1_, s1) = res
+    assert np.array_equal(np.array(l0), np.array(l1)), (l0, l1)
+    for a, b in zip(w0_ + s0, w1_ + s1):
+        assert torch.equal(a, b)

@@ -29,6 +29,7 @@ for run in range(2):
     for i in range(N):
         replay(*x)
     torch.cuda.synchronize()
+    ctx.assert_no_stack_timeout()          # (a layer-stack kernel whose grid barrier timed out would have raised its flag)
     res.append((st.losses.clone().cpu(), [n.params.master.clone().cpu() for n in st.nets()]))
     print(f"run {run}: losses {res[-1][0][:7].tolist()}", flush=True)
 same_l = torch.equal(res[0][0], res[1][0])
