@@ -602,7 +602,7 @@ def test_pix2pix_other_configs_f32(size, channels, batch):
     assert cosine(gd['down0.kernel'], ref[6]['down0.kernel']) > 0.999
 
 
-@pytest.mark.parametrize("dtype,step,tol", [('f32', 2e-3, 0.05), ('bf16', 3e-2, 0.2)])
+@pytest.mark.parametrize("dtype,step,tol", [('f32', 2e-3, 0.005), ('bf16', 3e-2, 0.12)])      # (measured: f32 0.04 % / 0.002 %; bf16 4.0 % / 0.03 % off)
 def test_full_size_gradients_are_directional_derivatives(dtype, step, tol):
     """BASELINE config 1 at its full size (Pix2Pix 256x256, batch 16; fp32 exact path and the benchmarked bf16 path
     with its streaming / tiled kernel mix) is far beyond what the numpy
