@@ -50,6 +50,7 @@ Opt g_opts[] = {
     {"wgrad.pingpong_128", {1}},       // 128-channel SMALL tensors on the 256-column ping-pong tile (half the columns dropped): +0.5 % on the step
     {"wgrad.pingpong_min_gflop", {30}},
     {"wgrad.split_target", {512}},
+    {"wgrad.fold_split_target", {512}},    // tap-folded (8-channel) layers: blocks wanted (each writes a 32 KB slab tile; 1024 before round 4: 46 -> 40 us per step for the two launches, 256: 57)
     {"wgrad.reduce_adam_min_params", {1 << 20}},
     {"wgrad.reduce_adam", {1}},     // GanAdamFuse on split launches: the slab reduce ends in the optimiser step
 };

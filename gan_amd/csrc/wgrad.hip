@@ -482,7 +482,7 @@ static int plan_wgrad(const GanWgradDesc* d, WgradPlan* pl, bool allow_swap = tr
   int splits = 1;
   const int wtarget = gan_opt("wgrad.split_target");
   // fold mode streams the SMALL tensor once: HBM-bound, wants many blocks; beside a mirror chain (concurrent == 2) half the chip is the target
-  const long long target = p.fold ? 1024 : (d->concurrent >= 2 ? (wtarget + 1) / 2 : wtarget);
+  const long long target = p.fold ? gan_opt("wgrad.fold_split_target") : (d->concurrent >= 2 ? (wtarget + 1) / 2 : wtarget);
   if (blocks < target) {
     splits = (int)((target + blocks - 1) / blocks);
     int maxs = p.kchunks / 4; if (maxs < 1) maxs = 1;
