@@ -326,48 +326,55 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* src, T* dst, int
 // up to 4 (source, destination view) pairs of the same shape in one launch (blockIdx.y = pair): the input pipeline of
 // a step packs the same two images into the generator's and the discriminator's typed input buffers
 struct PackMulti { const float* src[4]; void* dst[4]; int pitch[4]; };
-// 8 consecutive source elements per thread (two float4 loads; one element per thread with a 64-bit division each made this
-// launch - the first of every step, on the serial head of the schedule - 18 us for 17 MB)
+// Consecutive lanes on consecutive elements (4-byte loads coalesce; the 2-byte stores of a wave land in one 1-KB span of the
+// channel-padded destination), 8 elements per thread a workgroup-stride apart, 32-bit index arithmetic when the tensor allows.
+// (Round 4 tried 8 CONSECUTIVE elements per thread - vector loads, but every store instruction then touched 64 different lines:
+// 18-24 -> 26 us.)
 template <typename T>
 __global__ __launch_bounds__(256) void pack_multi_kernel(const PackMulti pm, int C, long long total) {
-  const long long i0 = ((long long)blockIdx.x * 256 + threadIdx.x) * 8;
-  if (i0 >= total) return;
   const int k = blockIdx.y;
-  const float* src = pm.src[k] + i0;
-  T* dst = (T*)pm.dst[k];
+  const float* __restrict__ src = pm.src[k];
+  T* __restrict__ dst = (T*)pm.dst[k];
   const int pitch = pm.pitch[k];
-  float v[8];
-  if (i0 + 8 <= total && (((uintptr_t)src) & 15) == 0) {
-    const float4 a = *(const float4*)src, b = *(const float4*)(src + 4);
-    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  const long long base = (long long)blockIdx.x * 2048 + threadIdx.x;
+  if (total < 0x7fffffffLL) {
+    const unsigned tot = (unsigned)total, b0 = (unsigned)base;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const unsigned i = b0 + e * 256u;
+      if (i < tot) {
+        const unsigned pix = C == 1 ? i : i / (unsigned)C, c = C == 1 ? 0u : i - pix * (unsigned)C;
+        st_f(dst + (size_t)pix * pitch + c, src[i]);
+      }
+    }
   } else {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = i0 + e < total ? src[e] : 0.f;
-  }
-  long long pix = i0 / C;
-  int c = (int)(i0 - pix * C);
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    if (i0 + e < total) st_f(dst + pix * pitch + c, v[e]);
-    if (++c == C) { c = 0; ++pix; }
+    for (int e = 0; e < 8; ++e) {
+      const long long i = base + e * 256;
+      if (i < total) st_f(dst + (i / C) * pitch + (i % C), src[i]);
+    }
   }
 }
 struct DropMulti { uint8_t* mask[4]; long long count[4]; uint32_t sid[4]; };
 // `draws` (optional): {number of launches so far, block ticket}: every block reads the count before it takes a ticket, the
 // last ticket holder advances it - successive calls draw new masks even while *step stands still (validation passes).
 __global__ __launch_bounds__(256) void dropout_multi_kernel(const DropMulti dm, uint64_t seed, const int32_t* step, int32_t* draws) {
+  // 8 hash words (64 mask bytes) per thread: the launch ends in one ticket per workgroup on ONE address (~15 ns each, serialised) -
+  // 768 workgroups of one word per thread spent 11 us there for 0.7 MB of masks
   const int k = blockIdx.y;
-  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  const long long w = i * 8;
   const uint32_t draw = draws ? (uint32_t)draws[0] : 0u;
-  if (w < dm.count[k]) {
-    uint64_t key = mix64(seed ^ ((uint64_t)(uint32_t)(*step) << 32) ^ dm.sid[k]);
-    if (draw) key = mix64(key + draw);
-    uint64_t h = mix64(key ^ (uint64_t)i);
-    if (w + 8 <= dm.count[k] && (((uintptr_t)(dm.mask[k] + w)) & 7) == 0)      // one 8-byte store: bit 7 of every byte of h -> 0/1 bytes
-      *(uint64_t*)(dm.mask[k] + w) = (h >> 7) & 0x0101010101010101ull;
-    else
-      for (int e = 0; e < 8 && w + e < dm.count[k]; ++e) dm.mask[k][w + e] = (uint8_t)((h >> (e * 8 + 7)) & 1);
+  uint64_t key = mix64(seed ^ ((uint64_t)(uint32_t)(*step) << 32) ^ dm.sid[k]);
+  if (draw) key = mix64(key + draw);
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 8 + u;      // hash word index: 8 mask bytes
+    const long long w = i * 8;
+    if (w < dm.count[k]) {
+      const uint64_t h = mix64(key ^ (uint64_t)i);
+      if (w + 8 <= dm.count[k] && (((uintptr_t)(dm.mask[k] + w)) & 7) == 0)      // one 8-byte store: bit 7 of every byte of h -> 0/1 bytes
+        *(uint64_t*)(dm.mask[k] + w) = (h >> 7) & 0x0101010101010101ull;
+      else
+        for (int e = 0; e < 8 && w + e < dm.count[k]; ++e) dm.mask[k][w + e] = (uint8_t)((h >> (e * 8 + 7)) & 1);
+    }
   }
   if (draws) {
     __syncthreads();
@@ -629,7 +636,7 @@ int gan_dropout_mask_multi(int32_t n, uint8_t* const* masks, const int64_t* coun
     const long long w = (counts[k] + 7) / 8;
     if (w > maxw) maxw = w;
   }
-  hipLaunchKernelGGL(dropout_multi_kernel, dim3((unsigned)((maxw + 255) / 256), (unsigned)n), dim3(256), 0, (hipStream_t)stream, dm,
+  hipLaunchKernelGGL(dropout_multi_kernel, dim3((unsigned)((maxw + 2047) / 2048), (unsigned)n), dim3(256), 0, (hipStream_t)stream, dm,
                      seed, step, draws);
   GAN_CHECK_LAUNCH();
   return 0;
