@@ -175,7 +175,12 @@ template <bool COH> __device__ __forceinline__ void st_u2(const CohBuf& b, void*
 // LDS at `smem` are free for staging (the caller has passed a block barrier after its last LDS read).
 // PARCOLS (conv_par_kernel): the tile's BN = 4 x PCOLS columns are (output parity, channel) pairs - column block v / PCOLS
 // goes to the output pixel of parity v / PCOLS, channel bn0 + v % PCOLS; statistics partials come out as one chunk per parity.
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int SMEMB, bool PARCOLS = false, bool COH = false>
+// BF = false: the fused-backward-epilogue paths (GanBwdFuse) are not compiled in.  They cost registers - the 256x128 ping-pong kernel
+// is 238 VGPRs with them (U = 8 rows of reference / skip / mask loads in flight), 175 with U = 2, 132 without; 256x256: 256 / 216 - and a
+// 512-thread block puts TWO waves on every SIMD: at 238-256 registers nothing else fits beside them (512 per SIMD lane), at <= 216 an
+// 80-register streaming wave does.  The kernels are therefore instantiated twice and a launch without bwd_fuse takes the lean one
+// (round 4, tools/probe_overlap.py: overlap of a 256x128 GEMM stream with a normalisation stream 0.25 -> 0.45).
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int SMEMB, bool PARCOLS = false, bool COH = false, bool BF = true>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[BM / WAVES_M / 16][BN / WAVES_N / 16],
                                               unsigned char* smem, int bm0, int bn0, int par, int P, int split) {
   constexpr int VEC = VecOf<T>::N;
@@ -231,7 +236,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
 #pragma unroll
     for (int e = 0; e < VEC; ++e) ssum[e] = ssq[e] = 0.f;
     float cmu[VEC], crs[VEC], cga[VEC], cbe[VEC];              // fused backward epilogue: this thread's per-channel constants
-    if (p.bf_mode >= 1 && p.bf_mode <= 3 && bn0 + (scg % PVECS) * VEC < p.bf_cols) {
+    if (BF && p.bf_mode >= 1 && p.bf_mode <= 3 && bn0 + (scg % PVECS) * VEC < p.bf_cols) {
       const int grp = p.stats_tpg ? (bm0 / BM) / p.stats_tpg : 0, c0 = bn0 + (scg % PVECS) * VEC;
 #pragma unroll
       for (int e = 0; e < VEC; ++e) {
@@ -292,7 +297,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
         } else {
           // fused backward epilogue: the reference / skip / mask vectors of U rows are requested together before any of them
           // is used (one dependent global load per iteration made this loop pure latency: +9..+40 us per launch)
-          constexpr int ITERS = TOTAL / NTHREADS, U = (BN == 128 && ITERS % 8 == 0) ? 8 : (BN == 128 && ITERS % 4 == 0) ? 4 : (ITERS % 2 == 0 ? 2 : 1);
+          constexpr int ITERS = TOTAL / NTHREADS, U = (ITERS % 2 == 0 ? 2 : 1);      // (8 / 4 rows at a time on the 128-column tiles until round 4: +63 registers)
           const int n = bn0 + (scg % PVECS) * VEC;
           const int cpy = PARCOLS ? (scg / PVECS) >> 1 : py, cpx = PARCOLS ? (scg / PVECS) & 1 : px;
           const bool colok = n < p.Cout, fuse = n < p.bf_cols;
@@ -325,12 +330,16 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
           }
         }
       };
-      switch (p.bf_mode) {
-        case 1: store_rows(std::integral_constant<int, 1>{}); break;
-        case 2: store_rows(std::integral_constant<int, 2>{}); break;
-        case 3: store_rows(std::integral_constant<int, 3>{}); break;
-        case 4: store_rows(std::integral_constant<int, 4>{}); break;
-        default: store_rows(std::integral_constant<int, 0>{}); break;
+      if constexpr (BF) {
+        switch (p.bf_mode) {
+          case 1: store_rows(std::integral_constant<int, 1>{}); break;
+          case 2: store_rows(std::integral_constant<int, 2>{}); break;
+          case 3: store_rows(std::integral_constant<int, 3>{}); break;
+          case 4: store_rows(std::integral_constant<int, 4>{}); break;
+          default: store_rows(std::integral_constant<int, 0>{}); break;
+        }
+      } else {
+        store_rows(std::integral_constant<int, 0>{});
       }
       if (p.stats && !p.bf_mode) {
         for (int sr = sslice; sr < WAVES_M * IPP * 16; sr += SL) {
@@ -618,7 +627,7 @@ template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
   if constexpr (N > 0) { static_for<N - 1>(f); f(std::integral_constant<int, N - 1>{}); }
 }
 
-template <typename T, int BN>
+template <typename T, int BN, bool BF>
 __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(const GemmParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int BM = 256, WAVES_M = 2, WAVES_N = 4, BKB = 128;
@@ -810,7 +819,7 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(const GemmParams p) {
   wait_vmcnt<0>();
   __syncthreads();
   DIAG_STAMP(3);
-  gemm_epilogue<T, BM, BN, WAVES_M, WAVES_N, NB * STAGE>(p, acc, smem, bm0, bn0, par, P, split);
+  gemm_epilogue<T, BM, BN, WAVES_M, WAVES_N, NB * STAGE, false, false, BF>(p, acc, smem, bm0, bn0, par, P, split);
   DIAG_STAMP(4);
 #endif
 }
@@ -1591,11 +1600,11 @@ static int launch_cfg(const GemmPlan& pl, hipStream_t st) {
   return 0;
 }
 
-template <typename T, int BN>
-static int launch_pp(const GemmPlan& pl, hipStream_t st) {
+template <typename T, int BN, bool BF>
+static int launch_pp_v(const GemmPlan& pl, hipStream_t st) {
   static bool attr_set = false;
   constexpr size_t smem = (size_t)(BN == 256 ? 2 : 3) * (256 + BN) * 128;
-  auto kern = conv_gemm_pp_kernel<T, BN>;
+  auto kern = conv_gemm_pp_kernel<T, BN, BF>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return (int)e;
@@ -1604,6 +1613,11 @@ static int launch_pp(const GemmPlan& pl, hipStream_t st) {
   hipLaunchKernelGGL(kern, pl.grid, dim3(512), smem, st, pl.p);
   GAN_CHECK_LAUNCH();
   return 0;
+}
+template <typename T, int BN>
+static int launch_pp(const GemmPlan& pl, hipStream_t st) {       // the lean instantiation unless the launch carries a fused backward epilogue
+  const bool full = pl.p.bf_mode != 0 || !gan_opt("conv.lean_epilogue");
+  return full ? launch_pp_v<T, BN, true>(pl, st) : launch_pp_v<T, BN, false>(pl, st);
 }
 
 template <typename T, int NPW>
