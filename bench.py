@@ -290,7 +290,7 @@ def main():
                      "sclk_mhz_after": read_sclk_mhz(local)}
     losses = step.losses.cpu().numpy()
     ctx.assert_no_stack_timeout()          # (a persistent layer-stack kernel that timed out at a grid barrier raises a flag instead of hanging)
-    if not np.all(np.isfinite(losses)):
+    if not np.all(np.isfinite(losses)) and not os.environ.get('GAN_BENCH_KNOCKOUT'):   # (knock-out libraries of tools/knockout_build.sh compute garbage on purpose)
         raise RuntimeError(f"non-finite losses {losses}")
 
     if rank == 0:

@@ -103,6 +103,7 @@ SYMBOLS = {
     "gan_conv_wgrad": (C.c_int, [C.POINTER(GanWgradDesc), C.c_void_p]),
     "gan_wgrad_workspace_bytes": (C.c_size_t, [C.POINTER(GanWgradDesc)]),
     "gan_conv_stack_eligible": (C.c_int, [C.POINTER(GanConvDesc), C.c_int]),
+    "gan_conv_tap_shared": (C.c_int, [C.POINTER(GanConvDesc), C.c_int]),
     "gan_conv_stack_plan_bytes": (C.c_size_t, [C.c_int32]),
     "gan_conv_stack_plan": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_int32, C.c_void_p, C.c_size_t]),
     "gan_conv_stack_launch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -732,8 +732,8 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(const GemmParams p) {
         constexpr int bi = BN == 256 ? (i - 2) : (i - 2);  // 256: 0..3 = (h, k) as h*2+k;  128: 0..1 = k
         constexpr int h = BN == 256 ? (bi >> 1) : 0, k = bi & 1;
         const int pb = BN == 256 ? ((wave >> 2) * 8 + 16 * k + 4 * h + (wave & 3)) : (wave + 8 * k);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(st + BM * BKB + pb * 1024), 16,
-                                                 b_org[BN == 256 ? h * 2 + k : k] + s_boff, 0, 0, 0);
+        const int boff = b_org[BN == 256 ? h * 2 + k : k] + s_boff;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(st + BM * BKB + pb * 1024), 16, boff, 0, 0, 0);
       }
     });
   };
@@ -820,6 +820,587 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(const GemmParams p) {
   __syncthreads();
   DIAG_STAMP(3);
   gemm_epilogue<T, BM, BN, WAVES_M, WAVES_N, NB * STAGE, false, false, BF>(p, acc, smem, bm0, bn0, par, P, split);
+  DIAG_STAMP(4);
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------
+// Tap-shared ping-pong kernel (round 4): the ping-pong kernel above with the A operand of SH taps staged ONCE.
+//
+// The taps of one kernel row read the same source pixels, shifted: tap tx of output column gx reads source column
+// gx*S + dx0 + tx*dstep, i.e. tap tx + NC (NC = S tap classes per row) reads what tap tx reads for the NEIGHBOURING output column
+// gx + dstep.  A K "super tile" = (channel chunk, tap row ty, class c) therefore stages the 256 tile rows of the class's first tap
+// once and multiplies SH = TW / NC taps (2: stride-2 convolutions and the parity sub-GEMMs, 4: stride-1 convolutions) against it:
+// sub tile j reads the A fragment of tile row m from LDS row m + j*dir (dir = sign of dstep).  Where that leaves the row's SEGMENT
+// (the part of an image row inside the row's 64-row block of the tile) the pixel is a HALO entry: per block 16 LDS rows behind the
+// tile (256 + 16*block + segment*(SH-1) + k), staged by one extra piece per wave and super tile with the same validity logic as a tile
+// row at the virtual column.  Staged bytes per K tile: 256x128 tile 48 KB -> 34 (SH 2) / 26 (SH 4); 256x256 64 -> 50 / 42 - the loop
+// of the kernel above is bound by the issue of exactly these pieces.
+//
+// K order: chunk major, then tap row, class, and the SH taps of the class (the kernel above: chunk major, tap minor), so sums differ
+// from it in fp32 rounding order only.  LDS: A ring of 2 super tiles x (256 + 64 halo rows) x 128 B | B ring of NBB K tiles.
+// Schedule: phases as above (PH per K tile, NPH = PH*SH per super tile); the pieces of a super tile are issued by the table
+// PsSched<BN, SH> (entry: what, and the phase relative to the super tile's first phase in whose LOAD segment it is issued); the
+// counted vmcnt of every phase follows from the table (ps_vm), the RAW / WAR rules of the kernel above are static_asserts below:
+//   RAW: a piece first read in phase r is covered by the vmcnt at the end of LOAD(r-1)   (need - issue phase >= 2 is asserted)
+//   WAR: a slot is re-filled >= 2 phases after the last LOAD segment that reads its old contents
+//        A0 blocks (rows 0-63 of each wave row): last read in phase (SH-1)*PH (sub tile SH-1's first-half phase; segments are cut at the
+//        64-row blocks so that a shifted read never leaves its block + halo), A1 blocks and halo: last phase that reads A.
+enum { PS_A0 = 0, PS_A1 = 1, PS_H = 2, PS_B = 3 };
+struct PsEntry { int kind, k, j, h, p; };     // piece k of the kind (B: of sub tile j, column half h), issue phase p
+template <int BN, int SH, int PH> struct PsSched;        // PH: phases per K tile
+template <int BN, int SH, int PH> constexpr int ps_need(const PsEntry& e) {   // phase (of the super tile) whose LOAD segment first reads it
+  return e.kind == PS_A0 ? 0 : e.kind == PS_A1 ? (PH == 4 ? 2 : 1) : e.kind == PS_H ? PH : e.j * PH + (PH == 4 ? e.h : 0);
+}
+// The table: every piece is issued PS_LA phases before the phase that first reads it, or as early as its slot's WAR rule allows
+// if that is later; entries in issue order (stable: the order below inside one phase)
+#ifndef PS_LA
+#define PS_LA 3
+#endif
+template <int BN, int SH> struct PsTable { static constexpr int Q = 4 + 1 + SH * (BN == 256 ? 4 : 2); PsEntry e[Q]; };
+template <int BN, int SH, int PH> constexpr PsTable<BN, SH> ps_make() {
+  constexpr int NPH = PH * SH, NBB = BN == 256 ? 2 : 4, Q = PsTable<BN, SH>::Q;
+  constexpr int lastA0 = (SH - 1) * PH, lastA1 = (SH - 1) * PH + (PH == 4 ? 2 : 1);
+  PsTable<BN, SH> t{};
+  int n = 0;
+  for (int k = 0; k < 2; ++k) t.e[n++] = PsEntry{PS_A0, k, 0, 0, 0};
+  for (int k = 0; k < 2; ++k) t.e[n++] = PsEntry{PS_A1, k, 0, 0, 0};
+  t.e[n++] = PsEntry{PS_H, 0, 0, 0, 0};
+  for (int j = 0; j < SH; ++j)
+    for (int h = 0; h < (BN == 256 ? 2 : 1); ++h)
+      for (int k = 0; k < 2; ++k) t.e[n++] = PsEntry{PS_B, k, j, h, 0};
+  for (int i = 0; i < Q; ++i) {
+    const int need = ps_need<BN, SH, PH>(t.e[i]);
+    const int last = t.e[i].kind == PS_A0 ? lastA0 : lastA1;
+    const int most = t.e[i].kind == PS_B ? NBB * PH - 2 : 2 * NPH + need - last - 2;
+    t.e[i].p = need - (PS_LA < most ? PS_LA : most);
+  }
+  for (int i = 1; i < Q; ++i) {                              // insertion sort by issue phase
+    const PsEntry x = t.e[i];
+    int m = i - 1;
+    while (m >= 0 && t.e[m].p > x.p) { t.e[m + 1] = t.e[m]; --m; }
+    t.e[m + 1] = x;
+  }
+  return t;
+}
+template <int BN, int SH, int PH> struct PsSched {
+  static constexpr int Q = PsTable<BN, SH>::Q;
+  static constexpr PsTable<BN, SH> tab = ps_make<BN, SH, PH>();
+};
+template <int BN, int SH, int PH> constexpr int ps_phase_of(const PsEntry& e) { constexpr int NPH = PH * SH; return ((e.p % NPH) + NPH) % NPH; }
+template <int BN, int SH, int PH> constexpr int ps_ahead_of(const PsEntry& e) { constexpr int NPH = PH * SH; return e.p < 0 ? (-e.p + NPH - 1) / NPH : 0; }
+// pieces that may stay outstanding at the end of LOAD(gph) in the steady state: everything issued after the newest piece that phase
+// gph + 1 reads (LDS-DMA pieces retire in issue order; program order inside a phase = table order)
+template <int BN, int SH, int PH> constexpr int ps_vm(int gph) {
+  using S = PsSched<BN, SH, PH>;
+  constexpr int NPH = PH * SH;
+  const int g = 3 * NPH + gph;
+  int seq = 0, newest_needed = -1;
+  for (int gg = -2 * NPH; gg <= g; ++gg)
+    for (int i = 0; i < S::Q; ++i) {
+      const int d = gg - S::tab.e[i].p;
+      if (d % NPH != 0) continue;
+      const int U = d / NPH;                                   // the super tile this issue belongs to
+      if (U * NPH + ps_need<BN, SH, PH>(S::tab.e[i]) <= g + 1) newest_needed = seq;
+      ++seq;
+    }
+  return seq - 1 - newest_needed;
+}
+template <int BN, int SH, int PH> constexpr int ps_pos(int i) {               // position of entry i among the entries of its phase
+  using S = PsSched<BN, SH, PH>;
+  int n = 0;
+  for (int j = 0; j < i; ++j) n += ps_phase_of<BN, SH, PH>(S::tab.e[j]) == ps_phase_of<BN, SH, PH>(S::tab.e[i]) ? 1 : 0;
+  return n;
+}
+template <int BN, int SH, int PH> constexpr int ps_max_per_phase() {
+  int m = 0;
+  for (int i = 0; i < PsSched<BN, SH, PH>::Q; ++i) m = ps_pos<BN, SH, PH>(i) + 1 > m ? ps_pos<BN, SH, PH>(i) + 1 : m;
+  return m;
+}
+template <int BN, int SH, int PH> constexpr bool ps_sched_ok() {
+  using S = PsSched<BN, SH, PH>;
+  constexpr int NPH = PH * SH, NBB = BN == 256 ? 2 : 4;
+  constexpr int lastA0 = (SH - 1) * PH, lastA1 = (SH - 1) * PH + (PH == 4 ? 2 : 1);
+  int count = 0;
+  for (int i = 0; i < S::Q; ++i) {
+    const PsEntry& e = S::tab.e[i];
+    const int need = ps_need<BN, SH, PH>(e), ahead = need - e.p;
+    if (ahead < 2) return false;
+    if (i && e.p < S::tab.e[i - 1].p) return false;                // table in issue order
+    const int last = e.kind == PS_A0 ? lastA0 : lastA1;
+    if (e.kind == PS_B ? ahead > NBB * PH - 2 : ahead > 2 * NPH + need - last - 2) return false;
+    ++count;
+  }
+  return count == 4 + 1 + SH * (BN == 256 ? 4 : 2);
+}
+static_assert(ps_sched_ok<128, 2, 2>() && ps_sched_ok<128, 4, 2>() && ps_sched_ok<256, 2, 4>() && ps_sched_ok<256, 4, 4>(), "tap-shared piece schedule");
+
+template <typename T, int BN, int SH, int PH, bool BF>
+__global__ __launch_bounds__(512) void conv_gemm_ps_kernel(const GemmParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  using Sched = PsSched<BN, SH, PH>;
+  constexpr int BM = 256, WAVES_M = 2, WAVES_N = 4, BKB = 128;
+  constexpr int WTN = BN / 4, MT = 8, NT = WTN / 16;        // wave tile 128 x (64 | 32)
+  constexpr int NPH = PH * SH;
+  constexpr int NBB = BN == 256 ? 2 : 4;
+  constexpr int LOG2SH = SH == 4 ? 2 : 1;
+  constexpr int ASTAGE = (BM + 64) * BKB, BOFF = 2 * ASTAGE, BSTAGE = BN * BKB;
+  constexpr int ES = sizeof(T);
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x;
+  DIAG_STAMP(0);
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int r = lane & 15, q = lane >> 4;
+
+  const int P = p.parity ? 4 : 1;
+  int bid = blockIdx.x;
+  const int nb = p.tilesM * p.tilesN * P;
+  if ((nb & 7) == 0) bid = (bid & 7) * (nb >> 3) + (bid >> 3);
+  const int par = bid % P;
+  bid /= P;
+  const int bm0 = (bid / p.tilesN) * BM, bn0 = (bid % p.tilesN) * BN;
+  const int split = blockIdx.z;
+  const int py = par >> 1, px = par & 1;
+  int dy0 = p.dy0, dx0 = p.dx0, wy0 = p.wy0, wx0 = p.wx0;
+  if (p.parity) { dy0 = py; dx0 = px; wy0 = 1 - py; wx0 = 1 - px; }
+  const int twmask = (1 << p.TWlog2) - 1, TW = 1 << p.TWlog2;
+  const int dir = p.dstep > 0 ? 1 : -1;
+
+  // ---- per-lane gather state: 4 tile rows + 1 halo row ---------------------------------------------------
+  const int lrow = lane >> 3, slot = lane & 7;
+  const int chunkB = ((slot ^ lrow) << 4);
+  // window origin (+ chunk) and tap mask of the (possibly virtual) grid position (image row t, column gx)
+  auto pix_state = [&](unsigned t, int gx, int& org, unsigned& msk) {
+    const unsigned img = fdiv(t, p.divHg);
+    const int gy = (int)t - (int)img * p.Hg;
+    const int sy0 = gy * p.S + dy0, sx0 = gx * p.S + dx0;
+    unsigned vx = 0, m_ = 0;
+    for (int tx = 0; tx < TW; ++tx) vx |= ((unsigned)(sx0 + tx * p.dstep) < (unsigned)p.Ws ? 1u : 0u) << tx;
+    for (int ty = 0; ty < TW; ++ty)
+      if ((unsigned)(sy0 + ty * p.dstep) < (unsigned)p.Hs) m_ |= vx << (ty << p.TWlog2);
+    msk = m_;
+    org = (int)((((long long)((int)img * p.Hs + sy0) * p.Ws + sx0) * (long long)p.xpitch) * ES) + chunkB;
+  };
+  int a_org[2][2];
+  unsigned a_msk[2][2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int m = bm0 + (k * 16 + 8 * h + wave) * 8 + lrow;
+      a_org[h][k] = 0; a_msk[h][k] = 0;
+      if (m < p.M) {
+        const unsigned t = fdiv((unsigned)m, p.divWg);
+        pix_state(t, m - (int)t * p.Wg, a_org[h][k], a_msk[h][k]);
+      }
+    }
+  int h_org = 0;
+  unsigned h_msk = 0;
+  {
+    const int hb = wave >> 1, sub = (wave & 1) * 8 + lrow;           // halo row 16*hb + sub of block hb
+    const int seg = sub / (SH - 1), k = sub - seg * (SH - 1);
+    const int g0 = bm0 + hb * 64, g1 = g0 + 63;
+    const unsigned t = fdiv((unsigned)g0, p.divWg) + (unsigned)seg;
+    const long long rs = (long long)t * p.Wg;                        // first GEMM row of image row t
+    if (rs <= g1 && rs < p.M) {
+      const int gs = g0 > (int)rs ? g0 - (int)rs : 0, ge = g1 - (int)rs < p.Wg - 1 ? g1 - (int)rs : p.Wg - 1;
+      pix_state(t, dir > 0 ? ge + 1 + k : gs - 1 - k, h_org, h_msk);
+    }
+  }
+  constexpr int BK_ = BN == 256 ? 4 : 2;                    // B pieces per wave per K tile
+  int b_org[BK_];
+#pragma unroll
+  for (int i = 0; i < BK_; ++i) {
+    const int pb = BN == 256 ? ((wave >> 2) * 8 + 16 * (i & 1) + 4 * (i >> 1) + (wave & 3)) : (wave + 8 * i);
+    const int n = bn0 + pb * 8 + lrow;
+    b_org[i] = n < p.Wrows ? (int)((size_t)n * p.Cin * ES) + chunkB : (int)0x80000000;
+  }
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.xbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.wbytes, 0x00020000);
+  const int wtapbytes = p.Wrows * p.Cin * ES;
+  const int pixbytes = p.xpitch * ES;
+
+  const int su_total = p.kchunks >> LOG2SH;
+  const int su_begin = (int)((long long)su_total * split / p.splits);
+  const int nsu = (int)((long long)su_total * (split + 1) / p.splits) - su_begin;
+  const int log2NC = p.TWlog2 - LOG2SH;                     // tap classes per kernel row = TW / SH
+
+  // fragment addresses.  Unshifted (sub tile 0): tile row R, 16-byte K slot c at R*128 + ((c ^ (R & 7)) << 4), as above.
+  // Shifted (sub tile j): per fragment and lane the LDS row of (tile row + j*dir) or of its halo entry; slot q, the second k step = ^ 64.
+  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  const unsigned swz0 = (unsigned)((q ^ (r & 7)) << 4), swz1 = (unsigned)(((4 + q) ^ (r & 7)) << 4);
+  const unsigned a_row = lds_base + (wr * 128 + r) * BKB, b_row = lds_base + BOFF + (wc * WTN + r) * BKB;
+  unsigned a_tbl[8][SH - 1];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int m = wr * 128 + i * 16 + r, hb = wr * 2 + (i >> 2);
+    const int g0 = bm0 + hb * 64;
+    const unsigned t = fdiv((unsigned)(bm0 + m), p.divWg);
+    const int rs = (int)t * p.Wg, gx = bm0 + m - rs;
+    const int gs = g0 > rs ? g0 - rs : 0, ge = g0 + 63 - rs < p.Wg - 1 ? g0 + 63 - rs : p.Wg - 1;
+    const int seg = (int)t - (int)fdiv((unsigned)g0, p.divWg);
+#pragma unroll
+    for (int j = 1; j < SH; ++j) {
+      const int gv = gx + j * dir;
+      const int L = (gv >= gs && gv <= ge) ? m + j * dir : BM + hb * 16 + seg * (SH - 1) + (dir > 0 ? gv - ge - 1 : gs - 1 - gv);
+      a_tbl[i][j - 1] = lds_base + (unsigned)L * BKB + (unsigned)((q ^ (L & 7)) << 4);
+    }
+  }
+
+  // issue table entry E for the block's super tile us (us >= nsu: out-of-range pieces).  (Computing these offsets behind the wave's own
+  // MFMAs, one phase ahead, measured slower: the work is a serial chain wherever it sits; conv_gemm_pt_kernel removes it instead.)
+  auto issue_entry = [&](auto Ec, int us) {
+    constexpr PsEntry e = Sched::tab.e[decltype(Ec)::value];
+    const bool live = us < nsu;
+    const int su = su_begin + us;
+    const int c = su & ((1 << log2NC) - 1);
+    const int ty = (su >> log2NC) & twmask;
+    const int coff = (su >> (log2NC + p.TWlog2)) * BKB;
+    if constexpr (e.kind == PS_B) {
+      const int tx = c + (e.j << log2NC);
+      const int s_boff = live ? ((wy0 + ty * p.wstep) * 4 + (wx0 + tx * p.wstep)) * wtapbytes + coff : (int)0x80000000;
+      constexpr int bi = BN == 256 ? e.h * 2 + e.k : e.k;
+      const int pb = BN == 256 ? ((wave >> 2) * 8 + 16 * e.k + 4 * e.h + (wave & 3)) : (wave + 8 * e.k);
+      unsigned char* dst = smem + BOFF + ((us * SH + e.j) & (NBB - 1)) * BSTAGE + pb * 1024;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)dst, 16, b_org[bi] + s_boff, 0, 0, 0);
+    } else {
+      const unsigned s_bit = live ? (1u << ((ty << p.TWlog2) + c)) : 0u;
+      const int s_aoff = (ty * p.dstep * p.Ws + c * p.dstep) * pixbytes + coff;
+      unsigned char* stA = smem + (us & 1) * ASTAGE;
+      if constexpr (e.kind == PS_H) {
+        const int off = (h_msk & s_bit) ? h_org + s_aoff : (int)0x80000000;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(stA + BM * BKB + wave * 1024), 16, off, 0, 0, 0);
+      } else {
+        constexpr int h = e.kind == PS_A1 ? 1 : 0;
+        const int pa = e.k * 16 + 8 * h + wave;
+        const int off = (a_msk[h][e.k] & s_bit) ? a_org[h][e.k] + s_aoff : (int)0x80000000;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(stA + pa * 1024), 16, off, 0, 0, 0);
+      }
+    }
+  };
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  DIAG_STAMP(1);
+  // prologue: what the steady state would have issued before the first phase (issue phase < 0), in its order
+  static_for<2 * NPH>([&](auto Gc) {
+    constexpr int gg = decltype(Gc)::value - 2 * NPH;
+    static_for<Sched::Q>([&](auto Ec) {
+      constexpr PsEntry e = Sched::tab.e[decltype(Ec)::value];
+      if constexpr ((gg - e.p) % NPH == 0 && gg - e.p >= 0) issue_entry(Ec, (gg - e.p) / NPH);
+    });
+  });
+  wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();
+  DIAG_STAMP(2);
+  if (wr == 1) __builtin_amdgcn_s_barrier();              // waves 4..7 run one barrier behind
+
+  uint4 af[2][4], bf0[2][2], bf1[2][2];
+  for (int u = 0; u < nsu; ++u) {
+    const unsigned soA = (unsigned)((u & 1) * ASTAGE);
+    const unsigned aA0 = a_row + soA + swz0, aA1 = a_row + soA + swz1;
+    static_for<NPH>([&](auto Gc) {
+      constexpr int gph = decltype(Gc)::value, jsub = gph / PH, ph = gph % PH;
+      // ---- LOAD segment ----
+      constexpr int mh = PH == 4 ? ((ph == 0 || ph == 1) ? 0 : 1) : ph;       // row half multiplied in this phase
+      constexpr int nh = PH == 4 ? ((ph == 1 || ph == 2) ? 1 : 0) : 0;        // column half (256x256 only)
+      constexpr bool readA = PH == 4 ? (ph == 0 || ph == 2) : true;
+      constexpr bool readB = PH == 4 ? (ph == 0 || ph == 1) : (ph == 0);
+      static_for<Sched::Q>([&](auto Ec) {
+        constexpr PsEntry e = Sched::tab.e[decltype(Ec)::value];
+        if constexpr (ps_phase_of<BN, SH, PH>(e) == gph) issue_entry(Ec, u + ps_ahead_of<BN, SH, PH>(e));
+      });
+      if constexpr (readB) {
+        const unsigned soB = (unsigned)(((u * SH + jsub) & (NBB - 1)) * BSTAGE);
+        const unsigned bB0 = b_row + soB + swz0, bB1 = b_row + soB + swz1;
+        static_for<2>([&](auto Jc) {
+          constexpr int j = decltype(Jc)::value;
+          constexpr int imm = (nh * 2 + j) * 16 * BKB;
+          if constexpr (nh == 0) { lds_read128<imm>(bf0[0][j], bB0); lds_read128<imm>(bf0[1][j], bB1); }
+          else { lds_read128<imm>(bf1[0][j], bB0); lds_read128<imm>(bf1[1][j], bB1); }
+        });
+      }
+      if constexpr (readA) {
+        static_for<4>([&](auto Ic) {
+          constexpr int i = decltype(Ic)::value;
+          if constexpr (jsub == 0) {
+            constexpr int imm = (mh * 4 + i) * 16 * BKB;
+            lds_read128<imm>(af[0][i], aA0); lds_read128<imm>(af[1][i], aA1);
+          } else {
+            const unsigned a0 = a_tbl[mh * 4 + i][jsub - 1] + soA;
+            lds_read128<0>(af[0][i], a0); lds_read128<0>(af[1][i], a0 ^ 64u);
+          }
+        });
+      }
+      wait_vmcnt<ps_vm<BN, SH, PH>(gph)>();
+      __builtin_amdgcn_s_barrier();
+      // ---- MATH segment ----
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            Mma<T>::run(acc[mh * 4 + i][nh * 2 + j], nh == 0 ? bf0[s2][j] : bf1[s2][j], af[s2][i]);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_s_barrier();
+    });
+  }
+  if (wr == 0) __builtin_amdgcn_s_barrier();
+  wait_vmcnt<0>();
+  __syncthreads();
+  DIAG_STAMP(3);
+  gemm_epilogue<T, BM, BN, WAVES_M, WAVES_N, BOFF + NBB * BSTAGE, false, false, BF>(p, acc, smem, bm0, bn0, par, P, split);
+  DIAG_STAMP(4);
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------
+// Table-driven form of the tap-shared kernel (round 4): a LOAD segment of the kernels above is a serial chain - ~40 scalar instructions
+// that decode the K tile into tap / channel offsets, 4 vector instructions per piece that apply them and the validity mask, then the
+// pieces, then the fragment reads - and it, not the MFMAs, sets the length of a phase (knock-outs on the kernel above, 256x128 class:
+// no scalar decode -14 %, no vector work -19 %, neither -27 %; pieces out of range or not makes no difference; moving the same work behind
+// the wave's own MFMAs gained nothing).  Here the work is done ONCE per block:
+//   * every A piece's offset is a loop-invariant register: atab[row][combo] = window origin + tap offset of the (tap row, class) combination,
+//     or 0x80000000 where that tap leaves the map (5 rows x 8 | 4 | 2 combinations);
+//   * the K loop is `for (chunk) unroll (combination) unroll (phase)`: what differs from chunk to chunk is ONE scalar (the channel
+//     offset, handed to the instruction as its scalar offset), LDS stage / ring-slot offsets are immediates, B pieces take the lane's
+//     row offset register + a scalar tap offset;
+//   * pieces issued for the chunk after the block's last one use a descriptor with zero records (zeros, no vector instruction).
+// A LOAD segment is then <= 3 x (m0, scalar offset, buffer_load ... lds) + 12 ds_read_b128 with immediates.  Arithmetic, schedule and
+// results are those of conv_gemm_ps_kernel.
+template <typename T, int BN, int SH, int TWV, bool BF>
+__global__ __launch_bounds__(512) void conv_gemm_pt_kernel(const GemmParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int PH = BN == 256 ? 4 : 2;
+  using Sched = PsSched<BN, SH, PH>;
+  constexpr int BM = 256, WAVES_M = 2, WAVES_N = 4, BKB = 128;
+  constexpr int WTN = BN / 4, MT = 8, NT = WTN / 16;
+  constexpr int NPH = PH * SH;
+  constexpr int NBB = BN == 256 ? 2 : 4;
+  constexpr int NC = TWV / SH, NCOMBO = TWV * NC;           // tap classes per kernel row; (tap row, class) combinations = super tiles per chunk
+  constexpr int LOG2T = TWV == 4 ? 4 : 2;
+  constexpr int ASTAGE = (BM + 64) * BKB, BOFF = 2 * ASTAGE, BSTAGE = BN * BKB;
+  constexpr int ES = sizeof(T);
+  static_assert((NCOMBO * SH) % NBB == 0 && NCOMBO % 2 == 0, "ring slots are compile-time inside a chunk");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x;
+  DIAG_STAMP(0);
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int r = lane & 15, q = lane >> 4;
+
+  const int P = p.parity ? 4 : 1;
+  int bid = blockIdx.x;
+  const int nb = p.tilesM * p.tilesN * P;
+  if ((nb & 7) == 0) bid = (bid & 7) * (nb >> 3) + (bid >> 3);
+  const int par = bid % P;
+  bid /= P;
+  const int bm0 = (bid / p.tilesN) * BM, bn0 = (bid % p.tilesN) * BN;
+  const int split = blockIdx.z;
+  const int py = par >> 1, px = par & 1;
+  int dy0 = p.dy0, dx0 = p.dx0, wy0 = p.wy0, wx0 = p.wx0;
+  if (p.parity) { dy0 = py; dx0 = px; wy0 = 1 - py; wx0 = 1 - px; }
+  const int dir = p.dstep > 0 ? 1 : -1;
+  const int pixbytes = p.xpitch * ES;
+
+  // ---- per-lane piece offsets: 4 tile rows + 1 halo row, one per (tap row, class) -----------------------
+  const int lrow = lane >> 3, slot = lane & 7;
+  const int chunkB = ((slot ^ lrow) << 4);
+  int atab[5][NCOMBO];
+  auto fill_row = [&](auto Rc, bool exists, unsigned t, int gx) {
+    constexpr int row = decltype(Rc)::value;
+    const unsigned img = fdiv(t, p.divHg);
+    const int gy = (int)t - (int)img * p.Hg;
+    const int sy0 = gy * p.S + dy0, sx0 = gx * p.S + dx0;
+    const int org = (int)((((long long)((int)img * p.Hs + sy0) * p.Ws + sx0) * (long long)p.xpitch) * ES) + chunkB;
+    static_for<NCOMBO>([&](auto Cc) {
+      constexpr int cc = decltype(Cc)::value, ty = cc / NC, c = cc % NC;
+      const bool ok = exists && (unsigned)(sy0 + ty * p.dstep) < (unsigned)p.Hs && (unsigned)(sx0 + c * p.dstep) < (unsigned)p.Ws;
+      atab[row][cc] = ok ? org + (ty * p.dstep * p.Ws + c * p.dstep) * pixbytes : (int)0x80000000;
+    });
+  };
+  static_for<4>([&](auto Rc) {
+    constexpr int row = decltype(Rc)::value, h = row >> 1, k = row & 1;          // row = 2 * half + piece, as the table's A0 / A1 entries
+    const int m = bm0 + (k * 16 + 8 * h + wave) * 8 + lrow;
+    const unsigned t = fdiv((unsigned)m, p.divWg);
+    fill_row(Rc, m < p.M, t, m - (int)t * p.Wg);
+  });
+  {
+    const int hb = wave >> 1, sub = (wave & 1) * 8 + lrow;           // halo row 16*hb + sub of block hb
+    const int seg = sub / (SH - 1), k = sub - seg * (SH - 1);
+    const int g0 = bm0 + hb * 64, g1 = g0 + 63;
+    const unsigned t = fdiv((unsigned)g0, p.divWg) + (unsigned)seg;
+    const long long rs = (long long)t * p.Wg;
+    const bool exists = rs <= g1 && rs < p.M;
+    const int gs = g0 > (int)rs ? g0 - (int)rs : 0, ge = g1 - (int)rs < p.Wg - 1 ? g1 - (int)rs : p.Wg - 1;
+    fill_row(std::integral_constant<int, 4>{}, exists, t, dir > 0 ? ge + 1 + k : gs - 1 - k);
+  }
+  constexpr int BK_ = BN == 256 ? 4 : 2;
+  int b_org[BK_];
+#pragma unroll
+  for (int i = 0; i < BK_; ++i) {
+    const int pb = BN == 256 ? ((wave >> 2) * 8 + 16 * (i & 1) + 4 * (i >> 1) + (wave & 3)) : (wave + 8 * i);
+    const int n = bn0 + pb * 8 + lrow;
+    b_org[i] = n < p.Wrows ? (int)((size_t)n * p.Cin * ES) + chunkB : (int)0x80000000;
+  }
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.xbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.wbytes, 0x00020000);
+  const int wtapbytes = p.Wrows * p.Cin * ES;
+  const int wstepb = p.wstep * wtapbytes, wbase = (wy0 * 4 + wx0) * wtapbytes;      // weight tap (ty, tx) at wbase + (4 ty + tx) * wstepb
+
+  const int ch_total = p.kchunks >> LOG2T;                  // 128-byte channel chunks
+  const int ch_begin = (int)((long long)ch_total * split / p.splits);
+  const int nch = (int)((long long)ch_total * (split + 1) / p.splits) - ch_begin;
+
+  // fragment addresses: stage and ring-slot offsets are immediates; the shifted reads take per-lane tables (both k steps)
+  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  const unsigned swz0 = (unsigned)((q ^ (r & 7)) << 4), swz1 = (unsigned)(((4 + q) ^ (r & 7)) << 4);
+  const unsigned a_base0 = lds_base + (wr * 128 + r) * BKB + swz0, a_base1 = lds_base + (wr * 128 + r) * BKB + swz1;
+  const unsigned b_base0 = lds_base + BOFF + (wc * WTN + r) * BKB + swz0, b_base1 = lds_base + BOFF + (wc * WTN + r) * BKB + swz1;
+  unsigned a_tbl[8][SH - 1], a_tbx[8][SH - 1];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int m = wr * 128 + i * 16 + r, hb = wr * 2 + (i >> 2);
+    const int g0 = bm0 + hb * 64;
+    const unsigned t = fdiv((unsigned)(bm0 + m), p.divWg);
+    const int rs = (int)t * p.Wg, gx = bm0 + m - rs;
+    const int gs = g0 > rs ? g0 - rs : 0, ge = g0 + 63 - rs < p.Wg - 1 ? g0 + 63 - rs : p.Wg - 1;
+    const int seg = (int)t - (int)fdiv((unsigned)g0, p.divWg);
+#pragma unroll
+    for (int j = 1; j < SH; ++j) {
+      const int gv = gx + j * dir;
+      const int L = (gv >= gs && gv <= ge) ? m + j * dir : BM + hb * 16 + seg * (SH - 1) + (dir > 0 ? gv - ge - 1 : gs - 1 - gv);
+      a_tbl[i][j - 1] = lds_base + (unsigned)L * BKB + (unsigned)((q ^ (L & 7)) << 4);
+      a_tbx[i][j - 1] = a_tbl[i][j - 1] ^ 64u;
+    }
+  }
+  unsigned char* const a_dst = smem + wave * 1024;           // this wave's piece inside an A panel / B panel
+  unsigned char* const b_dst = smem + BOFF + wave * 1024;
+
+  // table entry E for combination CT counted from the current chunk's first (CT >= NCOMBO: the next chunk's; `rxn` / `rwn` have zero records
+  // when there is none), coff = the current chunk's byte offset
+  auto issue = [&](auto Ec, auto CTc, int coff, const __amdgpu_buffer_rsrc_t& rxn, const __amdgpu_buffer_rsrc_t& rwn) {
+    constexpr PsEntry e = Sched::tab.e[decltype(Ec)::value];
+    constexpr int ct = decltype(CTc)::value, cc = ct % NCOMBO, ty = cc / NC, c = cc % NC;
+    constexpr bool wrap = ct >= NCOMBO;
+    const int so = coff + (wrap ? BKB : 0);
+    if constexpr (e.kind == PS_B) {
+      constexpr int tapmul = 4 * ty + c + e.j * NC;
+      constexpr int bslot = (ct * SH + e.j) & (NBB - 1);
+      constexpr int pbo = BN == 256 ? (16 * e.k + 4 * e.h) * 1024 : 8 * e.k * 1024;
+      unsigned char* dst = (BN == 256 ? smem + BOFF + ((wave >> 2) * 8 + (wave & 3)) * 1024 : b_dst) + bslot * BSTAGE + pbo;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wrap ? rwn : rw, (__attribute__((address_space(3))) void*)dst, 16, b_org[BN == 256 ? e.h * 2 + e.k : e.k],
+                                               wbase + tapmul * wstepb + so, 0, 0);
+    } else {
+      constexpr int row = e.kind == PS_H ? 4 : (e.kind == PS_A1 ? 2 : 0) + e.k;
+      constexpr int pa = e.kind == PS_H ? 32 : e.k * 16 + 8 * (e.kind == PS_A1 ? 1 : 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wrap ? rxn : rx, (__attribute__((address_space(3))) void*)(a_dst + (ct & 1) * ASTAGE + pa * 1024), 16,
+                                               atab[row][cc], so, 0, 0);
+    }
+  };
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  DIAG_STAMP(1);
+  // prologue: what the steady state would have issued before the first phase
+  static_for<2 * NPH>([&](auto Gc) {
+    constexpr int gg = decltype(Gc)::value - 2 * NPH;
+    static_for<Sched::Q>([&](auto Ec) {
+      constexpr PsEntry e = Sched::tab.e[decltype(Ec)::value];
+      if constexpr ((gg - e.p) % NPH == 0 && gg - e.p >= 0) {
+        static_assert((gg - e.p) / NPH < NCOMBO, "look-ahead inside one chunk");
+        issue(Ec, std::integral_constant<int, (gg - e.p) / NPH>{}, ch_begin * BKB, rx, rw);
+      }
+    });
+  });
+  wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();
+  DIAG_STAMP(2);
+  if (wr == 1) __builtin_amdgcn_s_barrier();              // waves 4..7 run one barrier behind
+
+  uint4 af[2][4], bf0[2][2], bf1[2][2];
+  for (int cu = 0; cu < nch; ++cu) {
+    const int coff = (ch_begin + cu) * BKB;
+    const bool more = cu + 1 < nch;
+    const __amdgpu_buffer_rsrc_t rxn = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, more ? p.xbytes : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rwn = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, more ? p.wbytes : 0u, 0x00020000);
+    static_for<NCOMBO>([&](auto Cc) {
+      constexpr int combo = decltype(Cc)::value;
+      static_for<NPH>([&](auto Gc) {
+        constexpr int gph = decltype(Gc)::value, jsub = gph / PH, ph = gph % PH;
+        constexpr int mh = PH == 4 ? ((ph == 0 || ph == 1) ? 0 : 1) : ph;
+        constexpr int nh = PH == 4 ? ((ph == 1 || ph == 2) ? 1 : 0) : 0;
+        constexpr bool readA = PH == 4 ? (ph == 0 || ph == 2) : true;
+        constexpr bool readB = PH == 4 ? (ph == 0 || ph == 1) : (ph == 0);
+        // ---- LOAD segment: scalar and memory instructions only ----
+        static_for<Sched::Q>([&](auto Ec) {
+          constexpr PsEntry e = Sched::tab.e[decltype(Ec)::value];
+          if constexpr (ps_phase_of<BN, SH, PH>(e) == gph) {
+            static_assert(ps_ahead_of<BN, SH, PH>(e) <= 1, "look-ahead of at most one super tile");
+            issue(Ec, std::integral_constant<int, combo + ps_ahead_of<BN, SH, PH>(e)>{}, coff, rxn, rwn);
+          }
+        });
+        if constexpr (readB) {
+          constexpr int bslot = (combo * SH + jsub) & (NBB - 1);
+          static_for<2>([&](auto Jc) {
+            constexpr int j = decltype(Jc)::value;
+            constexpr int imm = bslot * BSTAGE + (nh * 2 + j) * 16 * BKB;
+            if constexpr (nh == 0) { lds_read128<imm>(bf0[0][j], b_base0); lds_read128<imm>(bf0[1][j], b_base1); }
+            else { lds_read128<imm>(bf1[0][j], b_base0); lds_read128<imm>(bf1[1][j], b_base1); }
+          });
+        }
+        if constexpr (readA) {
+          constexpr int sA = (combo & 1) * ASTAGE;
+          static_for<4>([&](auto Ic) {
+            constexpr int i = decltype(Ic)::value;
+            if constexpr (jsub == 0) {
+              constexpr int imm = sA + (mh * 4 + i) * 16 * BKB;
+              lds_read128<imm>(af[0][i], a_base0); lds_read128<imm>(af[1][i], a_base1);
+            } else {
+              lds_read128<sA>(af[0][i], a_tbl[mh * 4 + i][jsub - 1]); lds_read128<sA>(af[1][i], a_tbx[mh * 4 + i][jsub - 1]);
+            }
+          });
+        }
+        wait_vmcnt<ps_vm<BN, SH, PH>(gph)>();
+        __builtin_amdgcn_s_barrier();
+        // ---- MATH segment ----
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+              Mma<T>::run(acc[mh * 4 + i][nh * 2 + j], nh == 0 ? bf0[s2][j] : bf1[s2][j], af[s2][i]);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_barrier();
+      });
+    });
+  }
+  if (wr == 0) __builtin_amdgcn_s_barrier();
+  wait_vmcnt<0>();
+  __syncthreads();
+  DIAG_STAMP(3);
+  gemm_epilogue<T, BM, BN, WAVES_M, WAVES_N, BOFF + NBB * BSTAGE, false, false, BF>(p, acc, smem, bm0, bn0, par, P, split);
   DIAG_STAMP(4);
 #endif
 }
@@ -1373,6 +1954,8 @@ struct GemmPlan {
   GemmParams p;
   int BM, BN, P, stats_chunks;
   bool pp;                 // 256-row tile on the ping-pong kernel
+  int ps_sh;               // > 0: on the tap-shared ping-pong kernel, taps per staged A tile (2 | 4)
+  bool ps_table;           // ... in its table-driven form (conv_gemm_pt_kernel)
   int par_npw;             // > 0: parity-patch kernel (all four parities of 256 grid positions per block), patch pieces per wave
   bool bf_requested;       // the caller asked for a fused backward epilogue (carried iff p.bf_mode != 0)
   dim3 grid;
@@ -1577,6 +2160,16 @@ static int plan_gemm(const GanConvDesc* d, int op, GemmPlan* pl) {
 #endif
   const int use_pp = gan_opt("conv.pingpong");
   pl->pp = use_pp && BM == 256 && (BN == 256 || BN == 128) && ((long long)x.c * (d->dtype == GAN_F32 ? 4 : 2)) % 128 == 0;
+  // tap-shared variant (conv_gemm_ps_kernel): the taps of a kernel row that read the same pixels one grid column apart share one staged
+  // A tile: 2 for the stride-2 shapes and the parity sub-GEMMs, 4 for the stride-1 convolutions.  Needs the halo of a 64-row block
+  // (one entry per image-row segment and shift) to fit its 16 LDS rows.  Option bit 0: 128-column tiles, bit 1: 256-column tiles.
+  pl->ps_sh = 0;
+  if (pl->pp && d->dtype != GAN_F32 && (gan_opt("conv.tap_share") & (BN == 256 ? 2 : 1))) {
+    const int sh = (p.S == 2 || p.parity) ? 2 : 4;
+    const int segs = (63 + p.Wg - 1) / p.Wg + 1;
+    if ((1 << p.TWlog2) % sh == 0 && p.kchunks % sh == 0 && segs * (sh - 1) <= 16) pl->ps_sh = sh;
+  }
+  pl->ps_table = pl->ps_sh && BN == 128 && (gan_opt("conv.tap_share") & 4) && (p.kchunks >> (2 * p.TWlog2)) >= splits;
   pl->BM = BM; pl->BN = BN;
   pl->grid = dim3((unsigned)(tilesM * tilesN * (pl->par_npw ? 1 : P)), 1, (unsigned)splits);
   pl->slab_bytes = splits > 1 ? (size_t)P * splits * (size_t)M * p.NslabPitch * sizeof(float) : 0;
@@ -1620,6 +2213,58 @@ static int launch_pp(const GemmPlan& pl, hipStream_t st) {       // the lean ins
   return full ? launch_pp_v<T, BN, true>(pl, st) : launch_pp_v<T, BN, false>(pl, st);
 }
 
+template <typename T, int BN, int SH, int TWV, bool BF>
+static int launch_pt_v(const GemmPlan& pl, hipStream_t st) {
+  static bool attr_set = false;
+  constexpr size_t smem = (size_t)2 * (256 + 64) * 128 + (size_t)(BN == 256 ? 2 : 4) * BN * 128;
+  if constexpr (sizeof(T) == 2) {
+    auto kern = conv_gemm_pt_kernel<T, BN, SH, TWV, BF>;
+    if (!attr_set) {
+      hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      if (e != hipSuccess) return (int)e;
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, pl.grid, dim3(512), smem, st, pl.p);
+    GAN_CHECK_LAUNCH();
+    return 0;
+  } else {
+    return GAN_E_SHAPE;
+  }
+}
+template <typename T, int BN, int SH, int PH, bool BF>
+static int launch_ps_v(const GemmPlan& pl, hipStream_t st) {
+  static bool attr_set = false;
+  constexpr size_t smem = (size_t)2 * (256 + 64) * 128 + (size_t)(BN == 256 ? 2 : 4) * BN * 128;
+  if constexpr (sizeof(T) == 2) {
+    auto kern = conv_gemm_ps_kernel<T, BN, SH, PH, BF>;
+    if (!attr_set) {
+      hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      if (e != hipSuccess) return (int)e;
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, pl.grid, dim3(512), smem, st, pl.p);
+    GAN_CHECK_LAUNCH();
+    return 0;
+  } else {
+    return GAN_E_SHAPE;       // (the planner keeps fp32 on the kernel above)
+  }
+}
+template <typename T, int BN>
+static int launch_ps(const GemmPlan& pl, hipStream_t st) {
+  const bool full = pl.p.bf_mode != 0 || !gan_opt("conv.lean_epilogue");
+  if constexpr (BN == 128) {
+    if (pl.ps_table) {                        // table-driven form
+      const int twv = 1 << pl.p.TWlog2;
+      if (pl.ps_sh == 4) return full ? launch_pt_v<T, BN, 4, 4, true>(pl, st) : launch_pt_v<T, BN, 4, 4, false>(pl, st);
+      if (twv == 4) return full ? launch_pt_v<T, BN, 2, 4, true>(pl, st) : launch_pt_v<T, BN, 2, 4, false>(pl, st);
+      return full ? launch_pt_v<T, BN, 2, 2, true>(pl, st) : launch_pt_v<T, BN, 2, 2, false>(pl, st);
+    }
+  }
+  constexpr int PH = BN == 256 ? 4 : 2;
+  if (pl.ps_sh == 2) return full ? launch_ps_v<T, BN, 2, PH, true>(pl, st) : launch_ps_v<T, BN, 2, PH, false>(pl, st);
+  return full ? launch_ps_v<T, BN, 4, PH, true>(pl, st) : launch_ps_v<T, BN, 4, PH, false>(pl, st);
+}
+
 template <typename T, int NPW>
 static int launch_par(const GemmPlan& pl, hipStream_t st) {
   static bool attr_set = false;
@@ -1651,8 +2296,8 @@ static int launch_gemm(const GemmPlan& pl, hipStream_t st) {
   }
   const int key = pl.pp ? pl.BN : pl.BM * 1000 + pl.BN;
   switch (key) {
-    case 256: rc = launch_pp<T, 256>(pl, st); break;
-    case 128: rc = launch_pp<T, 128>(pl, st); break;
+    case 256: rc = pl.ps_sh ? launch_ps<T, 256>(pl, st) : launch_pp<T, 256>(pl, st); break;
+    case 128: rc = pl.ps_sh ? launch_ps<T, 128>(pl, st) : launch_pp<T, 128>(pl, st); break;
     case 256256: rc = launch_cfg<T, 256, 256, 2, 4>(pl, st); break;
     case 256128: rc = launch_cfg<T, 256, 128, 4, 2>(pl, st); break;
     case 128128: rc = launch_cfg<T, 128, 128, 2, 2>(pl, st); break;
@@ -1816,6 +2461,15 @@ int gan_conv_plan_info(const GanConvDesc* d, int op, int32_t* info /*[5]: BM, BN
   info[4] = pl.stats_chunks;          // > 0: this launch can emit normalisation-statistics partials (chunks per group)
   if (const int fam = thin_family(&t, op, pl.p)) { info[0] = 0; info[1] = fam; info[2] = 1; info[4] = 0; }   // thin.hip kernels
   return 0;
+}
+int gan_conv_tap_shared(const GanConvDesc* d, int op) {
+  if (!d || d->struct_size != sizeof(GanConvDesc)) return GAN_E_ARG;
+  GemmPlan pl;
+  GanConvDesc t = *d;
+  plan_only_desc(&t);
+  const int rc = plan_gemm(&t, op, &pl);
+  if (rc) return rc;
+  return (thin_family(&t, op, pl.p) || pl.par_npw || !pl.pp) ? 0 : pl.ps_sh;
 }
 /* ---- layer stack: plan on the host, launch from a device copy of the plan ---- */
 size_t gan_conv_stack_plan_bytes(int32_t n) { return n > 0 ? 256 + (size_t)n * sizeof(StackLayer) : 0; }

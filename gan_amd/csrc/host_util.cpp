@@ -30,6 +30,7 @@ Opt g_opts[] = {
     {"conv.big_min_blocks", {128}}, // a 256-row tile needs at least this many blocks
     {"conv.tall64", {1}},           // 256x64 tiles for 64-channel outputs on big maps
     {"conv.lean_epilogue", {1}},    // ping-pong launches without a fused backward epilogue use the instantiation compiled without it (fewer registers)
+    {"conv.tap_share", {7}},        // tap-shared ping-pong kernel: bit 0 on the 256x128 tiles, bit 1 on the 256x256 tiles, bit 2 the table-driven form (256x128)
     {"conv.pingpong", {1}},         // 256-row tiles on the ping-pong kernel
     {"conv.parity_patch", {1}},     // parity-patch kernel for stride-2 transposed convs with 64 output channels
     {"conv.parity_patch_max_n", {64}},

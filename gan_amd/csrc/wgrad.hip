@@ -857,7 +857,11 @@ template <typename T>
 __global__ __launch_bounds__(512) void wgrad_pp_kernel(const WgradParams p, unsigned bigbytes, unsigned smallbytes) {
 #if defined(__HIP_DEVICE_COMPILE__)
   static_assert(sizeof(T) == 2, "16-bit storage types");
-  constexpr int PANEL = 64 * 128, STAGE = 8 * PANEL, NB = 2, PH = 4, PP = 2, DP = 6, VMW = 6, QS = 8;
+#ifndef WPP_DP
+#define WPP_DP 5      // (6 = the deepest the two stages allow: 1 % slower; 4: +12 %)
+#endif
+  constexpr int PANEL = 64 * 128, STAGE = 8 * PANEL, NB = 2, PH = 4, PP = 2, DP = WPP_DP, VMW = 2 * DP - 6, QS = 8;
+  static_assert(DP >= 4 && DP <= 6, "staged 4..6 phases ahead (WAR: <= 6 with two stages; RAW: the last B pair is read DP - 2 phases after its issue)");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   WDIAG_STAMP(0);
@@ -949,8 +953,10 @@ __global__ __launch_bounds__(512) void wgrad_pp_kernel(const WgradParams p, unsi
   // prologue: slots of phases -6 .. -1 = all of K tile 0 and A0, B, B of K tile 1
   rowinfo(0);
   issue_slots(std::integral_constant<int, 0>{}, std::integral_constant<int, 8>{}, 0);
-  rowinfo(1);
-  issue_slots(std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{}, 1);
+  if constexpr (DP > 4) {
+    rowinfo(1);
+    issue_slots(std::integral_constant<int, 0>{}, std::integral_constant<int, 2 * (DP - 4)>{}, 1);
+  }
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VMW) : "memory");
   __builtin_amdgcn_s_barrier();
   WDIAG_STAMP(2);
@@ -969,7 +975,7 @@ __global__ __launch_bounds__(512) void wgrad_pp_kernel(const WgradParams p, unsi
       constexpr int mh = ph < 2 ? 0 : 1, nh = (ph == 1 || ph == 2) ? 1 : 0;
       // ---- LOAD segment ----
       constexpr int x0 = PP * (ph + DP);                   // 12, 14, 16, 18 -> (tile t+1: slots 4,5 | 6,7), (tile t+2: 0,1 | 2,3)
-      if constexpr (ph == 2) rowinfo(t + 2);
+      if constexpr ((ph + DP) % 4 == 0) rowinfo(t + (ph + DP) / 4);
       issue_slots(std::integral_constant<int, x0 % QS>{}, std::integral_constant<int, PP>{}, t + x0 / QS);
       WSEG_ADD(5);                                         // row decode + LDS-DMA issue
       if constexpr (ph == 0 || ph == 1) {

@@ -132,6 +132,10 @@ size_t gan_conv_workspace_bytes(const GanConvDesc* d, int op /*0 conv_fwd,1 conv
  * (BM = 0: streaming kernel family BN; BM = 1024: parity-patch kernel; info[4] = -1: norm_fuse is honoured, the launch
  * finishes the layer) */
 int gan_conv_plan_info(const GanConvDesc* d, int op, int32_t* info);
+/* Which main loop a 256-row tile of this launch takes: 0 = one staged A tile per tap (conv_gemm_pp_kernel), 2 | 4 = the taps of a
+ * kernel row that read the same pixels one grid column apart share one staged A tile (conv_gemm_ps_kernel; option conv.tap_share).
+ * 0 for every other tile; < 0: error code.  Results of the two loops differ in fp32 summation order only. */
+int gan_conv_tap_shared(const GanConvDesc* d, int op);
 
 /* ---- layer stack: a run of consecutive small split-K layers in ONE launch -------------------------------------------------
  * The inner layers of the U-Net (base_gan.py:183-193: down5..down8, up1..up3 at batch 16; most of the generator at the reference's
@@ -385,7 +389,7 @@ const char* gan_version(void);
 /* The launch planners' tunable constants.  The library reads NO environment variable: these calls are the only way to
  * change them, and a change applies to the entry-point calls that follow it (each call plans for itself).  Unknown key:
  * GAN_E_ARG.  Keys (default): conv.big_tiles (1), conv.q128 (55), conv.q256n (80), conv.big_min_blocks (128),
- * conv.tall64 (1), conv.pingpong (1), conv.lean_epilogue (1), conv.parity_patch (1), conv.parity_patch_max_n (64),
+ * conv.tall64 (1), conv.pingpong (1), conv.lean_epilogue (1), conv.tap_share (7: bit 0 = 256x128 tiles, bit 1 = 256x256 tiles on the tap-shared kernel, bit 2 = its table-driven form on the 256x128 tiles), conv.parity_patch (1), conv.parity_patch_max_n (64),
  * conv.parity_patch_min_blocks (192), conv.split_target (256), conv.split_target_skinny (1024),
  * conv.split_target_big (256), conv.split_min_ktiles (4), conv.split_max (64), conv.bwd_fuse_tile (1: the fused backward
  * epilogue rides on every tile epilogue; 0 never, 2 not on 64-column tiles, 3 on 64-column tiles only), conv.thin (7: bit 0

@@ -132,6 +132,61 @@ def test_conv2d_fwd_dgrad_wgrad(ctx, case):
     assert rel(dw.cpu().numpy().reshape(4, 4, ci, co), 2 * dw_ref) < TOL[ctx.dtype]
 
 
+TAPSHARE_CASES = [  # (op, N, H of x, Cin (x channels), Cout (y channels), stride, taps per staged A tile, oracle?)
+    ('conv_fwd', 8, 128, 64, 128, 2, 2, True),       # 256x128 tiles, rows of 64 positions
+    ('conv_fwd', 8, 128, 64, 256, 2, 2, False),      # 256x256 tiles
+    ('conv_fwd', 16, 100, 64, 128, 2, 2, True),      # rows of 50 positions: segments cut inside the 64-row blocks, ragged last tile
+    ('conv_fwd', 32, 32, 256, 512, 1, 4, False),     # D conv4 at batch 16: 256x256 tiles, rows of 31, four taps per staged tile
+    ('conv_fwd', 40, 32, 64, 128, 1, 4, True),       # stride 1 on 256x128 tiles
+    ('conv_dgrad', 32, 31, 512, 256, 1, 4, False),   # D conv4's dgrad (shifts to the left: dstep = -1), 256x128 tiles
+    ('conv_dgrad', 8, 64, 256, 128, 2, 2, True),     # stride-2 dgrad: four parity sub-GEMMs of two taps per row
+    ('convT_fwd', 4, 64, 128, 128, 2, 2, True),      # transposed forward (parity form)
+    ('convT_fwd', 16, 16, 1024, 256, 2, 2, False),   # rows of 16, split K
+    ('convT_dgrad', 16, 64, 128, 512, 2, 2, False),  # = stride-2 convolution over dy, 256 blocks
+    ('convT_dgrad', 16, 32, 256, 1024, 2, 2, False), # rows of 16, split K
+]
+
+
+@pytest.mark.parametrize("case", TAPSHARE_CASES)
+def test_tap_shared_pingpong_equals_pingpong(ctx, case, planner_options):
+    """conv_gemm_ps_kernel (the taps of a kernel row share one staged A tile) against conv_gemm_pp_kernel on the same launch: same
+    products, another fp32 summation order - fp32 outputs agree to 1e-5 of the largest value, 16-bit outputs to one rounding step
+    on a small fraction of the elements; the smaller shapes also against the oracle."""
+    from gan_amd import _lib as L
+    from gan_amd.nets import Buf
+    if ctx.dtype == 'f32':
+        pytest.skip("fp32 stays on the one-tap-per-tile kernel")
+    op, N, H, cx, cy, s, sh, with_oracle = case
+    rng = np.random.default_rng(abs(hash(case)) % 2**31)
+    Ho = {'conv_fwd': (H + 2 - 4) // s + 1, 'conv_dgrad': H * 2 if s == 2 else H + 1, 'convT_fwd': 2 * H, 'convT_dgrad': H // 2}[op]
+    x = q(ctx, rng.standard_normal((N, H, H, cx)))
+    # weights in Keras layout (4, 4, in, out) of the LAYER: conv_fwd in = cx; dgrads run over the layer's output side
+    kin, kout = {'conv_fwd': (cx, cy), 'conv_dgrad': (cy, cx), 'convT_fwd': (cy, cx), 'convT_dgrad': (cx, cy)}[op]
+    w = q(ctx, 0.05 * rng.standard_normal((4, 4, kin, kout)))
+    nat, tr = prep(ctx, w)
+    wk = {'conv_fwd': tr, 'conv_dgrad': nat, 'convT_fwd': nat, 'convT_dgrad': tr}[op]
+    xb, xv = dev(ctx, x)
+    outs = {}
+    for f32 in (0, 1):
+        for share in (0, 3, 7):                      # 3: tap-shared kernel, 7: its table-driven form on the 256x128 tiles
+            planner_options('conv.tap_share', share)
+            yb = Buf(ctx, N, Ho, Ho, cy, torch.float32 if f32 else None)
+            d = L.GanConvDesc(ctx.dt, s, xv, yb.view(0, cy), wk.data_ptr(), cy, None, 0, 0.3, f32, ctx.ws_ptr, ctx.ws_bytes)
+            assert ctx.lib.gan_conv_tap_shared(C.byref(d), ['conv_fwd', 'conv_dgrad', 'convT_fwd', 'convT_dgrad'].index(op)) == (sh if share else 0)
+            conv_call(ctx, op, xv, yb.view(0, cy), wk, cy, s, None, 0, f32)
+            outs[f32, share] = host(yb)
+    scale = np.abs(outs[1, 0]).max()
+    assert scale > 0
+    assert np.abs(outs[1, 3] - outs[1, 0]).max() < 1e-5 * scale
+    diff = outs[0, 3] != outs[0, 0]
+    assert diff.mean() < 0.02 and np.abs(outs[0, 3] - outs[0, 0]).max() <= (2.0 ** -7 if ctx.dtype == 'bf16' else 2.0 ** -10) * scale
+    assert np.array_equal(outs[1, 7], outs[1, 3]) and np.array_equal(outs[0, 7], outs[0, 3])     # same arithmetic, same order
+    if with_oracle:
+        ref = {'conv_fwd': lambda: O.conv2d_fwd(x, w, s), 'conv_dgrad': lambda: O.conv2d_bwd(np.zeros((N, Ho, Ho, cy)), w, x, s)[0],
+               'convT_fwd': lambda: O.convT2d_fwd(x, w), 'convT_dgrad': lambda: O.convT2d_bwd(np.zeros((N, Ho, Ho, cy)), w, x)[0]}[op]()
+        assert rel(outs[0, 3], ref) < TOL[ctx.dtype]
+
+
 CONVT_CASES = [  # (N, h, Cin, Cout)
     (16, 1, 512, 512),      # up0 at 256: 1x1 -> 2x2
     (2, 4, 1024, 512),

@@ -11,6 +11,9 @@ from gan_amd.nets import Ctx, Buf
 op, N, H, ci, co, s = sys.argv[1], *map(int, sys.argv[2:7])
 ctx = Ctx('cuda:0', os.environ.get('DT', 'bf16'))
 lib = ctx.lib
+for kv in os.environ.get('OPTS', '').split(','):       # planner options: OPTS=conv.tap_share=3,...
+    if kv:
+        L.set_option(kv.split('=')[0], int(kv.split('=')[1]))
 lib.gan_diag_set.argtypes = [C.c_void_p]
 opi = {'conv_fwd': 0, 'conv_dgrad': 1, 'convT_fwd': 2, 'convT_dgrad': 3}[op]
 if op == 'conv_fwd':
