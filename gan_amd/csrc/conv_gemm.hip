@@ -1270,6 +1270,7 @@ __global__ __launch_bounds__(512) void conv_gemm_pt_kernel(const GemmParams p) {
   const unsigned swz0 = (unsigned)((q ^ (r & 7)) << 4), swz1 = (unsigned)(((4 + q) ^ (r & 7)) << 4);
   const unsigned a_base0 = lds_base + (wr * 128 + r) * BKB + swz0, a_base1 = lds_base + (wr * 128 + r) * BKB + swz1;
   const unsigned b_base0 = lds_base + BOFF + (wc * WTN + r) * BKB + swz0, b_base1 = lds_base + BOFF + (wc * WTN + r) * BKB + swz1;
+  static_assert(BN == 128, "256 columns: no room for the tables (measured with the second table replaced by a v_xor per read: 0.164 -> 0.187 ms per step for the class, spills)");
   unsigned a_tbl[8][SH - 1], a_tbx[8][SH - 1];
 #pragma unroll
   for (int i = 0; i < 8; ++i) {

@@ -8,7 +8,7 @@ out, tag = sys.argv[1], sys.argv[2]
 
 
 def friendly(sym):
-    m = re.match(r'_Z19conv_gemm_pp_kernelI(DF16b|DF16_|f)Li(\d+)E', sym)
+    m = re.match(r'_Z19conv_gemm_p[pst]_kernelI(DF16b|DF16_|f)Li(\d+)E', sym)     # ping-pong, tap-shared and table-driven forms: one class per tile
     if m:
         return f"conv_gemm<{ {'DF16b': 'bf16', 'DF16_': 'f16', 'f': 'f32'}[m.group(1)] },256,{m.group(2)}>"
     m = re.match(r'_Z16conv_gemm_kernelI(DF16b|DF16_|f)Li(\d+)ELi(\d+)E', sym)
