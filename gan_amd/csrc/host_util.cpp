@@ -48,6 +48,7 @@ Opt g_opts[] = {
     {"conv.thin", {7}},             // bit 0: streaming kernels at all, bit 1: thin-N, bit 2: thin-K
     {"wgrad.tile256", {0}},         // 256-row tiles in the 128x128 kernel family
     {"wgrad.pingpong", {1}},
+    {"wgrad.row_table", {1}},       // ping-pong wgrad: the block decodes its reduction rows once into an LDS table instead of per K tile in the loop
     {"wgrad.pingpong_min_rows", {0}},   // 0: 1024 rows per split (2048 when the launch shares the chip)
     {"wgrad.pingpong_128", {1}},       // 128-channel SMALL tensors on the 256-column ping-pong tile (half the columns dropped): +0.5 % on the step
     {"wgrad.pingpong_min_gflop", {30}},

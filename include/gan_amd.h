@@ -393,7 +393,7 @@ const char* gan_version(void);
  * conv.parity_patch_min_blocks (192), conv.split_target (256), conv.split_target_skinny (1024),
  * conv.split_target_big (256), conv.split_min_ktiles (4), conv.split_max (64), conv.bwd_fuse_tile (1: the fused backward
  * epilogue rides on every tile epilogue; 0 never, 2 not on 64-column tiles, 3 on 64-column tiles only), conv.thin (7: bit 0
- * streaming kernels for the <= 8-channel layers, bit 1 thin-N, bit 2 thin-K), conv.norm_fuse (1), conv.stack (0: the callers in gan_amd/ merge eligible runs into layer stacks only when set), conv.stack_blocks (256), conv.thin_fused (1), wgrad.tile256 (0), wgrad.pingpong (1),
+ * streaming kernels for the <= 8-channel layers, bit 1 thin-N, bit 2 thin-K), conv.norm_fuse (1), conv.stack (0: the callers in gan_amd/ merge eligible runs into layer stacks only when set), conv.stack_blocks (256), conv.thin_fused (1), wgrad.tile256 (0), wgrad.pingpong (1), wgrad.row_table (1),
  * wgrad.pingpong_min_rows (0 = automatic), wgrad.pingpong_128 (1), wgrad.pingpong_min_gflop (30),
  * wgrad.split_target (512), wgrad.fold_split_target (512), wgrad.reduce_adam (1),
  * wgrad.reduce_adam_min_params (1048576: smaller kernels keep the flat slab reduce and the caller's multi-tensor Adam pass). */
