@@ -1036,11 +1036,17 @@ __global__ __launch_bounds__(512) void wgrad_pp_kernel(const WgradParams p, unsi
   s16x4 alo[2][4], ahi[2][4], b0lo[2][2], b0hi[2][2], b1lo[2][2], b1hi[2][2];
   WSEG_DECL;
   WSEG_T0;
-  for (int t = 0; t < nk; ++t) {
-    const unsigned so = lds_base + (unsigned)((t & 1) * STAGE) + lrow_off;
-    unsigned bt[4];
+  // fragment addresses of both stages: loop invariants (the K loop is unrolled by the stage so that a LOAD segment adds nothing to them)
+  unsigned btA[2][4], btB[2][4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) bt[k] = so + ((k ^ swl) << 5);
+  for (int st_ = 0; st_ < 2; ++st_)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const unsigned a = lds_base + (unsigned)(st_ * STAGE) + lrow_off + ((k ^ swl) << 5);
+      btA[st_][k] = a + wr * 2 * PANEL; btB[st_][k] = a + wc * PANEL;
+    }
+  auto ktile = [&](auto STc, int t) {
+    constexpr int ST = decltype(STc)::value;
     wg_static_for<PH>([&](auto Pc) {
       constexpr int ph = decltype(Pc)::value;
       constexpr int mh = ph < 2 ? 0 : 1, nh = (ph == 1 || ph == 2) ? 1 : 0;
@@ -1056,8 +1062,8 @@ __global__ __launch_bounds__(512) void wgrad_pp_kernel(const WgradParams p, unsi
           constexpr int imm = 4 * PANEL;                   // SMALL panels follow the 4 BIG panels
           wg_static_for<2>([&](auto Sc) {
             constexpr int s2 = decltype(Sc)::value;
-            if constexpr (nh == 0) { lds_read_tr<imm + s2 * 4096>(b0lo[s2][j], bt[j] + wc * PANEL); lds_read_tr<imm + s2 * 4096 + 512>(b0hi[s2][j], bt[j] + wc * PANEL); }
-            else { lds_read_tr<imm + s2 * 4096>(b1lo[s2][j], bt[2 + j] + wc * PANEL); lds_read_tr<imm + s2 * 4096 + 512>(b1hi[s2][j], bt[2 + j] + wc * PANEL); }
+            if constexpr (nh == 0) { lds_read_tr<imm + s2 * 4096>(b0lo[s2][j], btB[ST][j]); lds_read_tr<imm + s2 * 4096 + 512>(b0hi[s2][j], btB[ST][j]); }
+            else { lds_read_tr<imm + s2 * 4096>(b1lo[s2][j], btB[ST][2 + j]); lds_read_tr<imm + s2 * 4096 + 512>(b1hi[s2][j], btB[ST][2 + j]); }
           });
         });
       }
@@ -1067,7 +1073,7 @@ __global__ __launch_bounds__(512) void wgrad_pp_kernel(const WgradParams p, unsi
           wg_static_for<2>([&](auto Sc) {
             constexpr int s2 = decltype(Sc)::value;
             constexpr int imm = mh * PANEL + s2 * 4096;
-            lds_read_tr<imm>(alo[s2][i], bt[i] + wr * 2 * PANEL); lds_read_tr<imm + 512>(ahi[s2][i], bt[i] + wr * 2 * PANEL);
+            lds_read_tr<imm>(alo[s2][i], btA[ST][i]); lds_read_tr<imm + 512>(ahi[s2][i], btA[ST][i]);
           });
         });
       }
@@ -1099,6 +1105,10 @@ __global__ __launch_bounds__(512) void wgrad_pp_kernel(const WgradParams p, unsi
       __builtin_amdgcn_s_barrier();
       WSEG_ADD(4);                                         // waiting for the partner group's LOAD segment
     });
+  };
+  for (int t = 0; t < nk; t += 2) {
+    ktile(std::integral_constant<int, 0>{}, t);
+    if (t + 1 < nk) ktile(std::integral_constant<int, 1>{}, t + 1);
   }
   WSEG_STORE;
   if (wr == 0) __builtin_amdgcn_s_barrier();
