@@ -835,7 +835,7 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(const GemmParams p) {
 // (the part of an image row inside the row's 64-row block of the tile) the pixel is a HALO entry: per block 16 LDS rows behind the
 // tile (256 + 16*block + segment*(SH-1) + k), staged by one extra piece per wave and super tile with the same validity logic as a tile
 // row at the virtual column.  Staged bytes per K tile: 256x128 tile 48 KB -> 34 (SH 2) / 26 (SH 4); 256x256 64 -> 50 / 42 - the loop
-// of the kernel above is bound by the issue of exactly these pieces.
+// of the kernel above is as long as its LOAD segment, these pieces and the address work in front of them included.
 //
 // K order: chunk major, then tap row, class, and the SH taps of the class (the kernel above: chunk major, tap minor), so sums differ
 // from it in fp32 rounding order only.  LDS: A ring of 2 super tiles x (256 + 64 halo rows) x 128 B | B ring of NBB K tiles.
@@ -853,7 +853,8 @@ template <int BN, int SH, int PH> constexpr int ps_need(const PsEntry& e) {   //
   return e.kind == PS_A0 ? 0 : e.kind == PS_A1 ? (PH == 4 ? 2 : 1) : e.kind == PS_H ? PH : e.j * PH + (PH == 4 ? e.h : 0);
 }
 // The table: every piece is issued PS_LA phases before the phase that first reads it, or as early as its slot's WAR rule allows
-// if that is later; entries in issue order (stable: the order below inside one phase)
+// if that is later; entries in issue order (stable: the order below inside one phase).  PS_LA = 3 from a sweep (2: latency shows,
+// +10 %; 4-6: more pieces in flight lengthen the LOAD segments, up to +45 % on the 256x256 tiles)
 #ifndef PS_LA
 #define PS_LA 3
 #endif
@@ -905,17 +906,6 @@ template <int BN, int SH, int PH> constexpr int ps_vm(int gph) {
       ++seq;
     }
   return seq - 1 - newest_needed;
-}
-template <int BN, int SH, int PH> constexpr int ps_pos(int i) {               // position of entry i among the entries of its phase
-  using S = PsSched<BN, SH, PH>;
-  int n = 0;
-  for (int j = 0; j < i; ++j) n += ps_phase_of<BN, SH, PH>(S::tab.e[j]) == ps_phase_of<BN, SH, PH>(S::tab.e[i]) ? 1 : 0;
-  return n;
-}
-template <int BN, int SH, int PH> constexpr int ps_max_per_phase() {
-  int m = 0;
-  for (int i = 0; i < PsSched<BN, SH, PH>::Q; ++i) m = ps_pos<BN, SH, PH>(i) + 1 > m ? ps_pos<BN, SH, PH>(i) + 1 : m;
-  return m;
 }
 template <int BN, int SH, int PH> constexpr bool ps_sched_ok() {
   using S = PsSched<BN, SH, PH>;
