@@ -1423,9 +1423,13 @@ __global__ __launch_bounds__(512) void conv_gemm_pt_kernel(const GemmParams p) {
 //   patch pieces of chunk c+1 are issued in LOAD(4c+1) and LOAD(4c+2) into buffer (c+1) & 1, last read in LOAD(4c-1);
 //   RAW: everything first read in LOAD(s+1) is covered by the vmcnt at the end of LOAD(s) of every wave: at that point only
 //     the pieces issued in LOAD(s) itself may be outstanding (2 B pieces + the patch pieces of that step).
-template <typename T, int NPW>
+// (Round 4: templated on log2 of the grid width so that every fragment address is `per-lane register + immediate`, the chunk loop unrolled
+// by the patch buffer, piece offsets = a loop-invariant register + a scalar chunk offset, chunks past the end through a zero-record
+// descriptor: no vector instruction and no address arithmetic left in a LOAD segment, as in conv_gemm_pt_kernel.)
+template <typename T, int LW>
 __global__ __launch_bounds__(512) void conv_par_kernel(const GemmParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int NPW = LW == 7 ? 5 : 4;                       // patch pieces per wave: ceil((256 / Wg + 2) * (Wg + 8) / 16 / 8)
   constexpr int BM = 256, PC = 64, BN = 4 * PC, CKB = 64;    // rows, channels per parity, virtual columns, bytes of K per LDS row
   constexpr int BSTEP = 4 * PC * CKB;                        // B tiles of one K step (4 parities): 16 KB
   constexpr int BRING = 4 * BSTEP;
@@ -1443,8 +1447,8 @@ __global__ __launch_bounds__(512) void conv_par_kernel(const GemmParams p) {
   const int nb = p.tilesM * p.tilesN;
   if ((nb & 7) == 0) bid = (bid & 7) * (nb >> 3) + (bid >> 3);
   const int bm0 = (bid / p.tilesN) * BM, bn0 = (bid % p.tilesN) * PC;
-  const int Wg = p.Wg, PW = Wg + 8;                          // patch row: halo | Wg pixels | halo | 6 unused (PW % 8 == 0, below)
-  const int lw = 31 - __builtin_clz((unsigned)Wg);           // Wg is a power of two (16..128)
+  constexpr int Wg = 1 << LW, PW = Wg + 8;                   // patch row: halo | Wg pixels | halo | 6 unused (PW % 8 == 0, below)
+  constexpr int lw = LW;                                     // Wg is a power of two (16..128)
   const int Rrows = BM >> lw;
   // tile origin (R whole rows of one image)
   const int img = bm0 / (p.Hg * Wg), gy0 = (bm0 - img * p.Hg * Wg) >> lw;
@@ -1469,6 +1473,8 @@ __global__ __launch_bounds__(512) void conv_par_kernel(const GemmParams p) {
   }
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.xbytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.wbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rx0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, 0u, 0x00020000);     // zero records: chunks past the end
+  const __amdgpu_buffer_rsrc_t rw0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, 0u, 0x00020000);
   const int wtapbytes = p.Wrows * p.Cin * ES;
   const int nchunks = p.kchunks;                             // channel chunks of CKB bytes
 
@@ -1479,8 +1485,8 @@ __global__ __launch_bounds__(512) void conv_par_kernel(const GemmParams p) {
     for (int h = 0; h < 2; ++h) {
       const int pb = (wave >> 2) + 2 * h, pyb = pb >> 1, pxb = pb & 1;
       const int wtap = (1 - pyb + 2 * ty) * 4 + (1 - pxb + 2 * tx);
-      const int off = live ? b_src + wtap * wtapbytes + cc * CKB : (int)0x80000000;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(smem + t * BSTEP + (wave + 8 * h) * 1024), 16, off, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(live ? rw : rw0, (__attribute__((address_space(3))) void*)(smem + t * BSTEP + (wave + 8 * h) * 1024), 16, b_src,
+                                               wtap * wtapbytes + cc * CKB, 0, 0);
     }
   };
   auto issue_patch = [&](auto J0c, auto CNTc, int cc) {      // pieces wave + 8j, j in [J0, J0 + CNT), of chunk cc
@@ -1489,8 +1495,7 @@ __global__ __launch_bounds__(512) void conv_par_kernel(const GemmParams p) {
     unsigned char* dst = smem + BRING + (cc & 1) * PATCH;
     static_for<CNT>([&](auto Jc) {
       constexpr int j = J0 + decltype(Jc)::value;
-      const int off = live ? a_src[j] + cc * CKB : (int)0x80000000;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(dst + (wave + 8 * j) * 1024), 16, off, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(live ? rx : rx0, (__attribute__((address_space(3))) void*)(dst + (wave + 8 * j) * 1024), 16, a_src[j], cc * CKB, 0, 0);
     });
   };
 
@@ -1507,18 +1512,13 @@ __global__ __launch_bounds__(512) void conv_par_kernel(const GemmParams p) {
   // A: fragment i = tile rows wr*128 + i*16 + (0..15): 16 consecutive pixels of one image row (Wg >= 16), patch pixel
   // (row_i + 1 + dy) * PW + col_i + r + 1 + dx at shift (dy, dx).  PW % 8 == 0 and col_i % 16 == 0, so the swizzle term depends
   // on r + 1 + dx only: byte address = [wave-uniform (row_i + 1 + dy) * PW + col_i] * 64 + lane_off[dx], one add per fragment.
-  unsigned lane_off[2];                                      // tx = 0, 1 -> dx = px - tx
+  unsigned a_base[2];                                        // tx = 0, 1 -> dx = px - tx; + this wave's row half and its parity's row shift
 #pragma unroll
   for (int tx = 0; tx < 2; ++tx) {
     const unsigned c = (unsigned)(r + 1 + px - tx);
-    lane_off[tx] = (c << 6) + ((((unsigned)q) ^ (((c >> 2) & 1) << 1)) << 4);
+    a_base[tx] = lds_base + BRING + (c << 6) + ((((unsigned)q) ^ (((c >> 2) & 1) << 1)) << 4) + (unsigned)((wr * (128 >> lw) + py) * PW * CKB);
   }
-  int frag_org[8];                                           // (row_i * PW + col_i) * 64: wave-uniform
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int ml = wr * 128 + i * 16;
-    frag_org[i] = ((ml >> lw) * PW + (ml & (Wg - 1))) * CKB;
-  }
+  // fragment i of (tap row ty, patch buffer b): a_base[tx] + [(16 i >> lw) * PW + (16 i & (Wg - 1)) + (1 - ty) * PW] * 64 + b * PATCH: an immediate
 
   DIAG_STAMP(1);
   // prologue: patch of chunk 0, weights of steps 0 and 1
@@ -1533,8 +1533,8 @@ __global__ __launch_bounds__(512) void conv_par_kernel(const GemmParams p) {
   uint4 af[8], bfr[4];
   SEG_DECL;
   SEG_T0;
-  for (int c = 0; c < nchunks; ++c) {
-    const unsigned pbuf = lds_base + BRING + (unsigned)(c & 1) * PATCH;
+  auto chunk = [&](auto PBc, int c) {                        // one channel chunk: 4 K steps (taps) on patch buffer PB
+    constexpr int PB = decltype(PBc)::value;
     static_for<4>([&](auto Tc) {
       constexpr int t = decltype(Tc)::value, ty = t >> 1, tx = t & 1;
       // ---- LOAD segment ----
@@ -1542,10 +1542,12 @@ __global__ __launch_bounds__(512) void conv_par_kernel(const GemmParams p) {
         constexpr int j = decltype(Jc)::value;
         lds_read128<t * BSTEP + j * 16 * CKB>(bfr[j], b_row);
       });
-      int rowsh = (int)pbuf + (1 + py - ty) * PW * CKB;      // wave-uniform: buffer + the (parity, tap)'s row shift
-      asm volatile("" : "+s"(rowsh));                        // (recomputed per step: hoisted out of the chunk loop, the 32 (tap, fragment) addresses spill)
-#pragma unroll
-      for (int i = 0; i < 8; ++i) lds_read128<0>(af[i], lane_off[tx] + (unsigned)(frag_org[i] + rowsh));
+      static_for<8>([&](auto Ic) {
+        constexpr int i = decltype(Ic)::value;
+        constexpr int imm = (((16 * i) >> lw) * PW + ((16 * i) & (Wg - 1)) + (1 - ty) * PW) * CKB + PB * PATCH;
+        static_assert(imm >= 0 && imm < 65536, "ds_read immediate");
+        lds_read128<imm>(af[i], a_base[tx]);
+      });
       SEG_ADD(0);                                            // fragment read issue
       if constexpr (t < 2) issue_b(std::integral_constant<int, t + 2>{}, c);
       else issue_b(std::integral_constant<int, t - 2>{}, c + 1);
@@ -1569,6 +1571,10 @@ __global__ __launch_bounds__(512) void conv_par_kernel(const GemmParams p) {
       __builtin_amdgcn_s_barrier();
       SEG_ADD(4);                                            // waiting for the partner group's LOAD segment
     });
+  };
+  for (int c = 0; c < nchunks; c += 2) {
+    chunk(std::integral_constant<int, 0>{}, c);
+    if (c + 1 < nchunks) chunk(std::integral_constant<int, 1>{}, c + 1);
   }
   SEG_STORE;
   if (wr == 0) __builtin_amdgcn_s_barrier();
@@ -2256,12 +2262,13 @@ static int launch_ps(const GemmPlan& pl, hipStream_t st) {
   return full ? launch_ps_v<T, BN, 4, PH, true>(pl, st) : launch_ps_v<T, BN, 4, PH, false>(pl, st);
 }
 
-template <typename T, int NPW>
+template <typename T, int LW>
 static int launch_par(const GemmPlan& pl, hipStream_t st) {
   static bool attr_set = false;
+  constexpr int NPW = LW == 7 ? 5 : 4;
   constexpr size_t smem = (size_t)4 * 4 * 64 * 64 + 2 * (size_t)NPW * 8 * 1024;
   if constexpr (sizeof(T) == 2) {
-    auto kern = conv_par_kernel<T, NPW>;
+    auto kern = conv_par_kernel<T, LW>;
     if (!attr_set) {
       hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
       if (e != hipSuccess) return (int)e;
@@ -2279,9 +2286,11 @@ template <typename T>
 static int launch_gemm(const GemmPlan& pl, hipStream_t st) {
   int rc;
   if (pl.par_npw) {
-    switch (pl.par_npw) {
-      case 4: return launch_par<T, 4>(pl, st);
-      case 5: return launch_par<T, 5>(pl, st);
+    switch (pl.p.Wg) {                          // (the planner admits power-of-two grid widths 16..128; par_npw = 5 at 128, else 4)
+      case 16: return launch_par<T, 4>(pl, st);
+      case 32: return launch_par<T, 5>(pl, st);
+      case 64: return launch_par<T, 6>(pl, st);
+      case 128: return launch_par<T, 7>(pl, st);
       default: return GAN_E_SHAPE;
     }
   }
