@@ -766,6 +766,39 @@ def test_wgrad_pingpong_128_columns_matches_128_tile_kernel(ctx, planner_options
     assert np.abs(out[1]).max() > 100 and np.array_equal(out[0], out[1])
 
 
+@pytest.mark.parametrize("case", [(4, 128, 64, 128, 2, 4),      # 64-channel BIG tensor: four taps per 256-row tile (table of 4 columns)
+                                  (8, 64, 128, 256, 2, 2),      # 128 channels: two taps per tile
+                                  (8, 32, 256, 512, 1, 1),      # stride 1, 31 x 31 grid: rows of 31, the last K tile half empty (M % 64 = 8)
+                                  (2, 64, 128, 256, 2, 2)])     # few K tiles per block
+def test_wgrad_row_table_equals_row_decode(ctx, case, planner_options):
+    """wgrad_pp_kernel<T, NTAP>: the block's reduction rows decoded once into an LDS table (wgrad.row_table, default) against the decode
+    per K tile in the loop - same pieces, same order: bit-identical kernel gradients (random data, split reductions included)."""
+    from gan_amd import _lib as L
+    if ctx.dtype == 'f32':
+        pytest.skip("ping-pong wgrad: 16-bit storage only")
+    N, H, ci, co, s, ntap = case
+    rng = np.random.default_rng(5)
+    Ho = (H + 2 - 4) // s + 1
+    x = q(ctx, rng.standard_normal((N, H, H, ci)))
+    dy = q(ctx, rng.standard_normal((N, Ho, Ho, co)))
+    xb, xv = dev(ctx, x)
+    dyb, dyv = dev(ctx, dy)
+    planner_options('wgrad.pingpong_min_gflop', 1)
+    out = []
+    for tab in (1, 0):
+        planner_options('wgrad.row_table', tab)
+        dw = torch.zeros((16, ci, co), dtype=torch.float32, device=ctx.device)
+        d = L.GanWgradDesc(ctx.dt, s, xv, dyv, dw.data_ptr(), ci, co, 0, ctx.ws_ptr, ctx.ws_bytes)
+        winfo = (C.c_int32 * 4)()
+        assert ctx.lib.gan_wgrad_plan_info(C.byref(d), winfo) == 0 and winfo[0] == 256 and winfo[1] == 256, list(winfo)   # the ping-pong kernel
+        assert ctx.lib.gan_conv_wgrad(C.byref(d), ctx.stream()) == 0
+        torch.cuda.synchronize()
+        out.append(dw.cpu().numpy())
+    assert np.abs(out[1]).max() > 1 and np.array_equal(out[0], out[1])
+    _, dw_ref = O.conv2d_bwd(x, np.zeros((4, 4, ci, co)), dy, s, need_dx=False)
+    assert rel(out[0].reshape(4, 4, ci, co), dw_ref) < TOL[ctx.dtype]
+
+
 @pytest.mark.parametrize("case", [(2, 8, 512, 512, 'epilogue'), (4, 64, 64, 64, 'reduce'), (4, 128, 256, 256, 'reduce-pp'), (16, 32, 512, 128, 'reduce')])
 def test_wgrad_with_fused_adam_equals_wgrad_then_adam(ctx, case, planner_options):
     """GanAdamFuse: a wgrad launch that applies TF-form Adam to its kernel and refreshes both NK copies - in its own epilogue
