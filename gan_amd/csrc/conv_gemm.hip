@@ -297,7 +297,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
         } else {
           // fused backward epilogue: the reference / skip / mask vectors of U rows are requested together before any of them
           // is used (one dependent global load per iteration made this loop pure latency: +9..+40 us per launch)
-          constexpr int ITERS = TOTAL / NTHREADS, U = (ITERS % 2 == 0 ? 2 : 1);      // (8 / 4 rows at a time on the 128-column tiles until round 4: +63 registers)
+          constexpr int ITERS = TOTAL / NTHREADS, U = (BN == 128 && !PARCOLS && ITERS % 4 == 0) ? 4 : (ITERS % 2 == 0 ? 2 : 1);      // (8 / 4 rows at a time on the 128-column tiles until round 4: +63 registers)
           const int n = bn0 + (scg % PVECS) * VEC;
           const int cpy = PARCOLS ? (scg / PVECS) >> 1 : py, cpx = PARCOLS ? (scg / PVECS) & 1 : px;
           const bool colok = n < p.Cout, fuse = n < p.bf_cols;
