@@ -858,6 +858,9 @@ template <int BN, int SH, int PH> constexpr int ps_need(const PsEntry& e) {   //
 #ifndef PS_LA
 #define PS_LA 3
 #endif
+#ifndef PS_LA_A128
+#define PS_LA_A128 4      // A pieces of the 256x128 tiles (activations: HBM / Infinity Cache): -1 % on the class; on the 256x256 tiles +6 %; B pieces at 2: +9 %
+#endif
 template <int BN, int SH> struct PsTable { static constexpr int Q = 4 + 1 + SH * (BN == 256 ? 4 : 2); PsEntry e[Q]; };
 template <int BN, int SH, int PH> constexpr PsTable<BN, SH> ps_make() {
   constexpr int NPH = PH * SH, NBB = BN == 256 ? 2 : 4, Q = PsTable<BN, SH>::Q;
@@ -874,7 +877,8 @@ template <int BN, int SH, int PH> constexpr PsTable<BN, SH> ps_make() {
     const int need = ps_need<BN, SH, PH>(t.e[i]);
     const int last = t.e[i].kind == PS_A0 ? lastA0 : lastA1;
     const int most = t.e[i].kind == PS_B ? NBB * PH - 2 : 2 * NPH + need - last - 2;
-    t.e[i].p = need - (PS_LA < most ? PS_LA : most);
+    const int la = (t.e[i].kind != PS_B && BN == 128) ? PS_LA_A128 : PS_LA;
+    t.e[i].p = need - (la < most ? la : most);
   }
   for (int i = 1; i < Q; ++i) {                              // insertion sort by issue phase
     const PsEntry x = t.e[i];
