@@ -1210,20 +1210,32 @@ __global__ __launch_bounds__(512) void conv_gemm_pt_kernel(const GemmParams p) {
   const int dir = p.dstep > 0 ? 1 : -1;
   const int pixbytes = p.xpitch * ES;
 
+  DIAG_STAMP(5);
   // ---- per-lane piece offsets: 4 tile rows + 1 halo row, one per (tap row, class) -----------------------
   const int lrow = lane >> 3, slot = lane & 7;
   const int chunkB = ((slot ^ lrow) << 4);
   int atab[5][NCOMBO];
+  // (Straight-line, branch-free and short: written with && / ?: per entry this block compiled to ~1,100 instructions with 55 exec-masked
+  // branches and a scalar multiply chain per entry - 3.2 us per block in front of the first piece, tools/diag_gemm.py.)
+  int s_aoff[NCOMBO];                                        // tap offsets of the combinations: scalars, shared by the five rows
+#pragma unroll
+  for (int cc = 0; cc < NCOMBO; ++cc) s_aoff[cc] = ((cc / NC) * p.dstep * p.Ws + (cc % NC) * p.dstep) * pixbytes;
   auto fill_row = [&](auto Rc, bool exists, unsigned t, int gx) {
     constexpr int row = decltype(Rc)::value;
     const unsigned img = fdiv(t, p.divHg);
     const int gy = (int)t - (int)img * p.Hg;
     const int sy0 = gy * p.S + dy0, sx0 = gx * p.S + dx0;
     const int org = (int)((((long long)((int)img * p.Hs + sy0) * p.Ws + sx0) * (long long)p.xpitch) * ES) + chunkB;
+    unsigned vx = 0, vyx = 0;                                // validity bits: classes; (tap row, class) combinations
+#pragma unroll
+    for (int c = 0; c < NC; ++c) vx |= (unsigned)((unsigned)(sx0 + c * p.dstep) < (unsigned)p.Ws) << c;
+#pragma unroll
+    for (int ty = 0; ty < TWV; ++ty) vyx |= (vx & (0u - (unsigned)((unsigned)(sy0 + ty * p.dstep) < (unsigned)p.Hs))) << (ty * NC);
+    vyx &= 0u - (unsigned)exists;
     static_for<NCOMBO>([&](auto Cc) {
-      constexpr int cc = decltype(Cc)::value, ty = cc / NC, c = cc % NC;
-      const bool ok = exists && (unsigned)(sy0 + ty * p.dstep) < (unsigned)p.Hs && (unsigned)(sx0 + c * p.dstep) < (unsigned)p.Ws;
-      atab[row][cc] = ok ? org + (ty * p.dstep * p.Ws + c * p.dstep) * pixbytes : (int)0x80000000;
+      constexpr int cc = decltype(Cc)::value;
+      const int m = __builtin_amdgcn_sbfe((int)vyx, cc, 1);           // 0 | -1
+      atab[row][cc] = ((org + s_aoff[cc]) & m) | ((int)0x80000000 & ~m);
     });
   };
   static_for<4>([&](auto Rc) {
@@ -1242,6 +1254,7 @@ __global__ __launch_bounds__(512) void conv_gemm_pt_kernel(const GemmParams p) {
     const int gs = g0 > (int)rs ? g0 - (int)rs : 0, ge = g1 - (int)rs < p.Wg - 1 ? g1 - (int)rs : p.Wg - 1;
     fill_row(std::integral_constant<int, 4>{}, exists, t, dir > 0 ? ge + 1 + k : gs - 1 - k);
   }
+  DIAG_STAMP(6);
   constexpr int BK_ = BN == 256 ? 4 : 2;
   int b_org[BK_];
 #pragma unroll
@@ -1259,6 +1272,7 @@ __global__ __launch_bounds__(512) void conv_gemm_pt_kernel(const GemmParams p) {
   const int ch_begin = (int)((long long)ch_total * split / p.splits);
   const int nch = (int)((long long)ch_total * (split + 1) / p.splits) - ch_begin;
 
+  DIAG_STAMP(7);
   // fragment addresses: stage and ring-slot offsets are immediates; the shifted reads take per-lane tables (both k steps)
   const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
   const unsigned swz0 = (unsigned)((q ^ (r & 7)) << 4), swz1 = (unsigned)(((4 + q) ^ (r & 7)) << 4);

@@ -47,6 +47,9 @@ for cold in (0, 1):
     t = t[t[:, 0] != 0]
     segc = t[:, 8:14].astype(np.float64).mean(axis=0)
     nph = int(os.environ.get('NPH', '0'))
+    if t[:, 5].any():
+        ex = t[:, [0, 5, 6, 7, 1]].astype(np.float64) * 0.01
+        print('   setup split (us): block decode %.2f  piece tables %.2f  B rows + descriptors %.2f  fragment tables %.2f' % tuple(np.diff(ex, axis=1).mean(axis=0)))
     t = t[:, :5].astype(np.float64) * 0.01    # us
     t0 = t[:, 0].min()
     seg = np.diff(t, axis=1)
