@@ -25,6 +25,38 @@ def test_library_loads_and_exports_every_header_symbol():
     assert b'gfx950' in lib.gan_version()
 
 
+def test_planner_sends_the_256_row_launches_to_the_tap_shared_kernels():
+    """Host-side planning only (no GPU): which main loop a convolution launch takes (gan_conv_tap_shared, include/gan_amd.h) at the
+    BASELINE shapes of Pix2Pix batch 16 - 2 for the stride-2 shapes and the parity sub-GEMMs, 4 for stride 1, 0 for fp32, for the small
+    tiles of the inner layers and when the option is off - and that the planner option round-trips."""
+    import ctypes as C
+    from gan_amd import _lib as L
+    lib = L.load()
+
+    def T(n, h, c):
+        return L.GanTensor(16, n, h, h, c, c)
+
+    def shared(op, dt, x, y, w_rows, stride):
+        d = L.GanConvDesc(dt, stride, x, y, 16, w_rows, None, 0, 0.3, 0, 16, 1 << 40)
+        return lib.gan_conv_tap_shared(C.byref(d), op)
+
+    BF16, F32 = 1, 0
+    assert L.get_option('conv.tap_share') == 7
+    assert shared(0, BF16, T(16, 128, 64), T(16, 64, 128), 128, 2) == 2       # G.down1 forward: conv s2, 256x128 tiles
+    assert shared(3, BF16, T(16, 64, 128), T(16, 32, 512), 512, 2) == 2       # G.up5 dgrad: = stride-2 convolution over dy
+    assert shared(2, BF16, T(16, 32, 512), T(16, 64, 128), 128, 2) == 2       # G.up5 forward: transposed conv, parity sub-GEMMs
+    assert shared(0, BF16, T(32, 32, 256), T(32, 31, 512), 512, 1) == 4       # D conv4 forward: stride 1, four taps per staged tile
+    assert shared(1, BF16, T(32, 31, 512), T(32, 32, 256), 256, 1) == 4       # ... and its dgrad
+    assert shared(0, F32, T(16, 128, 64), T(16, 64, 128), 128, 2) == 0        # fp32 stays on the one-tap-per-tile kernel
+    assert shared(0, BF16, T(16, 8, 512), T(16, 4, 512), 512, 2) == 0         # inner layer: small tiles
+    old = L.set_option('conv.tap_share', 0)
+    try:
+        assert old == 7 and shared(0, BF16, T(16, 128, 64), T(16, 64, 128), 128, 2) == 0
+    finally:
+        L.set_option('conv.tap_share', old)
+    assert shared(0, BF16, T(16, 128, 64), T(16, 64, 128), 128, 2) == 2
+
+
 def test_product_path_has_no_cpu_fallback_and_never_imports_oracle():
     for dirpath, _, files in os.walk(os.path.join(ROOT, 'gan_amd')):
         for f in files:
