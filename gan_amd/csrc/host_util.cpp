@@ -27,7 +27,7 @@ Opt g_opts[] = {
     {"conv.big_tiles", {1}},        // 256-row tiles for layers with >= 128 output channels
     {"conv.q128", {55}},            // relative quality (percent) of the 128x128 tile in the tile choice
     {"conv.q256n", {80}},           //   ... of the 256x128 tile (256x256 = 100)
-    {"conv.big_min_blocks", {128}}, // a 256-row tile needs at least this many blocks
+    {"conv.big_min_blocks", {64}},  // a 256-row tile needs at least this many blocks (128 until the table-driven kernels: +0.5 % on the step)
     {"conv.tall64", {1}},           // 256x64 tiles for 64-channel outputs on big maps
     {"conv.lean_epilogue", {1}},    // ping-pong launches without a fused backward epilogue use the instantiation compiled without it (fewer registers)
     {"conv.tap_share", {7}},        // tap-shared ping-pong kernel: bit 0 on the 256x128 tiles, bit 1 on the 256x256 tiles, bit 2 the table-driven form (256x128)

@@ -388,7 +388,7 @@ const char* gan_version(void);
 /* ---- planner options -------------------------------------------------------------------------- */
 /* The launch planners' tunable constants.  The library reads NO environment variable: these calls are the only way to
  * change them, and a change applies to the entry-point calls that follow it (each call plans for itself).  Unknown key:
- * GAN_E_ARG.  Keys (default): conv.big_tiles (1), conv.q128 (55), conv.q256n (80), conv.big_min_blocks (128),
+ * GAN_E_ARG.  Keys (default): conv.big_tiles (1), conv.q128 (55), conv.q256n (80), conv.big_min_blocks (64),
  * conv.tall64 (1), conv.pingpong (1), conv.lean_epilogue (1), conv.tap_share (7: bit 0 = 256x128 tiles, bit 1 = 256x256 tiles on the tap-shared kernel, bit 2 = its table-driven form on the 256x128 tiles), conv.parity_patch (1), conv.parity_patch_max_n (64),
  * conv.parity_patch_min_blocks (192), conv.split_target (256), conv.split_target_skinny (1024),
  * conv.split_target_big (256), conv.split_min_ktiles (4), conv.split_max (64), conv.bwd_fuse_tile (1: the fused backward
