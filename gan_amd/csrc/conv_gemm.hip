@@ -2063,7 +2063,7 @@ static int plan_gemm(const GanConvDesc* d, int op, GemmPlan* pl) {
   const int t_small = gan_opt("conv.split_target"), t_skinny = gan_opt("conv.split_target_skinny"), t_big = gan_opt("conv.split_target_big");
   // 256-row tiles: a half-full chip (128..160 blocks) is worth a 2-way K split only when K is long enough
   // to amortise the fp32 slab round trip (measured: K>=4096 +25..40 %, K=2048 neutral)
-  const long long target = BM == 256 ? (p.kchunks >= 48 && blocks <= 160 ? t_big : 128) : (BN == 16 ? t_skinny : t_small);   // BN=16: streaming layers want more, shorter blocks
+  const long long target = BM == 256 ? (p.kchunks >= 48 && blocks <= 160 ? t_big : gan_opt("conv.split_target_256")) : (BN == 16 ? t_skinny : t_small);   // BN=16: streaming layers want more, shorter blocks
   if (blocks < target && !pl->par_npw) {
     splits = (int)((target + blocks - 1) / blocks);
     const int mink = gan_opt("conv.split_min_ktiles"), maxsp = gan_opt("conv.split_max");

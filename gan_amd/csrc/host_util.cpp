@@ -38,6 +38,7 @@ Opt g_opts[] = {
     {"conv.split_target", {256}},   // split K until this many blocks (128-row tiles and smaller; 512 before the slab-reduce kernels took over the normalisation)
     {"conv.split_target_skinny", {1024}},
     {"conv.split_target_big", {256}},
+    {"conv.split_target_256", {128}},   // 256-row tiles with a short reduction: split K until this many blocks
     {"conv.split_min_ktiles", {4}},
     {"conv.split_max", {64}},
     {"conv.bwd_fuse_tile", {1}},    // fused backward epilogue on tile epilogues: 0 never, 1 always (fastest step: round 3 measured +0.5 % / +1 %), 2 not on 64-column tiles, 3 only on them

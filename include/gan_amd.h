@@ -391,7 +391,7 @@ const char* gan_version(void);
  * GAN_E_ARG.  Keys (default): conv.big_tiles (1), conv.q128 (55), conv.q256n (80), conv.big_min_blocks (64),
  * conv.tall64 (1), conv.pingpong (1), conv.lean_epilogue (1), conv.tap_share (7: bit 0 = 256x128 tiles, bit 1 = 256x256 tiles on the tap-shared kernel, bit 2 = its table-driven form on the 256x128 tiles), conv.parity_patch (1), conv.parity_patch_max_n (64),
  * conv.parity_patch_min_blocks (192), conv.split_target (256), conv.split_target_skinny (1024),
- * conv.split_target_big (256), conv.split_min_ktiles (4), conv.split_max (64), conv.bwd_fuse_tile (1: the fused backward
+ * conv.split_target_big (256), conv.split_target_256 (128), conv.split_min_ktiles (4), conv.split_max (64), conv.bwd_fuse_tile (1: the fused backward
  * epilogue rides on every tile epilogue; 0 never, 2 not on 64-column tiles, 3 on 64-column tiles only), conv.thin (7: bit 0
  * streaming kernels for the <= 8-channel layers, bit 1 thin-N, bit 2 thin-K), conv.norm_fuse (1), conv.stack (0: the callers in gan_amd/ merge eligible runs into layer stacks only when set), conv.stack_blocks (256), conv.thin_fused (1), wgrad.tile256 (0), wgrad.pingpong (1), wgrad.row_table (1),
  * wgrad.pingpong_min_rows (0 = automatic), wgrad.pingpong_128 (1), wgrad.pingpong_min_gflop (30),
