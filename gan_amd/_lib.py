@@ -147,6 +147,7 @@ SYMBOLS = {
     "gan_version": (C.c_char_p, []),
     "gan_set_option": (C.c_int, [C.c_char_p, C.c_int32]),
     "gan_get_option": (C.c_int, [C.c_char_p, C.POINTER(C.c_int32)]),
+    "gan_launch_log": (C.c_size_t, [C.c_char_p, C.c_size_t]),
 }
 
 _lib = None
@@ -187,6 +188,15 @@ def get_option(key):
     v = C.c_int32()
     check(lib.gan_get_option(key.encode(), C.byref(v)), f"gan_get_option({key})")
     return v.value
+
+
+def launch_log():
+    """Kernel symbols (mangled) of every launch recorded since set_option('diag.launch_log', 1), in enqueue order."""
+    lib = load()
+    need = lib.gan_launch_log(None, 0)
+    buf = C.create_string_buffer(need)
+    lib.gan_launch_log(buf, need)
+    return [ln for ln in buf.value.decode().split('\n') if ln]
 
 
 def check(rc, what):

@@ -17,6 +17,16 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
     if (e__ != hipSuccess) return (int)e__;                  \
   } while (0)
 
+// Every kernel launch of the library goes through this macro: the diagnostic launch log (host_util.cpp, option diag.launch_log)
+// notes the kernel's host stub, then the launch proceeds as hipLaunchKernelGGL.
+void gan_launch_note(const void* kernel_host_fn);
+size_t gan_launch_log_ptrs(const void** out, size_t cap);
+#define GAN_LAUNCH(kern, ...)                       \
+  do {                                              \
+    gan_launch_note((const void*)(kern));           \
+    hipLaunchKernelGGL(kern, __VA_ARGS__);          \
+  } while (0)
+
 __device__ __forceinline__ float bf2f(bf16_t v) { return (float)v; }
 __device__ __forceinline__ float ld_f(const float* p) { return *p; }
 __device__ __forceinline__ float ld_f(const bf16_t* p) { return (float)*p; }

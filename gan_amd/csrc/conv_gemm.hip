@@ -2203,7 +2203,7 @@ static int launch_cfg(const GemmPlan& pl, hipStream_t st) {
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, pl.grid, dim3(64 * WM * WN), smem, st, pl.p);
+  GAN_LAUNCH(kern, pl.grid, dim3(64 * WM * WN), smem, st, pl.p);
   GAN_CHECK_LAUNCH();
   return 0;
 }
@@ -2218,7 +2218,7 @@ static int launch_pp_v(const GemmPlan& pl, hipStream_t st) {
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, pl.grid, dim3(512), smem, st, pl.p);
+  GAN_LAUNCH(kern, pl.grid, dim3(512), smem, st, pl.p);
   GAN_CHECK_LAUNCH();
   return 0;
 }
@@ -2239,7 +2239,7 @@ static int launch_pt_v(const GemmPlan& pl, hipStream_t st) {
       if (e != hipSuccess) return (int)e;
       attr_set = true;
     }
-    hipLaunchKernelGGL(kern, pl.grid, dim3(512), smem, st, pl.p);
+    GAN_LAUNCH(kern, pl.grid, dim3(512), smem, st, pl.p);
     GAN_CHECK_LAUNCH();
     return 0;
   } else {
@@ -2257,7 +2257,7 @@ static int launch_ps_v(const GemmPlan& pl, hipStream_t st) {
       if (e != hipSuccess) return (int)e;
       attr_set = true;
     }
-    hipLaunchKernelGGL(kern, pl.grid, dim3(512), smem, st, pl.p);
+    GAN_LAUNCH(kern, pl.grid, dim3(512), smem, st, pl.p);
     GAN_CHECK_LAUNCH();
     return 0;
   } else {
@@ -2292,7 +2292,7 @@ static int launch_par(const GemmPlan& pl, hipStream_t st) {
       if (e != hipSuccess) return (int)e;
       attr_set = true;
     }
-    hipLaunchKernelGGL(kern, pl.grid, dim3(512), smem, st, pl.p);
+    GAN_LAUNCH(kern, pl.grid, dim3(512), smem, st, pl.p);
     GAN_CHECK_LAUNCH();
     return 0;
   } else {
@@ -2335,16 +2335,16 @@ static int launch_gemm(const GemmPlan& pl, hipStream_t st) {
       const dim3 g((unsigned)(pl.p.Cout / 8), (unsigned)((pl.p.skn == 1 && !(pl.p.skn_mmean && pl.p.skn_groups > 1)) ? pl.p.skn_groups : 1));
       const long long rg = (long long)pl.P * (pl.p.M / pl.p.skn_groups);
       const int kr = rg <= 128 ? 1 : rg <= 256 ? 2 : rg <= 512 ? 4 : 8;
-#define SKN_LAUNCH(MODE, KRV) hipLaunchKernelGGL((splitk_norm_kernel<T, MODE, KRV>), g, dim3(256), 0, st, pl.p, pl.P)
+#define SKN_LAUNCH(MODE, KRV) GAN_LAUNCH((splitk_norm_kernel<T, MODE, KRV>), g, dim3(256), 0, st, pl.p, pl.P)
       if (pl.p.skn == 1) { if (kr == 1) SKN_LAUNCH(1, 1); else if (kr == 2) SKN_LAUNCH(1, 2); else if (kr == 4) SKN_LAUNCH(1, 4); else SKN_LAUNCH(1, 8); }
       else { if (kr == 1) SKN_LAUNCH(2, 1); else if (kr == 2) SKN_LAUNCH(2, 2); else if (kr == 4) SKN_LAUNCH(2, 4); else SKN_LAUNCH(2, 8); }
 #undef SKN_LAUNCH
     } else if (pl.p.vec_store && pl.p.Cout % 4 == 0 && (pl.p.out_f32 || sizeof(T) == 2)) {
       long long total = (long long)pl.P * pl.p.M * (pl.p.Cout / 4);
-      hipLaunchKernelGGL(splitk_reduce4_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, pl.p, pl.P);
+      GAN_LAUNCH(splitk_reduce4_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, pl.p, pl.P);
     } else {
       long long total = (long long)pl.P * pl.p.M * pl.p.Cout;
-      hipLaunchKernelGGL(splitk_reduce_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, pl.p, pl.P);
+      GAN_LAUNCH(splitk_reduce_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, pl.p, pl.P);
     }
     GAN_CHECK_LAUNCH();
   }
@@ -2434,7 +2434,7 @@ static int launch_stack(const StackHeader* h, const void* dev_plan, void* bar, i
     if (e != hipSuccess) return (int)e;
     attr_smem = h->smem;
   }
-  hipLaunchKernelGGL(kern, dim3(h->grid), dim3(256), h->smem, st, (const StackLayer*)((const char*)dev_plan + 256), (int)h->n, (StackBar*)bar, (int*)err);
+  GAN_LAUNCH(kern, dim3(h->grid), dim3(256), h->smem, st, (const StackLayer*)((const char*)dev_plan + 256), (int)h->n, (StackBar*)bar, (int*)err);
   GAN_CHECK_LAUNCH();
   return 0;
 }

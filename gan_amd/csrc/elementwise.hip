@@ -447,13 +447,13 @@ int gan_bce_logits(const float* x, int64_t count, float target, float loss_scale
   if (blocks > 1024) blocks = 1024;
   int rc = with_dtype(dtype, [&](auto* tag) {
     typedef GAN_TAG_T(tag) T;
-    hipLaunchKernelGGL(bce_kernel<T>, dim3(blocks), dim3(256), 0, st, x, (long long)count, target, grad_scale, (T*)dx, dx_pitch,
+    GAN_LAUNCH(bce_kernel<T>, dim3(blocks), dim3(256), 0, st, x, (long long)count, target, grad_scale, (T*)dx, dx_pitch,
                        workspace, scale_state);
     GAN_CHECK_LAUNCH();
     return 0;
   });
   if (rc) return rc;
-  hipLaunchKernelGGL(l1_finalize_kernel, dim3(1), dim3(256), 0, st, (const float*)workspace, blocks, 1.0 / (double)count,
+  GAN_LAUNCH(l1_finalize_kernel, dim3(1), dim3(256), 0, st, (const float*)workspace, blocks, 1.0 / (double)count,
                      loss_scale, loss_accumulate, loss_out);
   GAN_CHECK_LAUNCH();
   return 0;
@@ -468,13 +468,13 @@ int gan_patchgan_losses(const float* real_logits, const float* fake_logits, int6
   if (blocks > 256) blocks = 256;
   int rc = with_dtype(dtype, [&](auto* tag) {
     typedef GAN_TAG_T(tag) T;
-    hipLaunchKernelGGL(patchgan_bce_kernel<T>, dim3(blocks), dim3(256), 0, st, real_logits, fake_logits, (long long)count,
+    GAN_LAUNCH(patchgan_bce_kernel<T>, dim3(blocks), dim3(256), 0, st, real_logits, fake_logits, (long long)count,
                        (T*)g_dfake, (T*)d_dreal, (T*)d_dfake, pitch, workspace, scale_state);
     GAN_CHECK_LAUNCH();
     return 0;
   });
   if (rc) return rc;
-  hipLaunchKernelGGL(patchgan_finalize_kernel, dim3(1), dim3(64), 0, st, (const float*)workspace, blocks, 1.0 / (double)count, lambda,
+  GAN_LAUNCH(patchgan_finalize_kernel, dim3(1), dim3(64), 0, st, (const float*)workspace, blocks, 1.0 / (double)count, lambda,
                      l1, gen_total, gan_loss, disc_loss);
   GAN_CHECK_LAUNCH();
   return 0;
@@ -493,13 +493,13 @@ int gan_l1(int32_t dtype, const GanTensor* a, const GanTensor* b, float loss_sca
   hipStream_t st = (hipStream_t)stream;
   int rc = with_dtype(dtype, [&](auto* tag) {
     typedef GAN_TAG_T(tag) T;
-    hipLaunchKernelGGL(l1_kernel<T>, dim3(blocks), dim3(256), 0, st, (const T*)a->ptr, a->pitch, (const T*)b->ptr, b->pitch, a->c,
+    GAN_LAUNCH(l1_kernel<T>, dim3(blocks), dim3(256), 0, st, (const T*)a->ptr, a->pitch, (const T*)b->ptr, b->pitch, a->c,
                        pixels, gs, da ? (T*)da->ptr : nullptr, da ? da->pitch : 0, workspace, scale_state);
     GAN_CHECK_LAUNCH();
     return 0;
   });
   if (rc) return rc;
-  hipLaunchKernelGGL(l1_finalize_kernel, dim3(1), dim3(256), 0, st, (const float*)workspace, blocks, 1.0 / (double)total,
+  GAN_LAUNCH(l1_finalize_kernel, dim3(1), dim3(256), 0, st, (const float*)workspace, blocks, 1.0 / (double)total,
                      loss_scale, loss_accumulate, loss_out);
   GAN_CHECK_LAUNCH();
   return 0;
@@ -507,7 +507,7 @@ int gan_l1(int32_t dtype, const GanTensor* a, const GanTensor* b, float loss_sca
 
 int gan_adam_begin(int32_t* step, float* lr_t, float lr, float beta1, float beta2, const float* scale_state, gan_stream_t stream) {
   if (!step || !lr_t) return GAN_E_ARG;
-  hipLaunchKernelGGL(adam_begin_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step, lr_t, lr, beta1, beta2, scale_state);
+  GAN_LAUNCH(adam_begin_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step, lr_t, lr, beta1, beta2, scale_state);
   GAN_CHECK_LAUNCH();
   return 0;
 }
@@ -520,10 +520,10 @@ int gan_adam_tf(float* param, float* m, float* v, const void* grad, int64_t coun
   long long blocks = (nvec + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   if (grad_bf16)
-    hipLaunchKernelGGL(adam_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (float4*)param, (float4*)m,
+    GAN_LAUNCH(adam_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (float4*)param, (float4*)m,
                        (float4*)v, grad, nvec, lr_t, 1.f - beta1, 1.f - beta2, eps, grad_scale, scale_state);
   else
-    hipLaunchKernelGGL(adam_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (float4*)param, (float4*)m,
+    GAN_LAUNCH(adam_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (float4*)param, (float4*)m,
                        (float4*)v, grad, nvec, lr_t, 1.f - beta1, 1.f - beta2, eps, grad_scale, scale_state);
   GAN_CHECK_LAUNCH();
   return 0;
@@ -534,14 +534,14 @@ int gan_grads_check(const float* grad, int64_t count, float* scale_state, gan_st
   const long long nvec = count / 4;
   long long blocks = (nvec + 255) / 256;
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(grads_check_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const uint4*)grad, nvec, scale_state);
+  GAN_LAUNCH(grads_check_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const uint4*)grad, nvec, scale_state);
   GAN_CHECK_LAUNCH();
   return 0;
 }
 
 int gan_loss_scale_update(float* scale_state, int32_t growth_interval, float max_scale, gan_stream_t stream) {
   if (!scale_state || growth_interval <= 0 || !(max_scale >= 1.f)) return GAN_E_ARG;
-  hipLaunchKernelGGL(loss_scale_update_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, scale_state, growth_interval, max_scale);
+  GAN_LAUNCH(loss_scale_update_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, scale_state, growth_interval, max_scale);
   GAN_CHECK_LAUNCH();
   return 0;
 }
@@ -554,7 +554,7 @@ int gan_weights_prepare(const float* master, int32_t A, int32_t B, int32_t dtype
   hipStream_t st = (hipStream_t)stream;
   return with_dtype(dtype, [&](auto* tag) {
     typedef GAN_TAG_T(tag) T;
-    hipLaunchKernelGGL(wprep_kernel<T>, grid, dim3(256), 0, st, master, A, B, (T*)nk_native, (T*)nk_transposed);
+    GAN_LAUNCH(wprep_kernel<T>, grid, dim3(256), 0, st, master, A, B, (T*)nk_native, (T*)nk_transposed);
     GAN_CHECK_LAUNCH();
     return 0;
   });
@@ -565,7 +565,7 @@ int gan_weights_prepare_multi(const void* entries_dev, int32_t n, int32_t total_
   hipStream_t st = (hipStream_t)stream;
   return with_dtype(dtype, [&](auto* tag) {
     typedef GAN_TAG_T(tag) T;
-    hipLaunchKernelGGL(wprep_multi_kernel<T>, dim3((unsigned)total_tiles), dim3(256), 0, st, (const PrepEntry*)entries_dev, n);
+    GAN_LAUNCH(wprep_multi_kernel<T>, dim3((unsigned)total_tiles), dim3(256), 0, st, (const PrepEntry*)entries_dev, n);
     GAN_CHECK_LAUNCH();
     return 0;
   });
@@ -581,10 +581,10 @@ int gan_adam_prepare_multi(const void* entries_dev, int32_t n, int32_t total_til
   return with_dtype(dtype, [&](auto* tag) {
     typedef GAN_TAG_T(tag) T;
     if (grad_bf16)
-      hipLaunchKernelGGL((adam_prep_multi_kernel<T, true>), dim3((unsigned)total_tiles), dim3(256), 0, st, (const PrepEntry*)entries_dev, n, ab,
+      GAN_LAUNCH((adam_prep_multi_kernel<T, true>), dim3((unsigned)total_tiles), dim3(256), 0, st, (const PrepEntry*)entries_dev, n, ab,
                          lr_t, 1.f - beta1, 1.f - beta2, eps, grad_scale, scale_state);
     else
-      hipLaunchKernelGGL((adam_prep_multi_kernel<T, false>), dim3((unsigned)total_tiles), dim3(256), 0, st, (const PrepEntry*)entries_dev, n, ab,
+      GAN_LAUNCH((adam_prep_multi_kernel<T, false>), dim3((unsigned)total_tiles), dim3(256), 0, st, (const PrepEntry*)entries_dev, n, ab,
                          lr_t, 1.f - beta1, 1.f - beta2, eps, grad_scale, scale_state);
     GAN_CHECK_LAUNCH();
     return 0;
@@ -594,7 +594,7 @@ int gan_adam_prepare_multi(const void* entries_dev, int32_t n, int32_t total_til
 int gan_dropout_mask(uint8_t* mask, int64_t count, uint64_t seed, const int32_t* step, uint32_t stream_id, gan_stream_t stream) {
   if (!mask || count <= 0 || !step) return GAN_E_ARG;
   long long words = (count + 7) / 8;
-  hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, (hipStream_t)stream, mask,
+  GAN_LAUNCH(dropout_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, (hipStream_t)stream, mask,
                      (long long)count, seed, step, stream_id);
   GAN_CHECK_LAUNCH();
   return 0;
@@ -606,7 +606,7 @@ int gan_pack(int32_t dtype, const float* src, const GanTensor* dst, gan_stream_t
   dim3 grid((unsigned)((total + 255) / 256));
   return with_dtype(dtype, [&](auto* tag) {
     typedef GAN_TAG_T(tag) T;
-    hipLaunchKernelGGL(pack_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, src, (T*)dst->ptr, dst->c, dst->pitch, total);
+    GAN_LAUNCH(pack_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, src, (T*)dst->ptr, dst->c, dst->pitch, total);
     GAN_CHECK_LAUNCH();
     return 0;
   });
@@ -626,7 +626,7 @@ int gan_pack_multi(int32_t dtype, int32_t n, const float* const* srcs, const Gan
   dim3 grid((unsigned)((total + 2047) / 2048), (unsigned)n);
   return with_dtype(dtype, [&](auto* tag) {
     typedef GAN_TAG_T(tag) T;
-    hipLaunchKernelGGL(pack_multi_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, pm, dsts[0].c, total);
+    GAN_LAUNCH(pack_multi_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, pm, dsts[0].c, total);
     GAN_CHECK_LAUNCH();
     return 0;
   });
@@ -643,7 +643,7 @@ int gan_dropout_mask_multi(int32_t n, uint8_t* const* masks, const int64_t* coun
     const long long w = (counts[k] + 7) / 8;
     if (w > maxw) maxw = w;
   }
-  hipLaunchKernelGGL(dropout_multi_kernel, dim3((unsigned)((maxw + 2047) / 2048), (unsigned)n), dim3(256), 0, (hipStream_t)stream, dm,
+  GAN_LAUNCH(dropout_multi_kernel, dim3((unsigned)((maxw + 2047) / 2048), (unsigned)n), dim3(256), 0, (hipStream_t)stream, dm,
                      seed, step, draws);
   GAN_CHECK_LAUNCH();
   return 0;
@@ -655,7 +655,7 @@ int gan_unpack(int32_t dtype, const GanTensor* src, float* dst, gan_stream_t str
   dim3 grid((unsigned)((total + 255) / 256));
   return with_dtype(dtype, [&](auto* tag) {
     typedef GAN_TAG_T(tag) T;
-    hipLaunchKernelGGL(unpack_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)src->ptr, dst, src->c, src->pitch, total);
+    GAN_LAUNCH(unpack_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)src->ptr, dst, src->c, src->pitch, total);
     GAN_CHECK_LAUNCH();
     return 0;
   });
@@ -668,7 +668,7 @@ int gan_copy_view(int32_t dtype, const GanTensor* src, const GanTensor* dst, gan
   dim3 grid((unsigned)((total + 255) / 256));
   return with_dtype(dtype, [&](auto* tag) {
     typedef GAN_TAG_T(tag) T;
-    hipLaunchKernelGGL(copy_view_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)src->ptr, src->pitch, (T*)dst->ptr,
+    GAN_LAUNCH(copy_view_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)src->ptr, src->pitch, (T*)dst->ptr,
                        dst->pitch, src->c, total);
     GAN_CHECK_LAUNCH();
     return 0;
@@ -677,7 +677,7 @@ int gan_copy_view(int32_t dtype, const GanTensor* src, const GanTensor* dst, gan
 
 int gan_sum3(const float* a, const float* b, const float* c, float* out, int32_t n, gan_stream_t stream) {
   if (!a || !b || !c || !out || n <= 0 || n > 64) return GAN_E_ARG;
-  hipLaunchKernelGGL(sum3_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a, b, c, out, n);
+  GAN_LAUNCH(sum3_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a, b, c, out, n);
   GAN_CHECK_LAUNCH();
   return 0;
 }
@@ -685,7 +685,7 @@ int gan_grad_pack(const float* src, void* dst_bf16, int64_t count, gan_stream_t 
   if (!src || !dst_bf16 || count <= 0 || count % 8 || (((uintptr_t)src | (uintptr_t)dst_bf16) & 15)) return GAN_E_ARG;
   const long long n8 = count / 8;
   const unsigned grid = (unsigned)((n8 + 255) / 256 < 4096 ? (n8 + 255) / 256 : 4096);
-  hipLaunchKernelGGL(grad_pack_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float4*)src, (uint4*)dst_bf16, n8);
+  GAN_LAUNCH(grad_pack_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float4*)src, (uint4*)dst_bf16, n8);
   GAN_CHECK_LAUNCH();
   return 0;
 }
@@ -693,9 +693,30 @@ int gan_grad_unpack(const void* src_bf16, float* dst, int64_t count, float scale
   if (!src_bf16 || !dst || count <= 0 || count % 8 || (((uintptr_t)src_bf16 | (uintptr_t)dst) & 15)) return GAN_E_ARG;
   const long long n8 = count / 8;
   const unsigned grid = (unsigned)((n8 + 255) / 256 < 4096 ? (n8 + 255) / 256 : 4096);
-  hipLaunchKernelGGL(grad_unpack_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint4*)src_bf16, (float4*)dst, n8, scale);
+  GAN_LAUNCH(grad_unpack_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint4*)src_bf16, (float4*)dst, n8, scale);
   GAN_CHECK_LAUNCH();
   return 0;
 }
 const char* gan_version(void) { return "gan_amd 0.2 (gfx950)"; }
+}
+
+// ---- diagnostic launch log: names of the recorded launches (include/gan_amd.h) ---------------------------------------------
+#include <cstring>
+#include <string>
+#include <vector>
+extern "C" size_t gan_launch_log(char* buf, size_t cap) {
+  std::vector<const void*> ptrs(gan_launch_log_ptrs(nullptr, 0));
+  gan_launch_log_ptrs(ptrs.data(), ptrs.size());
+  std::string all;
+  for (const void* f : ptrs) {
+    const char* nm = hipKernelNameRefByPtr(f, nullptr);
+    all += nm ? nm : "?";
+    all += '\n';
+  }
+  if (buf && cap) {
+    const size_t n = all.size() < cap - 1 ? all.size() : cap - 1;
+    std::memcpy(buf, all.data(), n);
+    buf[n] = 0;
+  }
+  return all.size() + 1;
 }

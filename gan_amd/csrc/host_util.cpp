@@ -57,6 +57,7 @@ Opt g_opts[] = {
     {"wgrad.fold_split_target", {512}},    // tap-folded (8-channel) layers: blocks wanted (each writes a 32 KB slab tile; 1024 before round 4: 46 -> 40 us per step for the two launches, 256: 57)
     {"wgrad.reduce_adam_min_params", {1 << 20}},
     {"wgrad.reduce_adam", {1}},     // GanAdamFuse on split launches: the slab reduce ends in the optimiser step
+    {"diag.launch_log", {0}},       // record the kernel symbol of every launch (gan_launch_log; profiling tools)
 };
 Opt* find_opt(const char* key) {
   if (!key) return nullptr;
@@ -70,10 +71,34 @@ int gan_opt(const char* key) {              // internal: a key the table does no
   Opt* o = find_opt(key);
   return o ? o->value.load(std::memory_order_relaxed) : 0;
 }
+// ---- diagnostic launch log (include/gan_amd.h: gan_launch_log) ---------------------------------------------------------
+#include <mutex>
+#include <vector>
+namespace {
+std::atomic<int> g_log_on{0};
+std::mutex g_log_mu;
+std::vector<const void*> g_log;
+}  // namespace
+void gan_launch_note(const void* kernel_host_fn) {       // every launch site (GAN_LAUNCH, common.h)
+  if (!g_log_on.load(std::memory_order_relaxed)) return;
+  std::lock_guard<std::mutex> lk(g_log_mu);
+  g_log.push_back(kernel_host_fn);
+}
+size_t gan_launch_log_ptrs(const void** out, size_t cap) {     // elementwise.hip resolves the names (needs the HIP runtime)
+  std::lock_guard<std::mutex> lk(g_log_mu);
+  for (size_t i = 0; i < g_log.size() && i < cap; ++i) out[i] = g_log[i];
+  return g_log.size();
+}
+
 extern "C" int gan_set_option(const char* key, int32_t value) {
   Opt* o = find_opt(key);
   if (!o) return GAN_E_ARG;
   o->value.store(value, std::memory_order_relaxed);
+  if (!strcmp(key, "diag.launch_log")) {
+    std::lock_guard<std::mutex> lk(g_log_mu);
+    if (value) g_log.clear();
+    g_log_on.store(value ? 1 : 0, std::memory_order_relaxed);
+  }
   return 0;
 }
 extern "C" int gan_get_option(const char* key, int32_t* value) {

@@ -387,7 +387,7 @@ static size_t red_ws_bytes(int groups, int chunks, int c) {
 template <typename T, int MODE, int ACT = GAN_ACT_NONE, bool MASK = false>
 static int launch_partial(const NormP& p, const RedGeom& g, int groups, float* partial, hipStream_t st) {
   size_t lds = (size_t)g.rslots * g.C * 2 * sizeof(float);
-  hipLaunchKernelGGL((reduce_partial_kernel<T, MODE, ACT, MASK>), dim3(g.chunks, groups), dim3(256), lds, st, p, g, partial);
+  GAN_LAUNCH((reduce_partial_kernel<T, MODE, ACT, MASK>), dim3(g.chunks, groups), dim3(256), lds, st, p, g, partial);
   GAN_CHECK_LAUNCH();
   return 0;
 }
@@ -395,7 +395,7 @@ static int launch_partial(const NormP& p, const RedGeom& g, int groups, float* p
 template <typename K>
 static int launch_rows(K kern, const NormP& p, const RedGeom& g, long long rows, hipStream_t st) {
   long long threads = (rows + 3) / 4 * g.cvecs;
-  hipLaunchKernelGGL(kern, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, p, g, rows);
+  GAN_LAUNCH(kern, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, p, g, rows);
   GAN_CHECK_LAUNCH();
   return 0;
 }
@@ -462,7 +462,7 @@ int gan_norm_stats(const GanNormDesc* d, gan_stream_t stream) {
        : d->dtype == GAN_F16 ? launch_partial<f16_t, 0>(p, g, d->groups, partial, st)
                              : launch_partial<bf16_t, 0>(p, g, d->groups, partial, st);
   if (rc) return rc;
-  hipLaunchKernelGGL(stats_finalize_kernel, dim3((g.C + FC - 1) / FC, d->moving_mean ? 1 : d->groups), dim3(256), 0, st,
+  GAN_LAUNCH(stats_finalize_kernel, dim3((g.C + FC - 1) / FC, d->moving_mean ? 1 : d->groups), dim3(256), 0, st,
                      (const float*)partial, d->groups, g.chunks, g.C, g.rows_per_group, d->eps, d->mean, d->rstd,
                      d->moving_mean, d->moving_var, d->momentum);
   GAN_CHECK_LAUNCH();
@@ -475,7 +475,7 @@ int gan_norm_stats_finalize(const GanNormDesc* d, int32_t chunks, gan_stream_t s
   int rc = red_geom(d->y, d->groups, d->dtype, &g);
   if (rc) return rc;
   if ((size_t)d->groups * chunks * g.C * 2 * sizeof(float) > d->workspace_bytes) return GAN_E_WORKSPACE;   // the producer's partials
-  hipLaunchKernelGGL(stats_finalize_kernel, dim3((g.C + FC - 1) / FC, d->moving_mean ? 1 : d->groups), dim3(256), 0, (hipStream_t)stream,
+  GAN_LAUNCH(stats_finalize_kernel, dim3((g.C + FC - 1) / FC, d->moving_mean ? 1 : d->groups), dim3(256), 0, (hipStream_t)stream,
                      (const float*)d->workspace, d->groups, chunks, g.C, g.rows_per_group, d->eps, d->mean, d->rstd,
                      d->moving_mean, d->moving_var, d->momentum);
   GAN_CHECK_LAUNCH();
@@ -519,7 +519,7 @@ int gan_norm_act_bwd(const GanNormBwdDesc* d, gan_stream_t stream) {
        : d->dtype == GAN_F16 ? launch_bwd_partial<f16_t>(p, g, d->groups, partial, st)
                              : launch_bwd_partial<bf16_t>(p, g, d->groups, partial, st);
   if (rc) return rc;
-  hipLaunchKernelGGL(bwd_finalize_kernel, dim3((g.C + FC - 1) / FC), dim3(256), 0, st, (const float*)partial, d->groups,
+  GAN_LAUNCH(bwd_finalize_kernel, dim3((g.C + FC - 1) / FC), dim3(256), 0, st, (const float*)partial, d->groups,
                      g.chunks, g.C, sums, d->dgamma, d->dbeta, d->accumulate);
   GAN_CHECK_LAUNCH();
   long long rows = (long long)d->y.n * g.hw;
@@ -546,7 +546,7 @@ int gan_norm_act_bwd_fused(const GanNormBwdDesc* d, int32_t chunks, gan_stream_t
   float* sums = partial + (size_t)d->groups * chunks * g.C * 2;
   p.sums = sums;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(bwd_finalize_kernel, dim3((g.C + FC - 1) / FC), dim3(256), 0, st, (const float*)partial, d->groups,
+  GAN_LAUNCH(bwd_finalize_kernel, dim3((g.C + FC - 1) / FC), dim3(256), 0, st, (const float*)partial, d->groups,
                      chunks, g.C, sums, d->dgamma, d->dbeta, d->accumulate);
   GAN_CHECK_LAUNCH();
   long long rows = (long long)d->y.n * g.hw;
@@ -566,7 +566,7 @@ static int bias_grad_impl(int32_t dtype, const GanTensor& dy, float* dbias, int3
   float* partial = (float*)workspace;
   rc = dtype == GAN_F32 ? launch_partial<float, 2>(q, g, 1, partial, st) : dtype == GAN_F16 ? launch_partial<f16_t, 2>(q, g, 1, partial, st) : launch_partial<bf16_t, 2>(q, g, 1, partial, st);
   if (rc) return rc;
-  hipLaunchKernelGGL(bwd_finalize_kernel, dim3((g.C + FC - 1) / FC), dim3(256), 0, st, (const float*)partial, 1, g.chunks, g.C,
+  GAN_LAUNCH(bwd_finalize_kernel, dim3((g.C + FC - 1) / FC), dim3(256), 0, st, (const float*)partial, 1, g.chunks, g.C,
                      (float*)nullptr, (float*)nullptr, dbias, accumulate);
   GAN_CHECK_LAUNCH();
   return 0;

@@ -313,8 +313,8 @@ int thin_launch(int family, const GanConvDesc* d, const GemmParams& p, hipStream
     int gx = (k.tiles + 3) / 4;
     const int cap = 2048 / groups > 256 ? 2048 / groups : 256;
     if (gx > cap) gx = cap;
-    if (d->dtype == GAN_F16) hipLaunchKernelGGL(conv_thin_k_kernel<f16_t>, dim3((unsigned)gx, (unsigned)groups), dim3(256), 0, st, k);
-    else hipLaunchKernelGGL(conv_thin_k_kernel<bf16_t>, dim3((unsigned)gx, (unsigned)groups), dim3(256), 0, st, k);
+    if (d->dtype == GAN_F16) GAN_LAUNCH(conv_thin_k_kernel<f16_t>, dim3((unsigned)gx, (unsigned)groups), dim3(256), 0, st, k);
+    else GAN_LAUNCH(conv_thin_k_kernel<bf16_t>, dim3((unsigned)gx, (unsigned)groups), dim3(256), 0, st, k);
     GAN_CHECK_LAUNCH();
     return 0;
   }
@@ -338,7 +338,7 @@ int thin_launch(int family, const GanConvDesc* d, const GemmParams& p, hipStream
         auto kern = conv_thin_n_fused_kernel<T, KSV, PAR, TH, TW>;                                                                    \
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                 \
         if (e != hipSuccess) return (int)e;                                                                                           \
-        hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, f);                                                                       \
+        GAN_LAUNCH(kern, grid, dim3(256), smem, st, f);                                                                       \
       }
       if (KS == 2) THIN_F(2) else if (KS == 4) THIN_F(4) else THIN_F(16)
 #undef THIN_F
@@ -360,9 +360,9 @@ int thin_launch(int family, const GanConvDesc* d, const GemmParams& p, hipStream
   const size_t smem = (size_t)n.CO * KS * 1024;
   auto launch_n = [&](auto* tag) {
     typedef typename std::remove_pointer<decltype(tag)>::type T;
-    if (KS == 2) hipLaunchKernelGGL((conv_thin_n_kernel<T, 2>), dim3((unsigned)gx), dim3(256), smem, st, n);
-    else if (KS == 4) hipLaunchKernelGGL((conv_thin_n_kernel<T, 4>), dim3((unsigned)gx), dim3(256), smem, st, n);
-    else hipLaunchKernelGGL((conv_thin_n_kernel<T, 16>), dim3((unsigned)gx), dim3(256), smem, st, n);
+    if (KS == 2) GAN_LAUNCH((conv_thin_n_kernel<T, 2>), dim3((unsigned)gx), dim3(256), smem, st, n);
+    else if (KS == 4) GAN_LAUNCH((conv_thin_n_kernel<T, 4>), dim3((unsigned)gx), dim3(256), smem, st, n);
+    else GAN_LAUNCH((conv_thin_n_kernel<T, 16>), dim3((unsigned)gx), dim3(256), smem, st, n);
   };
   if (d->dtype == GAN_F16) launch_n((f16_t*)nullptr); else launch_n((bf16_t*)nullptr);
   GAN_CHECK_LAUNCH();
@@ -373,7 +373,7 @@ int thin_launch(int family, const GanConvDesc* d, const GemmParams& p, hipStream
   c.act = p.act; c.parity = p.parity; c.S = p.S; c.dy0 = p.dy0; c.dstep = p.dstep; c.slope = p.slope;
   c.total = (long long)x.n * p.Ho * p.Wo;
   c.divWo = make_fastdiv((uint32_t)p.Wo); c.divHo = make_fastdiv((uint32_t)p.Ho);
-  hipLaunchKernelGGL(conv_thin_col2im_kernel, dim3((unsigned)((c.total + 255) / 256)), dim3(256), 0, st, c);
+  GAN_LAUNCH(conv_thin_col2im_kernel, dim3((unsigned)((c.total + 255) / 256)), dim3(256), 0, st, c);
   GAN_CHECK_LAUNCH();
   return 0;
 }

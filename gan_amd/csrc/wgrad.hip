@@ -516,7 +516,7 @@ static int launch_wcfg(const WgradPlan& pl, hipStream_t st) {
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, pl.grid, dim3(256), smem, st, pl.p);
+  GAN_LAUNCH(kern, pl.grid, dim3(256), smem, st, pl.p);
   GAN_CHECK_LAUNCH();
   return 0;
 }
@@ -809,7 +809,7 @@ static int launch_wdma(const WgradPlan& pl, unsigned bigbytes, unsigned smallbyt
     attr_set = true;
   }
   if (pl.p.adam && !(sizeof(T) == 2 && TA == 128 && TB == 128 && WA == 2 && WB == 2)) return GAN_E_SHAPE;   // only that epilogue carries GanAdamFuse
-  hipLaunchKernelGGL(kern, pl.grid, dim3(64 * WA * WB), smem, st, pl.p, bigbytes, smallbytes);
+  GAN_LAUNCH(kern, pl.grid, dim3(64 * WA * WB), smem, st, pl.p, bigbytes, smallbytes);
   GAN_CHECK_LAUNCH();
   return 0;
 }
@@ -1157,7 +1157,7 @@ static int launch_wpp_v(const WgradPlan& pl, unsigned bigbytes, unsigned smallby
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, pl.grid, dim3(512), smem, st, pl.p, bigbytes, smallbytes);
+  GAN_LAUNCH(kern, pl.grid, dim3(512), smem, st, pl.p, bigbytes, smallbytes);
   GAN_CHECK_LAUNCH();
   return 0;
 }
@@ -1209,17 +1209,17 @@ int gan_conv_wgrad(const GanWgradDesc* d, gan_stream_t stream) {
     const unsigned tiles = 16u * (unsigned)((q.CaReal + 63) / 64) * (unsigned)((q.CbReal + 63) / 64);
     const size_t per_split = (size_t)16 * q.CaReal * q.CbReal;
     if (d->dtype == GAN_F16)
-      hipLaunchKernelGGL(wgrad_reduce_adam_kernel<f16_t>, dim3(tiles), dim3(256), 0, st, (const float*)q.slab, per_split, q.splits, log2sg, q.CaReal,
+      GAN_LAUNCH(wgrad_reduce_adam_kernel<f16_t>, dim3(tiles), dim3(256), 0, st, (const float*)q.slab, per_split, q.splits, log2sg, q.CaReal,
                          q.CbReal, q.aw, q.am, q.av, (f16_t*)q.anat, (f16_t*)q.atr, q.alr, q.omb1, q.omb2, q.aeps);
     else
-      hipLaunchKernelGGL(wgrad_reduce_adam_kernel<bf16_t>, dim3(tiles), dim3(256), 0, st, (const float*)q.slab, per_split, q.splits, log2sg, q.CaReal,
+      GAN_LAUNCH(wgrad_reduce_adam_kernel<bf16_t>, dim3(tiles), dim3(256), 0, st, (const float*)q.slab, per_split, q.splits, log2sg, q.CaReal,
                          q.CbReal, q.aw, q.am, q.av, (bf16_t*)q.anat, (bf16_t*)q.atr, q.alr, q.omb1, q.omb2, q.aeps);
     GAN_CHECK_LAUNCH();
   } else if (pl.p.splits > 1) {
     const long long count4 = (long long)4 * pl.p.CaReal * pl.p.CbReal;     // 16 taps * Ca * Cb floats, as float4
     const int log2sg = wgrad_reduce_log2sg(count4, pl.p.splits);
     const int EV = 256 >> log2sg;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((count4 + EV - 1) / EV)), dim3(256), 0, st,
+    GAN_LAUNCH(wgrad_reduce_kernel, dim3((unsigned)((count4 + EV - 1) / EV)), dim3(256), 0, st,
                        (const float*)pl.p.slab, pl.p.dw, count4, pl.p.splits, pl.p.accumulate, log2sg, pl.p.wire);
     GAN_CHECK_LAUNCH();
   }

@@ -243,8 +243,10 @@ def main(opt):
                     print(f"data-parallel run: {info.world} ranks, replicas in sync.")
         print("Done.")
     except BaseException:
-        run.close()
-        ddp.shutdown(info, failed=True)      # no barrier on the way out of an exception: the peers are inside other collectives
+        try:
+            run.close()
+        finally:
+            ddp.shutdown(info, failed=True)  # no barrier on the way out of an exception: the peers are inside other collectives
         raise
     run.close()
     ddp.shutdown(info)

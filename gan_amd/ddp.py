@@ -223,10 +223,13 @@ def shutdown(info: DistInfo, failed: bool = False):
     if failed:
         abort = getattr(dist.distributed_c10d, '_abort_process_group', None)     # (torch >= 2.6: ncclCommAbort, does not wait for peers)
         try:
-            if abort is not None:
-                abort()
-        except Exception:
-            pass                      # the process is on its way out with the original exception either way
+            if abort is None:
+                raise RuntimeError("torch.distributed has no _abort_process_group")
+            abort()
+        except Exception as e:        # nothing was torn down: say so (the launcher / the watchdog ends the peers, not this rank)
+            import sys
+            print(f"gan_amd.ddp: could not abort the process group on a failing rank ({e!r}); its peers block in their pending "
+                  f"collectives until the launcher or the RCCL watchdog ends them", file=sys.stderr, flush=True)
         return
     try:
         dist.barrier()

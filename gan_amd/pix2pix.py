@@ -204,6 +204,12 @@ def parse_opt(argv=None):
     parser.add_argument('--exchange', type=str, default='allreduce', choices=['allreduce', 'rs_ag'],
                         help='gradient exchange: one all-reduce per bucket, or fp32 reduce-scatter + all-gather in the wire format')
     args = parser.parse_args(argv)
+    if args.generator_loss == 'ssim':
+        # pix2pix.py:182-184 computes tf.image.ssim(input_image, target): no gradient reaches the generator and the total becomes
+        # a (batch,) vector.  That degenerate term is not built here, and training silently with L1
+        # under an 'ssim' label would not be a drop-in: refuse.
+        parser.error("--generator-loss ssim is not supported by gan_amd (the reference's SSIM term compares input with target and "
+                     "carries no gradient, pix2pix.py:182-184); use the default --generator-loss l1")
     assert (args.img_size == 256) or (args.img_size == 512), "img-size currently only supported for 256 x 256 or 512 x 512 pixels!"
     assert (args.validation_size > 0.0 and args.validation_size <= 0.3), "validation size is a proportion and bounded between 0-0.3!"
     assert (args.test_img >= 1), "test-img is an integer and must be >=1!"
@@ -246,8 +252,10 @@ def main(opt):
                     print(f"data-parallel run: {info.world} ranks, replicas in sync.")
         print("Done.")
     except BaseException:
-        run.close()
-        ddp.shutdown(info, failed=True)      # no barrier on the way out of an exception: the peers are inside other collectives
+        try:
+            run.close()
+        finally:
+            ddp.shutdown(info, failed=True)  # no barrier on the way out of an exception: the peers are inside other collectives
         raise
     run.close()
     ddp.shutdown(info)

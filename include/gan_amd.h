@@ -396,9 +396,16 @@ const char* gan_version(void);
  * streaming kernels for the <= 8-channel layers, bit 1 thin-N, bit 2 thin-K), conv.norm_fuse (1), conv.stack (0: the callers in gan_amd/ merge eligible runs into layer stacks only when set), conv.stack_blocks (256), conv.thin_fused (1), wgrad.tile256 (0), wgrad.pingpong (1), wgrad.row_table (1),
  * wgrad.pingpong_min_rows (0 = automatic), wgrad.pingpong_128 (1), wgrad.pingpong_min_gflop (30),
  * wgrad.split_target (512), wgrad.fold_split_target (512), wgrad.reduce_adam (1),
- * wgrad.reduce_adam_min_params (1048576: smaller kernels keep the flat slab reduce and the caller's multi-tensor Adam pass). */
+ * wgrad.reduce_adam_min_params (1048576: smaller kernels keep the flat slab reduce and the caller's multi-tensor Adam pass),
+ * diag.launch_log (0: see gan_launch_log below). */
 int gan_set_option(const char* key, int32_t value);
 int gan_get_option(const char* key, int32_t* value);
+/* Diagnostic launch log (profiling tools only; no counterpart in the reference, whose only timing is time.time() per epoch,
+ * pix2pix.py:261,319).  gan_set_option("diag.launch_log", 1) clears the log and starts recording the kernel symbol of EVERY
+ * launch the entry points make, in enqueue order (0 stops).  gan_launch_log() copies the mangled names, newline-separated, into
+ * buf (at most cap bytes, NUL-terminated) and returns the bytes the whole log needs.  tools/class_profile.py joins it with a
+ * rocprofv3 --kernel-trace of the replayed step: per-launch class label + algorithmic FLOPs beside the measured duration. */
+size_t gan_launch_log(char* buf, size_t cap);
 
 #ifdef __cplusplus
 }

@@ -81,6 +81,8 @@ def test_cli_surface_matches_reference():
         pix2pix.parse_opt(['--data', 'd', '--output', 'o', '--train'])
     with pytest.raises(SystemExit):       # --weights required with --predict
         pix2pix.parse_opt(['--data', 'd', '--output', 'o', '--predict'])
+    with pytest.raises(SystemExit):       # the flag exists (pix2pix.py:351) but the degenerate SSIM term is not built: refused, not silently L1
+        pix2pix.parse_opt(['--data', 'd', '--output', 'o', '--train', '--epochs', '1', '--generator-loss', 'ssim'])
     with pytest.raises(AssertionError):
         pix2pix.parse_opt(['--data', 'd', '--output', 'o', '--train', '--epochs', '1', '--img-size', '128'])
     with pytest.raises(AssertionError):

@@ -1,0 +1,209 @@
+"""Full-size oracle VALUES (tests/golden/golden_full_*.npz, written once by tests/golden/make_golden_full.py from the fp64 CPU
+oracle) at the shapes BASELINE.json names - where the planner picks the table-driven / tap-shared / parity-patch / ping-pong
+kernels, the fused carriers and the multi-lane captured graph:
+
+  p16   Pix2Pix 256x256 batch 16   (config 2, the object bench.py times)       pix2pix.py:190-218
+  p512  Pix2Pix 512x512 batch 8    (config 4's per-GPU shape)
+  c4    CycleGAN 256x256 batch 4   (config 3)                                   cycle_gan.py:206-276
+
+fp32 path (eager, exact MFMA): the 1e-3 max-abs gate on the generator output, losses to rtol 2e-4 (5e-4 CycleGAN), every gradient
+tensor (strided sample + l2 norm), post-Adam weights, BatchNorm moving statistics.  bf16 path: the CAPTURED DEFAULT SCHEDULE
+(hipGraph, lanes, Adam inside the wgrad launches - what bench.py replays) on losses, generator output and post-Adam weights, and an
+eager bf16 step on the gradients (direction), at the sibling gates of tests/test_gpu_step.py.  Inputs, weights and masks are
+regenerated from the fixture's seeds (numpy default_rng); nothing here reads /root/reference."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import gan_oracle as O
+from tests.golden.make_golden_full import CASES, GEN_STRIDE, SAMPLE
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+LR = 2e-4
+
+
+def load(name):
+    return np.load(os.path.join(HERE, 'golden', f'golden_full_{name}.npz'))
+
+
+def sample(v):
+    f = np.asarray(v, np.float64).ravel()
+    stride = max(1, f.size // SAMPLE)
+    return f[::stride][:SAMPLE]
+
+
+def cosine(a, b):
+    a, b = np.asarray(a, np.float64).ravel(), np.asarray(b, np.float64).ravel()
+    return float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-300))
+
+
+def check_grad_samples(dtype, gold, nets, tol_f32):
+    """Every gradient tensor: strided sample + l2 norm against the fp64 oracle.  fp32: max-abs error relative to the sample's
+    largest value and the norm to 1e-3; 16-bit: direction (cosine of the sample) for the tensors that carry weight."""
+    norms = {k[5:]: float(gold[k][2]) for k in gold.files if k.startswith('gsum/')}
+    gmax = max(norms.values())
+    worst_rel, worst_cos, worst_norm = ('', 0.0), ('', 1.0), ('', 0.0)
+    for prefix, ps in nets:
+        got = ps.to_numpy('grad')
+        for k, g in got.items():
+            name = f'{prefix}.{k}'
+            ref = gold['gsample/' + name].astype(np.float64)
+            s = sample(g)
+            r = float(np.abs(s - ref).max() / (np.abs(ref).max() + 1e-30))
+            c = cosine(s, ref)
+            nrm = float(np.sqrt((g.astype(np.float64) ** 2).sum()))
+            nr = abs(nrm - norms[name]) / (norms[name] + 1e-30)
+            worst_rel = max(worst_rel, (name, r), key=lambda t: t[1])
+            worst_norm = max(worst_norm, (name, nr), key=lambda t: t[1])
+            if dtype == 'f32':
+                assert r < tol_f32, (name, r)
+                assert nr < 2e-3, (name, nr)
+                if norms[name] > 1e-3 * gmax:
+                    assert c > 0.999, (name, c)
+            elif norms[name] > 1e-3 * gmax:
+                worst_cos = min(worst_cos, (name, c), key=lambda t: t[1])
+                assert c > 0.90, (name, c, r)
+                assert nr < 0.15, (name, nr)
+    print(f"[{dtype}] gradient samples: worst rel {worst_rel}, worst cosine {worst_cos}, worst l2-norm rel {worst_norm}")
+
+
+def check_new_weights(dtype, gold, nets, w0):
+    """Post-Adam kernels (strided sample).  Step 1 of TF-form Adam moves every element by ~lr*sign(g) (base_gan.py:247-252): the
+    update is right where |new - ref| << lr; an element whose (tiny) gradient changed sign is off by 2*lr."""
+    worst = ('', 1.0)
+    for prefix, ps in nets:
+        new = ps.to_numpy()
+        for k, v in new.items():
+            if not k.endswith('.kernel'):
+                continue
+            ref = gold[f'new/{prefix}.{k}'].astype(np.float64)
+            d = np.abs(sample(v) - ref)
+            assert d.max() < 2 * LR + 1e-5, (prefix, k, d.max())
+            moved = np.abs(sample(w0[prefix][k]) - ref) > 0.5 * LR      # elements the oracle's step moved
+            agree = float((d[moved] < 0.5 * LR).mean()) if moved.any() else 1.0
+            worst = min(worst, (f'{prefix}.{k}', agree), key=lambda t: t[1])
+            assert agree > (0.995 if dtype == 'f32' else 0.80), (prefix, k, agree)
+    print(f"[{dtype}] post-Adam kernels: lowest share of sampled elements within lr/2 of the oracle: {worst}")
+
+
+def reset_state(nets, P0):
+    for (_, ps), P in zip(nets, P0):
+        ps.load_numpy(P)
+        ps.m.zero_(); ps.v.zero_(); ps.step.zero_()
+        for k, t in ps.state.items():
+            t.fill_(0.0 if 'mean' in k else 1.0)
+
+
+# ---- Pix2Pix ----------------------------------------------------------------------------------------------------------------
+def _p2p(name, dtype):
+    from gan_amd.nets import Ctx, workspace_mb_for
+    from gan_amd.steps import Pix2PixStep
+    c = CASES[name]
+    B, S = c['B'], c['S']
+    ctx = Ctx('cuda:0', dtype, workspace_mb=workspace_mb_for(B, S))
+    st = Pix2PixStep(ctx, B, S, 1, lam=c['lam'], seed=123)
+    P0 = [O.init_generator(1, seed=c['g_seed']), O.init_discriminator(1, True, seed=c['d_seed'])]
+    nets = [('G', st.G.params), ('D', st.D.params)]
+    reset_state(nets, P0)
+    inp, tar = O.synthetic_pair(B, S, 1, seed=c['in_seed'])
+    st.g.set_dropmasks(O.dropout_masks(B, S, seed=c['mask_seed']))
+    x = [torch.from_numpy(inp).to(ctx.device), torch.from_numpy(tar).to(ctx.device)]
+    return ctx, st, nets, P0, x
+
+
+@pytest.mark.parametrize("name", ['p16', 'p512'])
+def test_pix2pix_full_size_f32_against_oracle_values(name):
+    gold = load(name)
+    ctx, st, nets, P0, x = _p2p(name, 'f32')
+    losses = st.train_step(*x, True).cpu().numpy()
+    gen = st.g.output_f32().cpu().numpy()[:, ::GEN_STRIDE, ::GEN_STRIDE, :]
+    err = float(np.abs(gen - gold['gen_sample']).max())
+    print(f"[{name} f32] generator output max-abs err vs fp64 oracle (every {GEN_STRIDE}th pixel): {err:.3e}; losses {losses} ref {gold['losses']}")
+    assert err < 1e-3                                     # BASELINE.json north_star gate, at full size
+    assert np.allclose(losses, gold['losses'], rtol=2e-4)
+    check_grad_samples('f32', gold, nets, 2e-2)
+    check_new_weights('f32', gold, nets, dict(G=P0[0], D=P0[1]))
+    for prefix, ps in nets:
+        for k, t in ps.state.items():
+            ref = gold[f'moving/{prefix}.{k}']
+            assert np.abs(t.cpu().numpy() - ref).max() < 1e-4 * (np.abs(ref).max() + 1e-30) + 1e-7, (prefix, k)
+
+
+@pytest.mark.parametrize("name", ['p16', 'p512'])
+def test_pix2pix_full_size_bf16_captured_schedule_against_oracle_values(name):
+    """The object bench.py times (captured default schedule) + an eager bf16 step for the gradients the captured one never writes."""
+    gold = load(name)
+    ctx, st, nets, P0, x = _p2p(name, 'bf16')
+    w0 = dict(G=P0[0], D=P0[1])
+    # eager step: fp32 gradient buffers of every tensor
+    losses_e = st.train_step(*x, True).cpu().numpy()
+    check_grad_samples('bf16', gold, nets, None)
+    # captured default schedule from the same start
+    replay = st.capture(training=True)
+    reset_state(nets, P0)
+    losses = replay(*x)[:4].cpu().numpy()
+    torch.cuda.synchronize()
+    assert any(st.g.adam_fused.values())                  # Adam ran inside wgrad launches: this is the benchmarked schedule
+    gen = st.g.output_f32().cpu().numpy()[:, ::GEN_STRIDE, ::GEN_STRIDE, :]
+    err = float(np.abs(gen - gold['gen_sample']).max())
+    print(f"[{name} bf16 graph] generator output max-abs err: {err:.3e}; losses {losses} (eager {losses_e}) ref {gold['losses']}")
+    assert err < 0.04                                     # bf16 storage: reported, sibling gate of test_pix2pix_train_step_parity
+    assert np.allclose(losses, gold['losses'], rtol=5e-3)
+    assert np.allclose(losses, losses_e, rtol=1e-5)
+    check_new_weights('bf16', gold, nets, w0)
+
+
+# ---- CycleGAN ---------------------------------------------------------------------------------------------------------------
+def _cyc(dtype):
+    from gan_amd.nets import Ctx, workspace_mb_for
+    from gan_amd.steps import CycleGANStep
+    c = CASES['c4']
+    B, S = c['B'], c['S']
+    ctx = Ctx('cuda:0', dtype, workspace_mb=workspace_mb_for(B, S))
+    st = CycleGANStep(ctx, B, S, 1, lam=c['lam'], seed=7, dropout=True)
+    n, s = 'instancenorm', c['seeds']
+    P0 = [O.init_generator(1, n, seed=s[0]), O.init_generator(1, n, seed=s[1]),
+          O.init_discriminator(1, False, n, seed=s[2]), O.init_discriminator(1, False, n, seed=s[3])]
+    nets = list(zip(('Gg', 'Gf', 'Dx', 'Dy'), [net.params for net in st.nets()]))
+    reset_state(nets, P0)
+    rx, ry = O.synthetic_pair(B, S, 1, seed=c['in_seed'])
+    keys = ['fake_y', 'cycled_x', 'fake_x', 'cycled_y', 'same_x', 'same_y']
+    for i, k in enumerate(keys):
+        st.gen_calls()[k].set_dropmasks(O.dropout_masks(B, S, seed=c['mask_seed'] + i))
+    x = [torch.from_numpy(rx).to(ctx.device), torch.from_numpy(ry).to(ctx.device)]
+    return ctx, st, nets, P0, x
+
+
+def _fakes(st, gold, tol):
+    for k in ('fake_y', 'fake_x'):
+        got = st.gen_calls()[k].output_f32().cpu().numpy()[:, ::GEN_STRIDE, ::GEN_STRIDE, :]
+        err = float(np.abs(got - gold[f'{k}_sample']).max())
+        print(f"    {k} max-abs err vs fp64 oracle: {err:.3e}")
+        assert err < tol, (k, err)
+
+
+def test_cyclegan_batch4_f32_against_oracle_values():
+    gold = load('c4')
+    ctx, st, nets, P0, x = _cyc('f32')
+    losses = st.train_step(*x, True).cpu().numpy()
+    print(f"[c4 f32] losses {losses} ref {gold['losses']}")
+    assert np.allclose(losses, gold['losses'], rtol=5e-4)
+    _fakes(st, gold, 1e-3)
+    check_grad_samples('f32', gold, nets, 1e-1)          # (InstanceNorm + ReLU kinks: sibling tolerance of test_cyclegan_train_step_parity)
+    check_new_weights('f32', gold, nets, dict(zip(('Gg', 'Gf', 'Dx', 'Dy'), P0)))
+
+
+def test_cyclegan_batch4_bf16_captured_schedule_against_oracle_values():
+    gold = load('c4')
+    ctx, st, nets, P0, x = _cyc('bf16')
+    replay = st.capture(training=True)
+    reset_state(nets, P0)
+    losses = replay(*x)[:7].cpu().numpy()
+    torch.cuda.synchronize()
+    print(f"[c4 bf16 graph] losses {losses} ref {gold['losses']}")
+    assert np.allclose(losses, gold['losses'], rtol=5e-3)
+    _fakes(st, gold, 0.025)
+    check_new_weights('bf16', gold, nets, dict(zip(('Gg', 'Gf', 'Dx', 'Dy'), P0)))

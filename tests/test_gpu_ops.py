@@ -1250,3 +1250,97 @@ def test_multi_launch_pack_and_dropout_equal_single_calls(ctx):
     assert all(torch.equal(a_, b_) for a_, b_ in zip(seen[0], m2))
     assert not torch.equal(seen[0][1], seen[1][1]) and not torch.equal(seen[1][1], seen[2][1])
     assert 0.4 < (seen[1][1] == seen[2][1]).float().mean().item() < 0.6          # independent draws
+
+
+# ---- operands embedded in NaN-filled memory: nothing behind a tensor may reach a result -------------------------------------
+def _guarded(t, guard_elems=2 << 20):
+    """Copy of device tensor `t` between two guard regions full of NaN -> (holder, device pointer of the copy)."""
+    flat = torch.full((2 * guard_elems + t.numel(),), float('nan'), dtype=t.dtype, device=t.device)
+    flat[guard_elems:guard_elems + t.numel()] = t.reshape(-1)
+    return flat, flat.data_ptr() + guard_elems * t.element_size()
+
+
+def _guarded_view(buf):
+    from gan_amd import _lib as L
+    holder, ptr = _guarded(buf.t)
+    return holder, L.GanTensor(ptr, buf.n, buf.h, buf.w, buf.c, buf.c)
+
+
+@pytest.mark.parametrize("case", [(8, 32, 256, 512, 1),       # D conv4's shape: 31 x 31 grid, M % 64 = 8 (the last K tile mostly past the end)
+                                  (5, 100, 64, 128, 2),       # rows of 50, M = 12500: M % 64 = 20, four taps per tile
+                                  (3, 64, 128, 256, 2)])      # M % 64 = 0 (control)
+def test_wgrad_pingpong_never_reads_past_its_operands(ctx, case, planner_options):
+    """wgrad_pp_kernel's row-table path addresses reduction rows m >= M of the SMALL operand (and K tiles past a split's range) with
+    an in-range vector offset + a SCALAR offset that leaves the tensor, relying on the buffer descriptor's range check covering
+    voffset + soffset (raw buffers: out of range iff offset >= num_records - soffset).  Both operands sit between NaN guards here:
+    were the scalar offset not range-checked, live NaNs behind dy would meet the zeroed BIG rows in the MFMA (0 x NaN = NaN) and
+    poison dW.  Result must be finite and bit-equal to the run on plain buffers, for the table path and the in-loop decode."""
+    from gan_amd import _lib as L
+    if ctx.dtype == 'f32':
+        pytest.skip("ping-pong wgrad: 16-bit storage only")
+    N, H, ci, co, s = case
+    rng = np.random.default_rng(11)
+    Ho = (H + 2 - 4) // s + 1
+    xb, xv = dev(ctx, q(ctx, rng.standard_normal((N, H, H, ci))))
+    dyb, dyv = dev(ctx, q(ctx, rng.standard_normal((N, Ho, Ho, co))))
+    hx, gxv = _guarded_view(xb)
+    hd, gdv = _guarded_view(dyb)
+    planner_options('wgrad.pingpong_min_gflop', 1)
+    out = {}
+    for tab in (1, 0):
+        planner_options('wgrad.row_table', tab)
+        for guard, (a, b) in (('plain', (xv, dyv)), ('guarded', (gxv, gdv))):
+            dw = torch.zeros((16, ci, co), dtype=torch.float32, device=ctx.device)
+            d = L.GanWgradDesc(ctx.dt, s, a, b, dw.data_ptr(), ci, co, 0, ctx.ws_ptr, ctx.ws_bytes)
+            winfo = (C.c_int32 * 4)()
+            assert ctx.lib.gan_wgrad_plan_info(C.byref(d), winfo) == 0 and (winfo[0], winfo[1]) == (256, 256) and winfo[2] > 1, list(winfo)
+            assert ctx.lib.gan_conv_wgrad(C.byref(d), ctx.stream()) == 0
+            torch.cuda.synchronize()
+            out[tab, guard] = dw.cpu().numpy()
+    assert np.isfinite(out[1, 'guarded']).all() and np.isfinite(out[0, 'guarded']).all()
+    assert np.abs(out[1, 'plain']).max() > 1
+    for k in ((1, 'guarded'), (0, 'plain'), (0, 'guarded')):
+        assert np.array_equal(out[k], out[1, 'plain']), k
+    assert torch.isnan(hx[:16]).all() and torch.isnan(hd[-16:]).all()          # (the guards are still NaN: nothing wrote there either)
+
+
+@pytest.mark.parametrize("case", [('conv_fwd', 16, 100, 64, 128, 2),       # table-driven 256x128 tiles, rows of 50, ragged last tile
+                                  ('conv_fwd', 32, 32, 256, 512, 1),       # D conv4: tap-shared 256x256 tiles, rows of 31, ragged
+                                  ('conv_dgrad', 32, 31, 512, 256, 1),     # its dgrad (shifts to the left), ragged
+                                  ('convT_fwd', 16, 16, 1024, 256, 2),     # split K: chunks past a split's range
+                                  ('convT_fwd', 1, 64, 128, 64, 2),        # parity-patch kernel: halo rows above / below the image
+                                  ('conv_dgrad', 3, 32, 64, 64, 2)])       # parity-patch kernel as a stride-2 dgrad, three images
+def test_conv_tiles_never_read_past_their_operands(ctx, case, planner_options):
+    """The 256-row convolution kernels (tap-shared, table-driven, parity-patch) name every staged piece as register + scalar chunk
+    offset and rely on the descriptor's range check (voffset + soffset) for rows past M, taps outside the map and chunks past the
+    block's range.  Activation and weight operands between NaN guards: the output must be finite and bit-equal to the run on plain
+    buffers."""
+    from gan_amd import _lib as L
+    from gan_amd.nets import Buf
+    if ctx.dtype == 'f32':
+        pytest.skip("16-bit kernels")
+    op, N, H, cx, cy, s = case
+    if cy == 64:
+        planner_options('conv.parity_patch_min_blocks', 1)
+    rng = np.random.default_rng(abs(hash(case)) % 2**31)
+    Ho = {'conv_fwd': (H + 2 - 4) // s + 1, 'conv_dgrad': H * 2 if s == 2 else H + 1, 'convT_fwd': 2 * H, 'convT_dgrad': H // 2}[op]
+    x = q(ctx, rng.standard_normal((N, H, H, cx)))
+    kin, kout = {'conv_fwd': (cx, cy), 'conv_dgrad': (cy, cx), 'convT_fwd': (cy, cx), 'convT_dgrad': (cx, cy)}[op]
+    nat, tr = prep(ctx, q(ctx, 0.05 * rng.standard_normal((4, 4, kin, kout))))
+    wk = {'conv_fwd': tr, 'conv_dgrad': nat, 'convT_fwd': nat, 'convT_dgrad': tr}[op]
+    xb, xv = dev(ctx, x)
+    hx, gxv = _guarded_view(xb)
+    hw, gw = _guarded(wk)
+    fn = getattr(ctx.lib, {'conv_fwd': 'gan_conv2d_fwd', 'conv_dgrad': 'gan_conv2d_dgrad', 'convT_fwd': 'gan_convT2d_fwd', 'convT_dgrad': 'gan_convT2d_dgrad'}[op])
+    outs = []
+    for xa, wa in ((xv, wk.data_ptr()), (gxv, gw)):
+        yb = Buf(ctx, N, Ho, Ho, cy)
+        d = L.GanConvDesc(ctx.dt, s, xa, yb.view(0, cy), wa, cy, None, 0, 0.3, 0, ctx.ws_ptr, ctx.ws_bytes)
+        info = (C.c_int32 * 5)()
+        assert ctx.lib.gan_conv_plan_info(C.byref(d), ['conv_fwd', 'conv_dgrad', 'convT_fwd', 'convT_dgrad'].index(op), info) == 0
+        assert info[0] in (256, 1024), list(info)                 # a 256-row tile or the parity-patch kernel
+        assert fn(C.byref(d), ctx.stream()) == 0
+        torch.cuda.synchronize()
+        outs.append(host(yb))
+    assert np.isfinite(outs[1]).all()
+    assert np.abs(outs[0]).max() > 0.1 and np.array_equal(outs[0], outs[1])
