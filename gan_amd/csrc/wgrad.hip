@@ -45,6 +45,11 @@ struct WgradParams {
   int swap, shift;  // swap: roles exchanged (thin SMALL tensor folded, thick BIG tensor streamed), taps flipped, rows shifted
   // GanAdamFuse (adam != 0: un-split launch, !fold, !swap, !accumulate, CaReal % 8 == CbReal % 8 == 0): the epilogue applies Adam
   int adam;
+  // adam == 1 only: taps whose source position lies outside the map for EVERY grid position (a 2x2 -> 1x1 layer uses 4 of its 16
+  // taps): their gradient is exactly zero, so with zero moments the step changes nothing - their blocks check m == v == 0 and leave
+  // (bit-identical to the update); ahalves == 2: the grid's z index names which 64-row half of the tile a block updates (the GEMM of
+  // such a layer is a few MFMAs; twice the blocks stream the optimiser state of the live taps)
+  int dead_taps, ahalves;
   float* aw; float* am; float* av; void* anat; void* atr; const float* alr;
   float omb1, omb2, aeps;
   void* wire;                // GanWgradDesc.dw_wire honoured: the result goes out as bfloat16 into the exchange's wire buffer, dw untouched
@@ -414,7 +419,7 @@ static int plan_wgrad(const GanWgradDesc* d, WgradPlan* pl, bool allow_swap = tr
   p.S = d->stride; p.M = (int)M; p.divW = make_fastdiv(s.w); p.divH = make_fastdiv(s.h);
   p.CaReal = d->big_c; p.CbReal = d->small_c; p.accumulate = d->accumulate;
   p.fold = (b.c == 8) ? 1 : 0;
-  p.swap = 0; p.shift = 0; p.adam = 0; p.wire = nullptr;
+  p.swap = 0; p.shift = 0; p.adam = 0; p.wire = nullptr; p.dead_taps = 0; p.ahalves = 1;
 #ifdef GAN_DIAG
   p.diag = g_wdiag;
 #endif
@@ -498,9 +503,18 @@ static int plan_wgrad(const GanWgradDesc* d, WgradPlan* pl, bool allow_swap = tr
     p.adam = 1;
     p.aw = af->master; p.am = af->m; p.av = af->v; p.anat = af->nk_native; p.atr = af->nk_transposed; p.alr = af->lr_t;
     p.omb1 = 1.f - af->beta1; p.omb2 = 1.f - af->beta2; p.aeps = af->eps;
+    if (gan_opt("wgrad.dead_taps")) {
+      for (int t = 0; t < 16; ++t) {
+        bool ly = false, lx = false;
+        for (int g = 0; g < s.h && !ly; ++g) ly = (unsigned)(g * p.S + (t >> 2) - 1) < (unsigned)p.Hb;
+        for (int g = 0; g < s.w && !lx; ++g) lx = (unsigned)(g * p.S + (t & 3) - 1) < (unsigned)p.Wb;
+        if (!(ly && lx)) p.dead_taps |= 1 << t;
+      }
+      if (p.dead_taps && M <= 64) p.ahalves = 2;
+    }
   }
   pl->TA = TA; pl->TB = TB;
-  pl->grid = dim3((unsigned)(tilesA * tilesB), (unsigned)taps, (unsigned)splits);
+  pl->grid = dim3((unsigned)(tilesA * tilesB), (unsigned)taps, (unsigned)(p.ahalves == 2 ? 2 : splits));
   pl->slab_bytes = splits > 1 ? (size_t)splits * 16 * p.CaReal * p.CbReal * sizeof(float) : 0;
   return 0;
 }
@@ -568,8 +582,27 @@ __global__ __launch_bounds__(64 * WAVES_A * WAVES_B) void wgrad_dma_kernel(const
   const int r = lane & 15, q = lane >> 4;
   const int ta = blockIdx.x / p.tilesB, tb = blockIdx.x % p.tilesB;
   const int ca0 = ta * TA, cb0 = tb * TB;
-  const int tap = blockIdx.y, split = blockIdx.z;
+  const int tap = blockIdx.y;
+  const int zhalf = p.ahalves == 2 ? (int)blockIdx.z : -1, split = p.ahalves == 2 ? 0 : (int)blockIdx.z;
   const int kh = tap >> 2, kw = tap & 3;
+  // GanAdamFuse: a tile whose gradient is exactly zero AND whose moments are zero is left as it is by the step (m, v stay 0,
+  // the weight moves by 0 / (0 + eps)): the block reads m and v (8 of the 28 bytes per parameter) and leaves.  Two cases: a tap that
+  // never meets the map at this shape (known before the GEMM: dead_taps) and an all-zero accumulator tile after it (e.g. everything
+  // above an InstanceNorm over a single position).  A block that finds a non-zero moment runs the full path: always bit-identical.
+  auto moments_zero = [&]() -> bool {
+    unsigned nz = 0;
+    for (int it = 0; it < TA * TB / 1024; ++it) {
+      const int idx = tid + it * 256, row = idx / (TB / 4), c4 = (idx % (TB / 4)) * 4;
+      const int a = ca0 + row, cb = cb0 + c4;
+      if ((zhalf < 0 || (row >> 6) == zhalf) && a < p.CaReal && cb < p.CbReal) {
+        const size_t o = ((size_t)tap * p.CaReal + a) * p.CbReal + cb;
+        const uint4 m4 = *(const uint4*)(p.am + o), v4 = *(const uint4*)(p.av + o);
+        nz |= m4.x | m4.y | m4.z | m4.w | v4.x | v4.y | v4.z | v4.w;
+      }
+    }
+    return !__syncthreads_or(nz != 0);
+  };
+  if (p.adam == 1 && ((p.dead_taps >> tap) & 1) && moments_zero()) return;
   const __amdgpu_buffer_rsrc_t rbig = __builtin_amdgcn_make_buffer_rsrc((void*)p.big, 0, bigbytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsmall = __builtin_amdgcn_make_buffer_rsrc((void*)p.small, 0, smallbytes, 0x00020000);
 
@@ -719,8 +752,19 @@ __global__ __launch_bounds__(64 * WAVES_A * WAVES_B) void wgrad_dma_kernel(const
       constexpr int LP = 129;                                // padded row of the 64 x 128 fp32 half tile
       float* tile = (float*)smem;
       const float lr = *p.alr;
+      {
+        unsigned gnz = 0;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) gnz |= __float_as_uint(acc[i][j][e]) << 1;       // (+0 and -0 alike)
+        if (!__syncthreads_or(gnz != 0) && moments_zero()) return;
+      }
       __syncthreads();                                       // every wave has left the last stage
       for (int h = 0; h < 2; ++h) {
+        if (zhalf >= 0 && h != zhalf) continue;             // (block-uniform: this block updates one half only)
         if (wa == h) {
 #pragma unroll
           for (int i = 0; i < MT; ++i)

@@ -522,14 +522,14 @@ class _Builder:
             meta['stack'] = (d, opi)
         return (fn, (self._desc(d),), op, meta)
 
-    def wgrad(self, big, small, dw_ptr, big_c, small_c, stride, accumulate, adam_fuse=None, wire_ptr=None):
+    def wgrad(self, big, small, dw_ptr, big_c, small_c, stride, accumulate, adam_fuse=None, wire_ptr=None, ws_ptr=None, alt=False):
         """adam_fuse: a GanAdamFuse - ask the launch to apply the optimiser step itself; self.last_adam_fused tells whether it will.
         wire_ptr: this kernel's place in the bf16 wire buffer of the data-parallel exchange - ask the launch to write the gradient
         there (GanWgradDesc.dw_wire); self.last_wire_direct tells whether it will (then dw stays untouched)."""
         if adam_fuse is not None:
             self.keep.append(adam_fuse)
         d = L.GanWgradDesc(self.ctx.dt, stride, big, small, dw_ptr, big_c, small_c, int(accumulate),
-                           self.ws_side_ptr, self.ws_bytes, int(self.wgrad_concurrent),
+                           ws_ptr or self.ws_side_ptr, self.ws_bytes, int(self.wgrad_concurrent),
                            C.addressof(adam_fuse) if adam_fuse is not None else None, wire_ptr if (wire_ptr and not accumulate and adam_fuse is None) else None)
         self.last_wire_direct = False
         if d.dw_wire:
@@ -553,7 +553,7 @@ class _Builder:
         info = (C.c_int32 * 4)()
         self.lib.gan_wgrad_plan_info(C.byref(d), info)
         flops = 2.0 * small.n * small.h * small.w * 16 * big_c * small_c
-        meta = dict(kind='gemm', kernel=f"wgrad<{self.ctx.dtype},{info[0]},{info[1]}>", flops=flops, splits=info[2],
+        meta = dict(kind='gemm', kernel=f"wgrad<{self.ctx.dtype},{info[0]},{info[1]}>", flops=flops, splits=info[2], alt=bool(alt),
                     shape=f"wgrad A{big_c} B{small_c} M{small.n * small.h * small.w} s{info[2]}")
         return (self.lib.gan_conv_wgrad, (self._desc(d),), "conv_wgrad", meta, True)      # True: side-stream op
 
@@ -797,6 +797,10 @@ class GenCall:
         self._bwd_cache = {}
         self.adam_fused = {}
         self.wire_direct = {}
+        # kernels whose wgrad launch runs on a SECOND wgrad lane (own slab workspace) in the staged schedule: set by the step object
+        # before the first backward op list is built (Pix2PixStep.wgrad_alt)
+        self.alt_wgrad = frozenset()
+        self.wgrad_stream2 = None
 
     def _build_bwd(self, use_dgen2, need_dx, accumulate, wgrads='own', adam=None, wire=None):
         """wgrads: 'own' - this call's kernel gradients (accumulate as the other gradients do); 'none' - a guest call whose host
@@ -827,7 +831,9 @@ class GenCall:
                 return
             af = P.adam_fuse_desc(kname, adam[0], adam[1]) if adam is not None else None
             wp = wire + 2 * P.entries[kname][0] if wire else None
-            ops.append(bd.wgrad(big_v, small_v, P.ptr(kname, 'grad'), big_c, small_c, stride, wacc, adam_fuse=af, wire_ptr=wp))
+            alt = kname in self.alt_wgrad
+            ops.append(bd.wgrad(big_v, small_v, P.ptr(kname, 'grad'), big_c, small_c, stride, wacc, adam_fuse=af, wire_ptr=wp,
+                                ws_ptr=self.ctx.ws_lanes[5].data_ptr() if alt else None, alt=alt))
             if af is not None and bd.last_adam_fused:
                 fused_names.append(kname)
             if bd.last_wire_direct:
@@ -981,7 +987,12 @@ class GenCall:
             for k, (main_ops, w_ops) in enumerate(self.bwd_stages(self.wgrad_cuts, use_dgen2, need_dx, accumulate, wgrads, adam)):
                 self.ctx.run(main_ops)
                 self.wgrad_stream.wait_stream(main)
-                self.ctx.run_on(w_ops, self.wgrad_stream)
+                two = self.wgrad_stream2 is not None
+                w2 = [o for o in w_ops if two and o[3].get('alt')]
+                self.ctx.run_on([o for o in w_ops if not (two and o[3].get('alt'))], self.wgrad_stream)
+                if w2:           # second wgrad lane (forked from the origin stream, like every side lane)
+                    self.wgrad_stream2.wait_stream(main)
+                    self.ctx.run_on(w2, self.wgrad_stream2)
                 if getattr(self, 'stage_hook', None) is not None:
                     self.stage_hook(k)         # e.g. the optimiser step of the layers whose gradients are now complete
         else:

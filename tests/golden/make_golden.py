@@ -19,8 +19,8 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
-from gan_amd import data as D          # noqa: E402  (pure numpy/PIL helpers)
 from oracle import gan_oracle as O     # noqa: E402
+from tests.golden import independent_io as IO     # noqa: E402  (NOT gan_amd.data: the fixture must be able to catch a bug there)
 
 REF = '/root/reference/example_images'
 
@@ -28,9 +28,8 @@ REF = '/root/reference/example_images'
 def main():
     pairs = []
     for name in ('example1.png', 'example2.png'):
-        img = D.load(os.path.join(REF, name), 1)
-        a, b = D.split_img(img, 'left')
-        pairs.append((D.resize_nearest(a, 256, 256), D.resize_nearest(b, 256, 256)))
+        a, b = IO.split_left_right(IO.decode_gray(os.path.join(REF, name)))
+        pairs.append((IO.resize_nn(a, 256, 256)[..., None], IO.resize_nn(b, 256, 256)[..., None]))
     inp_u8 = np.stack([p[0] for p in pairs]).astype(np.uint8)
     tar_u8 = np.stack([p[1] for p in pairs]).astype(np.uint8)
     np.savez_compressed(os.path.join(HERE, 'example_pairs_256.npz'), input_u8=inp_u8, target_u8=tar_u8)

@@ -516,3 +516,58 @@ def test_checkpoint_keys_follow_the_keras_object_graph(tmp_path):
     m3 = Model(9)
     Checkpoint(discriminator=m3).restore(str(tmp_path / 'old'))
     assert np.array_equal(m3.loaded['layer_with_weights-3/kernel/.ATTRIBUTES/VARIABLE_VALUE'], a)
+
+
+def test_product_input_helpers_match_the_independent_fixture_code(tmp_path):
+    """tests/golden/make_golden.py builds the committed example-pair fixture with tests/golden/independent_io.py (PIL decode, split at
+    w // 2, TF-2 nearest-neighbour resize in exact integer arithmetic) - code that shares nothing with gan_amd/data.py.  The same
+    comparison on images of awkward sizes: the product's load / split_img / resize_nearest (base_gan.py:26-54, pix2pix.py:43-52)
+    must return the same pixels, for down- and up-scaling and for both orientations."""
+    from PIL import Image
+    from gan_amd import data as D
+    from tests.golden import independent_io as IO
+    rng = np.random.default_rng(5)
+    for k, (h, w) in enumerate([(37, 90), (512, 1280), (101, 203), (8, 16)]):
+        a = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        f = str(tmp_path / f"i{k}.png")
+        Image.fromarray(a, mode='L').save(f)
+        img = D.load(f, 1)
+        assert np.array_equal(img[..., 0].astype(np.uint8), IO.decode_gray(f))
+        left, right = IO.split_left_right(IO.decode_gray(f))
+        pl, pr = D.split_img(img, 'left')
+        ql, qr = D.split_img(img, 'right')
+        assert np.array_equal(pl[..., 0], left) and np.array_equal(pr[..., 0], right)
+        assert np.array_equal(ql[..., 0], pr[..., 0]) and np.array_equal(qr[..., 0], pl[..., 0])
+        for oh, ow in [(256, 256), (286, 286), (16, 24), (h, w // 2)]:
+            assert np.array_equal(D.resize_nearest(pl, oh, ow)[..., 0], IO.resize_nn(left, oh, ow)), (h, w, oh, ow)
+            assert np.array_equal(D.resize_nearest(pr, oh, ow)[..., 0], IO.resize_nn(right, oh, ow)), (h, w, oh, ow)
+    # the committed fixture holds exactly two 256 x 256 single-channel pairs
+    ex = np.load(os.path.join(ROOT, 'tests', 'golden', 'example_pairs_256.npz'))
+    assert ex['input_u8'].shape == ex['target_u8'].shape == (2, 256, 256, 1) and ex['input_u8'].dtype == np.uint8
+
+
+def test_full_size_golden_fixtures_are_complete():
+    """tests/golden/golden_full_*.npz (fp64 oracle at BASELINE.json's shapes, tests/golden/make_golden_full.py): every trainable
+    tensor of every network has its checksum, its strided sample and - kernels - its post-Adam sample; finite values only."""
+    from oracle import gan_oracle as O
+    from tests.golden.make_golden_full import CASES, SAMPLE
+    nets = {'pix2pix': {'G': O.init_generator(1), 'D': O.init_discriminator(1, True)},
+            'cyclegan': {'Gg': O.init_generator(1, 'instancenorm'), 'Gf': O.init_generator(1, 'instancenorm'),
+                         'Dx': O.init_discriminator(1, False, 'instancenorm'), 'Dy': O.init_discriminator(1, False, 'instancenorm')}}
+    for name, c in CASES.items():
+        g = np.load(os.path.join(ROOT, 'tests', 'golden', f'golden_full_{name}.npz'))
+        assert g['losses'].shape == ((4,) if c['model'] == 'pix2pix' else (7,)) and np.isfinite(g['losses']).all()
+        n = 0
+        for prefix, P in nets[c['model']].items():
+            for k, v in P.items():
+                s = g[f'gsample/{prefix}.{k}']
+                assert g[f'gsum/{prefix}.{k}'].shape == (3,) and 0 < s.size <= SAMPLE and np.isfinite(s).all(), (name, prefix, k)
+                stride = max(1, v.size // SAMPLE) | 1
+                assert s.size == min(SAMPLE, (v.size + stride - 1) // stride), (name, prefix, k)
+                if k.endswith('.kernel'):
+                    assert g[f'new/{prefix}.{k}'].shape == s.shape
+                n += 1
+        assert n == (57 if c['model'] == 'pix2pix' else 114)
+        side = (c['S'] + 6) // 7
+        key = 'gen_sample' if c['model'] == 'pix2pix' else 'fake_y_sample'
+        assert g[key].shape == (c['B'], side, side, 1) and np.abs(g[key]).max() <= 1.0

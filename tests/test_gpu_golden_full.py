@@ -31,7 +31,7 @@ def load(name):
 
 def sample(v):
     f = np.asarray(v, np.float64).ravel()
-    stride = max(1, f.size // SAMPLE)
+    stride = max(1, f.size // SAMPLE) | 1        # odd: a stride that divides the row length would sample one channel only
     return f[::stride][:SAMPLE]
 
 
@@ -52,6 +52,9 @@ def check_grad_samples(dtype, gold, nets, tol_f32):
             name = f'{prefix}.{k}'
             ref = gold['gsample/' + name].astype(np.float64)
             s = sample(g)
+            if not np.any(ref):          # a tensor the oracle leaves without gradient (CycleGAN: InstanceNorm of the 1x1 bottleneck
+                assert np.abs(s).max() < 1e-12, (name, np.abs(s).max())      # is its offset, so up0 sees zeros): zero here too
+                continue
             r = float(np.abs(s - ref).max() / (np.abs(ref).max() + 1e-30))
             c = cosine(s, ref)
             nrm = float(np.sqrt((g.astype(np.float64) ** 2).sum()))
@@ -59,10 +62,13 @@ def check_grad_samples(dtype, gold, nets, tol_f32):
             worst_rel = max(worst_rel, (name, r), key=lambda t: t[1])
             worst_norm = max(worst_norm, (name, nr), key=lambda t: t[1])
             if dtype == 'f32':
+                # a sampled element may sit behind a ReLU / sign() kink that fp32 and fp64 take differently (the numpy oracle run
+                # in fp32 differs from its own fp64 run by up to 5.5e-2 per tensor): max-abs at `tol_f32`, the direction and the
+                # norm of every tensor that carries weight tightly
                 assert r < tol_f32, (name, r)
                 assert nr < 2e-3, (name, nr)
                 if norms[name] > 1e-3 * gmax:
-                    assert c > 0.999, (name, c)
+                    assert c > 0.9995, (name, c)
             elif norms[name] > 1e-3 * gmax:
                 worst_cos = min(worst_cos, (name, c), key=lambda t: t[1])
                 assert c > 0.90, (name, c, r)
@@ -124,7 +130,7 @@ def test_pix2pix_full_size_f32_against_oracle_values(name):
     print(f"[{name} f32] generator output max-abs err vs fp64 oracle (every {GEN_STRIDE}th pixel): {err:.3e}; losses {losses} ref {gold['losses']}")
     assert err < 1e-3                                     # BASELINE.json north_star gate, at full size
     assert np.allclose(losses, gold['losses'], rtol=2e-4)
-    check_grad_samples('f32', gold, nets, 2e-2)
+    check_grad_samples('f32', gold, nets, 6e-2)
     check_new_weights('f32', gold, nets, dict(G=P0[0], D=P0[1]))
     for prefix, ps in nets:
         for k, t in ps.state.items():

@@ -799,7 +799,9 @@ def test_wgrad_row_table_equals_row_decode(ctx, case, planner_options):
     assert rel(out[0].reshape(4, 4, ci, co), dw_ref) < TOL[ctx.dtype]
 
 
-@pytest.mark.parametrize("case", [(2, 8, 512, 512, 'epilogue'), (4, 64, 64, 64, 'reduce'), (4, 128, 256, 256, 'reduce-pp'), (16, 32, 512, 128, 'reduce')])
+@pytest.mark.parametrize("case", [(2, 8, 512, 512, 'epilogue'), (4, 64, 64, 64, 'reduce'), (4, 128, 256, 256, 'reduce-pp'), (16, 32, 512, 128, 'reduce'),
+                                  (16, 2, 512, 512, 'epilogue'),            # 2x2 -> 1x1 (G.down7 / up0 at 256x256): 12 of the 16 taps never meet the map
+                                  (16, 2, 512, 512, 'epilogue-moments')])   # ... with non-zero moments there: those blocks must run the update
 def test_wgrad_with_fused_adam_equals_wgrad_then_adam(ctx, case, planner_options):
     """GanAdamFuse: a wgrad launch that applies TF-form Adam to its kernel and refreshes both NK copies - in its own epilogue
     (un-split 128x128 launch) or at the end of its slab reduce (split launches, ping-pong kernel included; the reduce of the small
@@ -810,6 +812,8 @@ def test_wgrad_with_fused_adam_equals_wgrad_then_adam(ctx, case, planner_options
     if ctx.dtype != 'bf16':
         pytest.skip("bf16 only: fp32 has no 16-bit epilogue, fp16 steps keep the whole-step inf/nan check (and the un-scaling) before any update")
     N, H, ci, co, how = case
+    premoments = how.endswith('-moments')
+    how = how.split('-moments')[0]
     planner_options('wgrad.reduce_adam_min_params', 0)        # (the default leaves kernels under 2^20 parameters to the separate passes)
     rng = np.random.default_rng(17)
     x, dy = q(ctx, rng.standard_normal((N, H, H, ci))), q(ctx, 0.1 * rng.standard_normal((N, H // 2, H // 2, co)))
@@ -821,6 +825,9 @@ def test_wgrad_with_fused_adam_equals_wgrad_then_adam(ctx, case, planner_options
     for fused in (False, True):
         P = ParamSet(ctx, [('k.kernel', (4, 4, ci, co), True), ('k.beta', (co,), True)])
         P.load_numpy({'k.kernel': w0, 'k.beta': np.zeros(co, np.float32)})
+        if premoments:       # (a checkpoint trained at another resolution: the taps that are dead here carry moments)
+            P.m.copy_(torch.from_numpy((1e-3 * np.random.default_rng(3).standard_normal(P.m.numel())).astype(np.float32)))
+            P.v.copy_(torch.from_numpy((1e-6 * np.random.default_rng(4).random(P.v.numel())).astype(np.float32)))
         for step in range(2):
             if fused:
                 ctx.run(P.adam_begin_ops(2e-4, 0.5, 0.999))

@@ -19,7 +19,6 @@ import csv
 import json
 import os
 import re
-import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -99,33 +98,28 @@ def cmd_run(a):
     print(f"class_profile: {len(launches)} launches per captured step, {a.steps} replays, losses {losses[:4]}")
 
 
-def demangle(names):
-    tool = '/opt/rocm/lib/llvm/bin/llvm-cxxfilt'
-    if not os.path.exists(tool):
-        return {n: n for n in names}
-    out = subprocess.run([tool], input='\n'.join(names), capture_output=True, text=True).stdout.split('\n')
-    return dict(zip(names, out))
-
-
 def cmd_join(a):
     m = json.load(open(a.map))
     L_, steps = m['launches'], m['steps']
     N = len(L_)
     rows = [r for r in csv.DictReader(open(a.trace)) if r['Kind'] == 'KERNEL_DISPATCH']
-    rows.sort(key=lambda r: int(r['Start_Timestamp']) if not m['multi_lane'] else int(r['Dispatch_Id']))
-    assert len(rows) >= steps * N, (len(rows), steps, N)
-    tail = rows[-steps * N:]
-    dm = demangle(sorted({e['symbol'] for e in L_}))
-    norm = lambda s: re.sub(r'\s+', '', re.sub(r'^void ', '', s))
-    if not m['multi_lane']:              # one stream: dispatch order = enqueue order, checked symbol by symbol
-        for k, r in enumerate(tail):
-            e = L_[k % N]
-            got = r['Kernel_Name']
-            ok = got == e['symbol'] or norm(got) == norm(dm[e['symbol']]) or norm(got).split('(')[0] == norm(dm[e['symbol']]).split('(')[0]
-            assert ok, f"dispatch {k} (launch {k % N} of a step): trace has {got!r}, the launch log {e['symbol']!r}"
-        per = [[int(r['End_Timestamp']) - int(r['Start_Timestamp']) for r in tail[j::N]] for j in range(N)]
-    else:                                # lanes: dispatch order differs; join per symbol by multiset (class totals stay exact per symbol)
-        raise SystemExit("join: multi-lane traces are joined per symbol only; use the single-stream run for the class table")
+    if m['multi_lane']:                  # lanes: dispatch order differs from enqueue order
+        raise SystemExit("join: use the single-stream run for the class table")
+    rows.sort(key=lambda r: int(r['Start_Timestamp']))       # one stream: start order = enqueue order
+    base = lambda s: friendly(s) if s.startswith('_Z') else re.match(r'(?:void\s+)?([A-Za-z0-9_:]+)', s).group(1)
+
+    def same(got, sym):                  # rocprofv3 prints some names mangled and some demangled (with its own template spelling)
+        return got == sym or base(got) == base(sym)
+    # the replays: the last `steps` runs of N dispatches that start with the step's first kernel, N apart
+    firsts = [i for i, r in enumerate(rows) if same(r['Kernel_Name'], L_[0]['symbol'])]
+    starts = [i for i in firsts if i + N <= len(rows)][-steps:]
+    assert len(starts) == steps and all(b - a == N for a, b in zip(starts, starts[1:])), (len(rows), N, starts[-4:])
+    per = [[] for _ in range(N)]
+    for s0 in starts:
+        for j in range(N):
+            r = rows[s0 + j]
+            assert same(r['Kernel_Name'], L_[j]['symbol']), f"launch {j} of a step: trace has {r['Kernel_Name']!r}, the launch log {L_[j]['symbol']!r}"
+            per[j].append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
     with open(a.out + '_launches.csv', 'w', newline='') as f:
         w = csv.writer(f)
         w.writerow(['launch', 'class', 'op', 'symbol', 'flops', 'avg_us', 'min_us', 'max_us', 'replays'])

@@ -2,7 +2,7 @@
 # Round profiles of the headline bench (run on the GPU box through gpurun; outputs under gpurun_out/profiles_<tag>/, the
 # summaries are copied into profiles/ afterwards): kernel-trace statistics and separate PMC passes (FETCH_SIZE, WRITE_SIZE,
 # SQ_*), exactly the command the driver runs with fewer steps.
-tag=${1:-r02}
+tag=${1:-r05}
 out=$GRAFT_REPO_ROOT/gpurun_out/profiles_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
@@ -13,6 +13,10 @@ python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline > $out/bench_p16.json 2> $ou
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o s -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --repeats 1 --no-cpu-baseline --sustain 0 --no-roofline > $out/bench_under_rocprof.json 2>> $out/bench.err
 # the same with every launch on ONE stream (--single-stream): per-kernel durations without the other lanes' kernels sharing the chip
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats1 -o s1 -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --repeats 1 --no-cpu-baseline --sustain 0 --no-roofline --single-stream > $out/bench_single_stream_under_rocprof.json 2>> $out/bench.err
+# per-CLASS table of the replayed single-stream step: every launch with its bench.py class label and algorithmic FLOPs beside the measured
+# duration (tools/class_profile.py joins the library's launch log with the kernel trace, symbol by symbol)
+rocprofv3 --kernel-trace --output-format csv -d $out/cls -o t -- python3 $GRAFT_REPO_ROOT/tools/class_profile.py run --map $out/launch_map.json --steps 20 > $out/class_profile_run.log 2>&1
+python3 $GRAFT_REPO_ROOT/tools/class_profile.py join $out/cls/t_kernel_trace.csv $out/launch_map.json $out/${tag}_bench_p16_single_stream > $out/class_profile_join.log 2>&1
 cp $out/stats/s_kernel_stats.csv $out/${tag}_bench_p16_kernel_stats.csv
 cp $out/stats1/s1_kernel_stats.csv $out/${tag}_bench_p16_kernel_stats_single_stream.csv
 # CycleGAN 256x256 batch 1 (BASELINE.json configs[3] per-GPU shape): the two-chain schedule under the same profiler
