@@ -405,7 +405,10 @@ __device__ __forceinline__ void conv_gemm_body(const GemmParams& p, unsigned cha
   constexpr int AI = (AINS + NW - 1) / NW, BI = (BINS + NW - 1) / NW;  // per wave
   constexpr int STAGE = (BM + BN) * BKB;
   constexpr int KSTEPS = BKB / 64;                       // 64-byte MFMA k-steps per row
-  static_assert(NS == 2 || (AINS % NW == 0 && BINS % NW == 0), "counted vmcnt needs equal pieces per wave");
+  // counted vmcnt needs the same number of pieces from every wave: a tile with fewer A pieces than waves (16 rows: 2 pieces, 4 waves)
+  // lets the other waves fetch the same pieces again (identical bytes to the same LDS rows)
+  constexpr bool AWRAP = NS > 2 && AINS < NW && NW % AINS == 0;
+  static_assert(NS == 2 || ((AINS % NW == 0 || AWRAP) && BINS % NW == 0), "counted vmcnt needs equal pieces per wave");
   // slot swizzle so that the 16 rows of a ds_read_b128 fragment read hit 16 distinct 16-B bank groups
   auto fsw = [](int row) { return BKB == 128 ? (row & 7) : ((0 - (row >> 2)) & 3); };
 
@@ -445,9 +448,10 @@ __device__ __forceinline__ void conv_gemm_body(const GemmParams& p, unsigned cha
     const int m = bm0 + row;
     int off = (int)0x80000000;
     if (m < p.M) {
-      const int gx = m % p.Wg;
-      const int t = m / p.Wg;
-      const int gy = t % p.Hg, img = t / p.Hg;
+      const unsigned t = fdiv((unsigned)m, p.divWg);      // (multiply-high division: four runtime integer divisions per entry were ~1 us per block)
+      const int gx = m - (int)t * p.Wg;
+      const unsigned img = fdiv(t, p.divHg);
+      const int gy = (int)t - (int)img * p.Hg;
       const int ty = tap >> p.TWlog2, tx = tap & twmask;
       const int sy = gy * p.S + dy0 + ty * p.dstep, sx = gx * p.S + dx0 + tx * p.dstep;
       if ((unsigned)sy < (unsigned)p.Hs && (unsigned)sx < (unsigned)p.Ws)
@@ -485,7 +489,10 @@ __device__ __forceinline__ void conv_gemm_body(const GemmParams& p, unsigned cha
     }
     const int* trow = tbl + tap * BM + lrow;
 #pragma unroll
-    for (int i = 0; i < AI; ++i) va[i] = (wave + NW * i < AINS) ? trow[(wave + NW * i) * RPI] + coffB : (int)0x80000000;
+    for (int i = 0; i < AI; ++i) {
+      const int ia = AWRAP ? (wave + NW * i) % AINS : wave + NW * i;
+      va[i] = (ia < AINS) ? trow[ia * RPI] + coffB : (int)0x80000000;
+    }
     const int ty = tap >> p.TWlog2, tx = tap & twmask;
     const int wofs = ((wy0 + ty * p.wstep) * 4 + (wx0 + tx * p.wstep)) * wtapbytes + coffB;
 #pragma unroll
@@ -494,7 +501,7 @@ __device__ __forceinline__ void conv_gemm_body(const GemmParams& p, unsigned cha
   auto fire = [&](int idx, int stage) {
     unsigned char* As = smem + stage * STAGE;
     if (idx < AI) {
-      const int ia = wave + NW * idx;
+      const int ia = AWRAP ? (wave + NW * idx) % AINS : wave + NW * idx;
       if (ia < AINS)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(As + ia * 1024), 16, va[idx], 0, 0, COH ? 0x11 : 0);
     } else {
@@ -1960,9 +1967,14 @@ __global__ __launch_bounds__(256) void splitk_norm_kernel(const GemmParams p, in
 // pipeline shape per tile (measured): 128-byte K rows and 2 stages for the 8-wave 256-row tiles (one block per CU),
 // 64-byte rows for 256x64 and 2 stages for 128x128 so that two blocks share a CU, 3 stages with counted vmcnt for the
 // 4-wave 128x64 / 64x128 tiles.
+#ifndef GAN_NS64
+#define GAN_NS64 3        // stages of the 64x128 tile (experiment hook: -DGAN_NS64=2)
+#endif
 static constexpr int cfg_bkb(int BM, int BN) { return (BM == 256 && BN == 64) ? 64 : 128; }   // 256x64: two blocks per CU
 static constexpr int cfg_ns(int BM, int BN) {
-  return BM == 256 ? 2 : (BM == 128 && BN == 128) ? 2 : ((BM == 128 && BN >= 64) || (BM == 64 && BN == 128)) ? 3 : 2;
+  // (round 5: 5 stages on the <= 64-row tiles - every K tile of a 32-way split block in flight at once - measured +-0 / -6 % on those
+  // kernels alone and -2 % on the step: at 127 KB of LDS a block no longer shares its CU with the other lanes' kernels)
+  return BM == 256 ? 2 : (BM == 128 && BN == 128) ? 2 : (BM == 128 && BN >= 64) ? 3 : (BM == 64 && BN == 128) ? GAN_NS64 : 2;
 }
 
 struct GemmPlan {
@@ -2541,6 +2553,10 @@ int gan_conv_stack_plan(const GanConvDesc* const* descs, const int32_t* ops, int
   h->magic = STACK_MAGIC; h->n = (uint32_t)n; h->dtype = (uint32_t)descs[0]->dtype; h->smem = smem;
   int grid = gan_opt("conv.stack_blocks");
   if (grid < 8) grid = 8;
+  // every workgroup of the grid must be RESIDENT (the grid barriers spin): at most two 256-thread workgroups of this kernel fit on a CU
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+  if (grid > 2 * cus) return GAN_E_ARG;
   h->grid = (uint32_t)(grid & ~7);
   return 0;
 }

@@ -159,7 +159,8 @@ class CycleGAN(GAN):
         return run_epochs(self.config['epochs'], list(cyclegan_losses()), lambda: self._zipped(train_X, train_Y),
                           lambda: self._zipped(val_X, val_Y), self.train_step, save, sample,
                           ('Total X->Y Generator Loss', 'Discriminator Y Loss'),
-                          epoch_mean=lambda acc, n: ddp.mean_over_ranks(acc, n, self.dist))
+                          epoch_mean=lambda acc, n: ddp.mean_over_ranks(acc, n, self.dist),
+                          after_pass=(self.ctx.assert_no_stack_timeout if self.ctx.use_stacks else None))
 
     def predict(self, predict_ds, output_path: str):
         plot_path = os.path.join(output_path, 'prediction_images')

@@ -46,7 +46,20 @@ class LaneStream(torch.cuda.Stream):
     `Ctx.assert_lanes_joined()` runs before every capture ends."""
     open_in_capture = False
 
-    def wait_stream(self, stream):
+    def wait_stream(self, stream, _join=False):
+        """Inside a capture two patterns end in a host segfault inside hipStreamEndCapture on ROCm 7.2 (tools/capture_fork_probe.py,
+        profiles/r04_capture_fork_probe.txt) and are refused here instead: FORKING a lane from a lane that is itself forked and still
+        open (every side lane must be forked from the origin stream), and edges in BOTH directions between two open lanes.  One-way
+        cross-waits between lanes that are already forked (the CycleGAN chains' event waits) are fine."""
+        src_open = isinstance(stream, LaneStream) and stream.open_in_capture
+        if src_open and not _join:        # (Ctx.join: a lane that collects another lane's work is the schedule's own business)
+            if not self.open_in_capture:
+                raise L.GanAmdError("step schedule bug: a lane forked from a forked lane (every side lane must be forked from the origin stream: "
+                                    "hipStreamEndCapture crashes on nested forks, DESIGN.md section 5)")
+            if self in stream.__dict__.get('_waits_on', ()):
+                raise L.GanAmdError("step schedule bug: two forked lanes wait on each other in both directions (hipStreamEndCapture crashes, "
+                                    "DESIGN.md section 5)")
+            self.__dict__.setdefault('_waits_on', set()).add(stream)
         if torch.cuda.is_current_stream_capturing() or getattr(stream, 'open_in_capture', False):
             self.open_in_capture = True
         return super().wait_stream(stream)
@@ -95,9 +108,13 @@ class Ctx:
 
     def join(self, waiter, lane):
         """`waiter` waits for everything queued on `lane` (the join of a fork made with lane.wait_stream)."""
-        waiter.wait_stream(lane)
+        if isinstance(waiter, LaneStream):
+            waiter.wait_stream(lane, _join=True)
+        else:
+            waiter.wait_stream(lane)
         if isinstance(lane, LaneStream) and not getattr(waiter, 'open_in_capture', False):
             lane.open_in_capture = False          # joined into the capturing (or an already joined) stream
+            lane.__dict__.pop('_waits_on', None)
 
     def assert_lanes_joined(self):
         bad = [i + 1 for i, s in enumerate(self.side) if s.open_in_capture]

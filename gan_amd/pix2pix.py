@@ -161,7 +161,8 @@ class Pix2Pix(GAN):
             save = sample = (lambda *a: None)
         return run_epochs(self.config['epochs'], list(pix2pix_losses()), lambda: train_ds, lambda: val_ds, self.train_step,
                           save, sample, ('Generator Total Loss', 'Discriminator Loss'),
-                          epoch_mean=lambda acc, n: ddp.mean_over_ranks(acc, n, self.dist))
+                          epoch_mean=lambda acc, n: ddp.mean_over_ranks(acc, n, self.dist),
+                          after_pass=(self.ctx.assert_no_stack_timeout if self.ctx.use_stacks else None))
 
     def predict(self, predict_ds, output_path: str):
         plot_path = os.path.join(output_path, 'prediction_images')

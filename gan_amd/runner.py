@@ -92,7 +92,7 @@ def plot_loss_curves(train: dict, val: dict, model_name: str, out_dir: str) -> N
         plt.close(fig)
 
 
-def run_epochs(epochs: int, keys, train_batches, val_batches, step, on_checkpoint, on_sample, headline, epoch_mean=None):
+def run_epochs(epochs: int, keys, train_batches, val_batches, step, on_checkpoint, on_sample, headline, epoch_mean=None, after_pass=None):
     """Epoch driver.  train_batches()/val_batches() yield the positional arguments of `step(*args, training)`, which
     returns the per-step loss tensors (device); `headline` = (train key, val key) printed per epoch.
     epoch_mean(acc, n) -> mean loss vector of a pass (data-parallel runs: over all ranks' steps, gan_amd.ddp.mean_over_ranks).
@@ -111,6 +111,8 @@ def run_epochs(epochs: int, keys, train_batches, val_batches, step, on_checkpoin
                     print('.', end='', flush=True)
             mean = epoch_mean(acc, n) if epoch_mean is not None else ((acc / n) if n else None)
             sums.append(mean.cpu().tolist() if mean is not None else [float('nan')] * len(keys))      # one drain per pass
+            if after_pass is not None:
+                after_pass()          # device-side error flags are read where the pass has been drained anyway (layer stacks: grid-barrier timeout)
         for h, means in zip(hist, sums):
             for k, v in zip(keys, means):
                 h[k].append(v)

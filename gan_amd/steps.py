@@ -327,7 +327,7 @@ class Pix2PixStep(_StepBase):
             main, lane2 = self.ctx.lane_stream(0), self.ctx.lane_stream(2)
             if phase == 1 and self.ctx.lanes:   # data-parallel, phased: D's parameter pass is phase 2 (beside G's all-reduce)
                 lane3 = self.ctx.lane_stream(3)
-                g.wgrad_stream, g.wgrad_cuts = lane3, [8]
+                g.wgrad_stream, g.wgrad_cuts, g.wgrad_stream2 = lane3, [8], None
                 g.backward(use_dgen2=True, defer_wgrads='staged')
                 self.ctx.join(main, lane3)
             elif phase == 1:

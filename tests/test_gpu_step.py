@@ -659,6 +659,38 @@ def test_capture_guard_reports_an_unjoined_lane():
     assert float(buf[0]) == 1.0
 
 
+def test_lane_rules_refuse_the_patterns_that_crash_capture_end():
+    """hipStreamEndCapture segfaults on ROCm 7.2 when a lane is forked from a forked lane or when two forked lanes depend on each other
+    in both directions (tools/capture_fork_probe.py, profiles/r04_capture_fork_probe.txt).  LaneStream.wait_stream refuses both BEFORE
+    the runtime sees them (GanAmdError, nothing enqueued); a one-way cross-wait between two forked lanes is accepted."""
+    from gan_amd import _lib as L
+    from gan_amd.nets import Ctx
+    ctx = Ctx('cuda:0', 'bf16')
+    buf = torch.zeros(1024, device=ctx.device)
+    main = torch.cuda.Stream(device=ctx.device)
+    a, b, c = ctx.lane_stream(2), ctx.lane_stream(3), ctx.lane_stream(4)
+    main.wait_stream(torch.cuda.current_stream())
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(main):
+        with torch.cuda.graph(g, stream=main):
+            cur = torch.cuda.current_stream()
+            a.wait_stream(cur); b.wait_stream(cur)              # two lanes forked from the origin stream
+            with torch.cuda.stream(a):
+                buf.add_(1.0)
+            with pytest.raises(L.GanAmdError, match="forked from a forked lane"):
+                c.wait_stream(a)                                # nested fork
+            b.wait_stream(a)                                    # one-way edge between two forked lanes: fine
+            with torch.cuda.stream(b):
+                buf.add_(1.0)
+            with pytest.raises(L.GanAmdError, match="both directions"):
+                a.wait_stream(b)                                # ... and back: refused
+            ctx.join(cur, a); ctx.join(cur, b)
+            ctx.assert_lanes_joined()
+    g.replay()
+    torch.cuda.synchronize()
+    assert float(buf[0]) == 2.0
+
+
 def _plans_of(ops):
     return [o[3]['kernel'] for o in ops if len(o) > 3 and isinstance(o[3], dict)]
 
