@@ -57,6 +57,7 @@ Opt g_opts[] = {
     {"wgrad.fold_split_target", {512}},    // tap-folded (8-channel) layers: blocks wanted (each writes a 32 KB slab tile; 1024 before round 4: 46 -> 40 us per step for the two launches, 256: 57)
     {"wgrad.reduce_adam_min_params", {1 << 20}},
     {"wgrad.reduce_adam", {1}},     // GanAdamFuse on split launches: the slab reduce ends in the optimiser step
+    {"wgrad.adam_halves_max_rows", {0}},   // GanAdamFuse epilogue: launches with at most this many reduction rows put the two halves of a tile on two workgroups
     {"wgrad.dead_taps", {1}},       // GanAdamFuse epilogue: blocks of taps that never meet the map (2x2 -> 1x1 layers) skip the update where m == v == 0
     {"diag.launch_log", {0}},       // record the kernel symbol of every launch (gan_launch_log; profiling tools)
 };

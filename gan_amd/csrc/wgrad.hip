@@ -512,6 +512,10 @@ static int plan_wgrad(const GanWgradDesc* d, WgradPlan* pl, bool allow_swap = tr
       }
       if (p.dead_taps && M <= 64) p.ahalves = 2;
     }
+    // a launch with a short reduction is the optimiser step with a few MFMAs in front: one 128 x 128 tile per workgroup is 256 workgroups
+    // for a 4.2 M-parameter kernel - one per CU, every phase of the epilogue exposed; with the tile's two 64-row halves on two workgroups
+    // (each repeats the small GEMM) two of them share a CU and overlap
+    if (M <= gan_opt("wgrad.adam_halves_max_rows")) p.ahalves = 2;
   }
   pl->TA = TA; pl->TB = TB;
   pl->grid = dim3((unsigned)(tilesA * tilesB), (unsigned)taps, (unsigned)(p.ahalves == 2 ? 2 : splits));

@@ -230,6 +230,7 @@ class Pix2PixStep(_StepBase):
     early_adam = False           # Adam + NK refresh of a stage's kernels on lane 4 as soon as its wgrads are done: +1.5 % in round 2,
     adam_lane = 4                # -0.5 % since the step became work-bound (round 3; adam_lane 3 = behind the wgrads on their lane: same)
     wgrad_cuts = (4, 8, 12)      # G's wgrad GEMMs in four coarse stages: up7..up4 | up3..up0 | down7..4 | down3..0 (finer: -3 %)
+    d_wgrad_concurrent = 0       # planner hint of D's wgrad launches (GanWgradDesc.concurrent; 1: half-chip ping-pong plans with longer reductions)
     wgrad_alt = ('down3.kernel', 'down2.kernel', 'down1.kernel', 'down0.kernel')   # kernels of G whose wgrad launches run on a SECOND wgrad lane
                                  # (lane 4, own slab workspace): the last stage's GEMMs beside the optimiser-carrying (HBM-bound) launches of the
                                  # stage before instead of behind them: +1.0 % (5,363 -> 5,421 img/s, two interleaved pairs)
@@ -278,6 +279,8 @@ class Pix2PixStep(_StepBase):
         B, Cc, g, d = self.B, self.C, self.g, self.d
         if not g._bwd_cache:
             g.alt_wgrad = frozenset(self.wgrad_alt)       # (settled before the first backward op list is built)
+            if not d._cache:
+                d._bd2.wgrad_concurrent = int(self.d_wgrad_concurrent)
         if phase == 2:
             d.backward_params()
             return self.losses

@@ -11,6 +11,9 @@ def friendly(sym):
     m = re.match(r'_Z19conv_gemm_p[pst]_kernelI(DF16b|DF16_|f)Li(\d+)E', sym)     # ping-pong, tap-shared and table-driven forms: one class per tile
     if m:
         return f"conv_gemm<{ {'DF16b': 'bf16', 'DF16_': 'f16', 'f': 'f32'}[m.group(1)] },256,{m.group(2)}>"
+    m = re.match(r'_Z15conv_par_kernelI(DF16b|DF16_)', sym)                        # parity-patch kernel: bench.py reports it as a 1024 x 64 tile
+    if m:
+        return f"conv_gemm<{ {'DF16b': 'bf16', 'DF16_': 'f16'}[m.group(1)] },1024,64>"
     m = re.match(r'_Z16conv_gemm_kernelI(DF16b|DF16_|f)Li(\d+)ELi(\d+)E', sym)
     if m:
         return f"conv_gemm<{ {'DF16b': 'bf16', 'DF16_': 'f16', 'f': 'f32'}[m.group(1)] },{m.group(2)},{m.group(3)}>"
