@@ -67,7 +67,10 @@ def gemm_profile(step, inputs, reps=5):
             a_.record(); b_.record()
             pairs.append((a_, b_))
         torch.cuda.synchronize()
-        gemm_profile.bracket_ms = sorted(a_.elapsed_time(b_) for a_, b_ in pairs)[len(pairs) // 2]
+        # (an empty bracket is two event packets processed back to back; around a kernel the first packet is processed while the previous
+        # kernel drains, so ONE packet - half the empty bracket - is what a bracket adds to the kernel it encloses: with it the class times
+        # agree with the rocprofv3 kernel durations of the same launches to ~1 %, without it they read 5-7 % long)
+        gemm_profile.bracket_ms = 0.5 * sorted(a_.elapsed_time(b_) for a_, b_ in pairs)[len(pairs) // 2]
         ctx.run = timed_run
         for _ in range(reps):
             step._run(*inputs, training=True)
@@ -104,80 +107,74 @@ def read_sclk_mhz(index=0):
     return best
 
 
-def cpu_baseline(budget_s=20.0):
-    """The numpy oracle's pix2pix_train_step (the CPU restatement of the reference path; the TF reference
-    itself is not installable here) on this box's host cores: 256x256, batch 1 (BASELINE config 1).  Both legs pick their thread
-    count from a short sweep first: with every core of a 128-core host the BLAS / ATen pools oversubscribe (eager PyTorch-CPU 0.36
-    img/s at 128 threads against 2.4 at 16, tools/cpu_threads_sweep.py); `cores` is the count the reported figure ran with."""
+CPU_BASELINE_THREADS = 16       # eager PyTorch-CPU train_step on the 128-core host: 1.53 / 2.42 / 1.69 / 1.07 / 0.36 img/s at 8 / 16 / 32 / 64 /
+                                # 128 threads (tools/cpu_threads_sweep.py): every core oversubscribes the BLAS / ATen pools
+
+
+def cpu_baseline_worker(budget_s=20.0):
+    """Runs in a CHILD process whose BLAS / OpenMP pools were sized by the environment (cpu_baseline below): the numpy oracle's
+    pix2pix_train_step (the CPU restatement of the reference path; the TF reference itself is not installable here) and the same graph
+    as eager PyTorch-CPU autograd, 256x256, batch 1 (BASELINE config 1).  Prints one JSON line."""
     from oracle import gan_oracle as O
+    threads = int(os.environ.get('OMP_NUM_THREADS', os.cpu_count() or 1))
     Gp, Dp = O.init_generator(1, seed=11), O.init_discriminator(1, True, seed=12)
     optG, optD = O.AdamTF(), O.AdamTF()
     inp, tar = O.synthetic_pair(1, 256, 1, seed=123)
     masks = O.dropout_masks(1, 256, seed=5)
-    ncpu = os.cpu_count() or 1
-    cands = sorted({c for c in (8, 16, 32, ncpu) if c <= ncpu})
-    try:
-        from threadpoolctl import threadpool_limits
-    except Exception:
-        threadpool_limits = None
-
-    def oracle_step():
+    O.pix2pix_train_step(Gp, Dp, optG, optD, inp, tar, 100.0, masks, True)       # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
         O.pix2pix_train_step(Gp, Dp, optG, optD, inp, tar, 100.0, masks, True)
-
-    def limited(n):
-        import contextlib
-        return threadpool_limits(limits=n) if threadpool_limits is not None else contextlib.nullcontext()
-    oracle_step()                                                               # warm-up
-    best_n, best_t = cands[-1], None
-    if threadpool_limits is not None and len(cands) > 1:
-        for c in cands:
-            with limited(c):
-                t0 = time.perf_counter(); oracle_step(); dtc = time.perf_counter() - t0
-            if best_t is None or dtc < best_t:
-                best_n, best_t = c, dtc
-    with limited(best_n):
-        n, t0 = 0, time.perf_counter()
-        while True:
-            oracle_step()
-            n += 1
-            dt = time.perf_counter() - t0
-            if dt > budget_s or n >= 50:
-                break
-    out = {"value": round(n / dt, 4), "unit": "images/sec", "cores": int(best_n if threadpool_limits is not None else ncpu), "kind": "port",
-           "sample": f"{n} train_steps of the numpy oracle (fp32), Pix2Pix 256x256 batch 1, {dt:.1f} s, BLAS threads chosen from {cands}"}
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt > budget_s or n >= 50:
+            break
+    out = {"value": round(n / dt, 4), "unit": "images/sec", "cores": threads, "kind": "port",
+           "sample": f"{n} train_steps of the numpy oracle (fp32), Pix2Pix 256x256 batch 1, {dt:.1f} s, {threads} BLAS threads"}
     # second stand-in SURVEY.md 8(d) names: the same graph as eager PyTorch-CPU autograd (oracle/torch_ref.py), fp32
     try:
         from oracle import torch_ref as TR
+        torch.set_num_threads(threads)
         Gt, Dt = TR.params(Gp, torch.float32), TR.params(Dp, torch.float32)
         ti, tt = TR.t(inp, torch.float32), TR.t(tar, torch.float32)
         mt = [TR.t(m, torch.float32) for m in masks]
         state = {}
-        step = lambda: TR.pix2pix_train_step_eager(Gt, Dt, state, ti, tt, 100.0, mt)
-        threads0 = torch.get_num_threads()
-        bt, bn = None, threads0
-        for c in cands:
-            torch.set_num_threads(c)
-            step()
-            t0 = time.perf_counter(); step(); dtc = time.perf_counter() - t0
-            if bt is None or dtc < bt:
-                bt, bn = dtc, c
-        torch.set_num_threads(bn)
+        TR.pix2pix_train_step_eager(Gt, Dt, state, ti, tt, 100.0, mt)
         n2, t0 = 0, time.perf_counter()
         while True:
-            step()
+            TR.pix2pix_train_step_eager(Gt, Dt, state, ti, tt, 100.0, mt)
             n2 += 1
             dt2 = time.perf_counter() - t0
             if dt2 > budget_s / 2 or n2 >= 50:
                 break
-        torch.set_num_threads(threads0)
-        out["torch_cpu_eager"] = {"value": round(n2 / dt2, 4), "unit": "images/sec", "cores": int(bn),
-                                  "sample": f"{n2} eager PyTorch-CPU train_steps (fp32 autograd + TF-form Adam), batch 1, {dt2:.1f} s, threads chosen from {cands}"}
+        out["torch_cpu_eager"] = {"value": round(n2 / dt2, 4), "unit": "images/sec", "cores": threads,
+                                  "sample": f"{n2} eager PyTorch-CPU train_steps (fp32 autograd + TF-form Adam), batch 1, {dt2:.1f} s"}
     except Exception as e:      # the baseline is a report, not a gate
         out["torch_cpu_eager"] = {"error": repr(e)}
-    return out
+    print(json.dumps(out), flush=True)
+
+
+def cpu_baseline(budget_s=20.0, timeout_s=100.0):
+    """The CPU legs in a child process (never touches the GPU) with its thread pools sized by the environment - setting thread counts
+    inside a process that has already run parallel regions is fragile - and a hard time limit: the baseline is a report, not a gate."""
+    threads = max(1, min(CPU_BASELINE_THREADS, os.cpu_count() or 1))
+    env = dict(os.environ, OMP_NUM_THREADS=str(threads), OPENBLAS_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads),
+               HIP_VISIBLE_DEVICES='', CUDA_VISIBLE_DEVICES='', ROCR_VISIBLE_DEVICES='')
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-baseline-worker', str(budget_s)], env=env, capture_output=True,
+                           text=True, timeout=timeout_s)
+        lines = [ln for ln in r.stdout.strip().split('\n') if ln.startswith('{')]
+        if r.returncode == 0 and lines:
+            return json.loads(lines[-1])
+        return {"error": f"cpu baseline worker rc={r.returncode}: {r.stderr.strip()[-300:]}", "kind": "port"}
+    except subprocess.TimeoutExpired:
+        return {"error": f"cpu baseline worker exceeded {timeout_s:.0f} s", "kind": "port"}
 
 
 def main():
+    if len(sys.argv) >= 2 and sys.argv[1] == '--cpu-baseline-worker':      # child of cpu_baseline(): CPU only
+        cpu_baseline_worker(float(sys.argv[2]) if len(sys.argv) > 2 else 20.0)
+        return
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=50)
