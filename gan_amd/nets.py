@@ -966,10 +966,11 @@ class GenCall:
         dst = self.xin.view(0, self.C)
         L.check(self.ctx.lib.gan_copy_view(self.ctx.dt, C.byref(src_view), C.byref(dst), self.ctx.stream()), "copy_view")
 
-    def forward(self, inner_hook=None):
+    def forward(self, inner_hook=None, masks_done=False):
         """inner_hook: called when the op list reaches the inner layers (down3): a place to start independent work on
-        another lane that then runs beside the launch-latency-bound part of the generator."""
-        if self.auto_masks:
+        another lane that then runs beside the launch-latency-bound part of the generator.  masks_done: the caller has already
+        enqueued self.mask_ops elsewhere (a side lane) and orders them before the decoder itself."""
+        if self.auto_masks and not masks_done:
             self.ctx.run(self.mask_ops)
         if inner_hook is None:
             self.ctx.run(self.fwd_ops)

@@ -226,6 +226,8 @@ class _StepBase:
 class Pix2PixStep(_StepBase):
     # schedule constants (measured); attributes so that an experiment can change them per object
     dreal_on_side_lane = True    # D(real)'s forward on lane 2 beside the generator's launch-bound inner layers (+0.8 %)
+    head_on_side_lane = False    # ... the discriminator's input packs + the dropout masks on that lane too, at the head of the step: measured
+                                 # +-0 (5,672 / 5,688 / 5,687 with vs 5,695 / 5,682 / 5,707 without: the second launch and the event cost what they save)
     fused_wgrad_adam = True      # captured one-GPU step: the un-split wgrad launches apply Adam to their kernels themselves (GanAdamFuse)
     early_adam = False           # Adam + NK refresh of a stage's kernels on lane 4 as soon as its wgrads are done: +1.5 % in round 2,
     adam_lane = 4                # -0.5 % since the step became work-bound (round 3; adam_lane 3 = behind the wgrads on their lane: same)
@@ -285,9 +287,24 @@ class Pix2PixStep(_StepBase):
             d.backward_params()
             return self.losses
         # inputs -> typed, channel-padded buffers.  D input = concat([inp, tar|gen]) (base_gan.py:139)
-        self._pack_multi([(inp, g.xin.view(0, Cc)), (inp, d.xin.view(0, Cc, 0, B)), (inp, d.xin.view(0, Cc, B, B)),
-                          (tar, d.xin.view(Cc, Cc, 0, B))])
         dreal = self.ctx.lanes and self.dreal_on_side_lane
+        head_split = bool(dreal and self.head_on_side_lane)
+        if head_split:
+            # the serial head of the step: only the generator's own input is needed at once; the discriminator's three input slices and
+            # the dropout masks (first used by up0) are written on lane 2, where D(real) will run anyway, beside down0..down2
+            main_, lane2_ = self.ctx.lane_stream(0), self.ctx.lane_stream(2)
+            self._pack(inp, g.xin.view(0, Cc))
+            lane2_.wait_stream(main_)
+            with torch.cuda.stream(lane2_):
+                self._pack_multi([(inp, d.xin.view(0, Cc, 0, B)), (inp, d.xin.view(0, Cc, B, B)), (tar, d.xin.view(Cc, Cc, 0, B))])
+            masks_side = bool(g.auto_masks)
+            if masks_side:
+                self.ctx.run_on(g.mask_ops, lane2_)
+            head_ev = torch.cuda.Event()
+            head_ev.record(lane2_)
+        else:
+            self._pack_multi([(inp, g.xin.view(0, Cc)), (inp, d.xin.view(0, Cc, 0, B)), (inp, d.xin.view(0, Cc, B, B)),
+                              (tar, d.xin.view(Cc, Cc, 0, B))])
         if dreal:
             # D(real) does not depend on the generator: it starts on lane 2 when G reaches its inner layers (down3 on:
             # launch-bound layers that leave the chip idle; measured best start point, +0.8 %) and D(fake) follows G on the main chain.  Same
@@ -295,9 +312,14 @@ class Pix2PixStep(_StepBase):
             main_, lane2_ = self.ctx.lane_stream(0), self.ctx.lane_stream(2)
 
             def start_dreal():
+                if head_split:
+                    main_.wait_event(head_ev)                        # masks (and the packs) are in place before the decoder needs them
                 lane2_.wait_stream(main_)
                 self.ctx.run_on(d.forward_part_ops(0, lane=2), lane2_)
-            g.forward(inner_hook=start_dreal)                         # pix2pix.py:200
+            if head_split:
+                g.forward(inner_hook=start_dreal, masks_done=masks_side)
+            else:
+                g.forward(inner_hook=start_dreal)                     # pix2pix.py:200
         else:
             g.forward()                                               # pix2pix.py:200
         # generator loss (pix2pix.py:167-188): BCE(1, D(fake)) + lambda * mean|target - gen|; discriminator loss
