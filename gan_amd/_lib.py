@@ -165,6 +165,13 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise GanAmdError(f"{LIB_PATH} not built: the MI355X HIP extension is required (no CPU fallback). "
                           "Run `make -C gan_amd/csrc` or __graft_entry__.build().")
+    # PyTorch-ROCm ships its own libamdhip64: if this library were loaded first it would bind /opt/rocm's copy, torch would then load its
+    # own, and streams / pointers created by one runtime are strangers to the other (every launch: hipErrorNoDevice).  Loading torch
+    # first makes both resolve to ONE runtime.  (No torch in the process, e.g. the plain C caller: nothing to order.)
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)       # AttributeError if the library does not export it
