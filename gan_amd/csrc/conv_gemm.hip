@@ -1631,9 +1631,18 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p, 
 template <typename T>
 __global__ __launch_bounds__(256) void splitk_reduce4_kernel(const GemmParams p, int P) {
   const int c4 = p.Cout >> 2;
-  long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-  long long total = (long long)P * p.M * c4;
-  if (idx >= total) return;
+  const long long total = (long long)P * p.M * c4;
+  // With fused statistics a workgroup walks RG consecutive groups of RB = 256 / c4 whole rows (all of one parity and one statistics group:
+  // the planner guarantees it) and emits ONE chunk of partial sums for them: RG = 1 gave one chunk per 2 rows of a 512-channel layer,
+  // thousands per launch, and the planner then left the statistics to a separate pass over the tensor (round 5).
+  const int RG = p.stats ? p.stats_rg : 1;
+  float acc8[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc8[e] = 0.f;
+  int m_first = 0, par_first = 0;
+  for (int it = 0; it < RG; ++it) {
+  const long long idx = ((long long)blockIdx.x * RG + it) * 256 + threadIdx.x;
+  if (idx >= total) { if (p.stats) break; return; }
   const int n = (int)(idx % c4) * 4;
   long long t = idx / c4;
   const int m = (int)(t % p.M);
@@ -1675,7 +1684,7 @@ __global__ __launch_bounds__(256) void splitk_reduce4_kernel(const GemmParams p,
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = rf[e] > 0.f ? v[e] : v[e] * p.bf_slope;
     } else {
-      const int RBq = 256 / c4, grp = (m / RBq) / p.stats_tpg;
+      const int RBq = (256 / c4) * RG, grp = (m / RBq) / p.stats_tpg;
       float mk[4] = {1.f, 1.f, 1.f, 1.f};
       if (p.bf_mode == 3) {
         const uint32_t w = *(const uint32_t*)(p.bf_mask + pix * (size_t)p.bf_maskpitch + n);
@@ -1697,33 +1706,39 @@ __global__ __launch_bounds__(256) void splitk_reduce4_kernel(const GemmParams p,
   }
   if (p.out_f32) *(f32x4*)((float*)p.y + o) = f32x4{v[0], v[1], v[2], v[3]};
   else *(uint2*)((T*)p.y + o) = make_uint2(pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]));
+  if (it == 0) { m_first = m; par_first = par; }
   if (p.stats) {
-    // fused normalisation statistics of a split-K layer: a block covers RB = 256 / c4 whole rows of one parity and
-    // one statistics group (the planner guarantees it); per-channel (sum, sum^2) of the STORED values over those
-    // rows = one chunk, laid out like the tile partials of the unsplit epilogue: [group][chunk][C][2]
-    // (fused backward epilogue: (sum dz, sum dz*xhat) of the channels < bf_cols instead)
-    __shared__ float red[256][8];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const float w = p.out_f32 ? v[e] : (float)(T)v[e];                  // as stored (bf16-rounded on the fast path)
-      red[threadIdx.x][2 * e] = p.bf_mode ? v[e] : w; red[threadIdx.x][2 * e + 1] = p.bf_mode ? sx[e] : w * w;
+      acc8[2 * e] += p.bf_mode ? v[e] : w; acc8[2 * e + 1] += p.bf_mode ? sx[e] : w * w;
     }
+  }
+  }   // row groups
+  if (p.stats) {
+    // fused normalisation statistics of a split-K layer: per-channel (sum, sum^2) of the STORED values over the workgroup's RG * RB rows
+    // = one chunk, laid out like the tile partials of the unsplit epilogue: [group][chunk][C][2]
+    // (fused backward epilogue: (sum dz, sum dz*xhat) of the channels < bf_cols instead)
+    __shared__ float red[256][8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[threadIdx.x][e] = acc8[e];
     __syncthreads();
     const int RB = 256 / c4;
     if ((int)threadIdx.x < c4) {
-      float acc8[8];
+      float tot8[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) acc8[e] = 0.f;
+      for (int e = 0; e < 8; ++e) tot8[e] = 0.f;
       for (int rr = 0; rr < RB; ++rr)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc8[e] += red[rr * c4 + threadIdx.x][e];
-      const int mb = m / RB;                                   // this thread's row is the block's first row
-      const int rpb = p.stats_tpg;                             // row blocks per group (per parity)
-      const int grp = mb / rpb, chunk = (mb % rpb) * P + par;
-      float* dst = p.stats + (((size_t)grp * rpb * P + chunk) * p.stats_C + n) * 2;
-      if (n < p.stats_C) {
+        for (int e = 0; e < 8; ++e) tot8[e] += red[rr * c4 + threadIdx.x][e];
+      const int n0 = (int)threadIdx.x * 4;
+      const int mb = m_first / (RB * RG);                      // this thread's first row is the workgroup's first row
+      const int rpb = p.stats_tpg;                             // chunks per group (per parity)
+      const int grp = mb / rpb, chunk = (mb % rpb) * P + par_first;
+      float* dst = p.stats + (((size_t)grp * rpb * P + chunk) * p.stats_C + n0) * 2;
+      if (n0 < p.stats_C) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) dst[e] = acc8[e];
+        for (int e = 0; e < 8; ++e) dst[e] = tot8[e];
       }
     }
   }
@@ -2084,7 +2099,7 @@ static int plan_gemm(const GanConvDesc* d, int op, GemmPlan* pl) {
     if (splits > maxsp) splits = maxsp;
   }
   p.splits = splits;
-  p.stats = nullptr; p.stats_tpg = 0; p.stats_C = y.c;
+  p.stats = nullptr; p.stats_tpg = 0; p.stats_C = y.c; p.stats_rg = 1;
   pl->stats_chunks = 0;
   // fused backward epilogue request (GanBwdFuse): validated here, honoured below if this launch shape can carry it
   const GanBwdFuse* bf = d->bwd_fuse;
@@ -2154,11 +2169,18 @@ static int plan_gemm(const GanConvDesc* d, int op, GemmPlan* pl) {
     // split-K layer: the slab-reduce kernel emits the partials (one chunk per 256-thread block = RB whole rows)
     const int c4 = y.c / 4;
     const long long rpg = M / d->stats_groups;
-    if (c4 <= 256 && 256 % c4 == 0 && rpg % (256 / c4) == 0 &&
-        rpg / (256 / c4) * P <= 1024) {        // beyond ~1k chunks the finalize's walk costs more than a separate pass
-      p.stats_tpg = (int)(rpg / (256 / c4));
-      pl->stats_chunks = p.stats_tpg * P;
-      p.stats = d->stats_partial;
+    if (c4 <= 256 && 256 % c4 == 0 && rpg % (256 / c4) == 0) {
+      // one chunk per workgroup = RG groups of RB = 256 / c4 whole rows: the smallest RG <= 16 that brings the launch under ~512 chunks
+      // (beyond ~1k chunks the finalize's walk costs more than a separate pass over the tensor) and still divides the group's rows
+      const long long rb = 256 / c4;
+      int rg = 1;
+      const int rgmax = gan_opt("conv.reduce_stats_rg");
+      while (rg < rgmax && rpg / (rb * rg) * P > 512 && rpg % (rb * rg * 2) == 0) rg *= 2;
+      if (rpg / (rb * rg) * P <= 1024) {
+        p.stats_tpg = (int)(rpg / (rb * rg)); p.stats_rg = rg;
+        pl->stats_chunks = p.stats_tpg * P;
+        p.stats = d->stats_partial;
+      }
     }
   }
   if (bf_mode && !p.skn) {
@@ -2353,7 +2375,8 @@ static int launch_gemm(const GemmPlan& pl, hipStream_t st) {
 #undef SKN_LAUNCH
     } else if (pl.p.vec_store && pl.p.Cout % 4 == 0 && (pl.p.out_f32 || sizeof(T) == 2)) {
       long long total = (long long)pl.P * pl.p.M * (pl.p.Cout / 4);
-      GAN_LAUNCH(splitk_reduce4_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, pl.p, pl.P);
+      const long long per_wg = 256LL * (pl.p.stats ? pl.p.stats_rg : 1);
+      GAN_LAUNCH(splitk_reduce4_kernel<T>, dim3((unsigned)((total + per_wg - 1) / per_wg)), dim3(256), 0, st, pl.p, pl.P);
     } else {
       long long total = (long long)pl.P * pl.p.M * pl.p.Cout;
       GAN_LAUNCH(splitk_reduce_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, pl.p, pl.P);

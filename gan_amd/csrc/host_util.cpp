@@ -44,6 +44,7 @@ Opt g_opts[] = {
     {"conv.bwd_fuse_tile", {1}},    // fused backward epilogue on tile epilogues: 0 never, 1 always (fastest step: round 3 measured +0.5 % / +1 %), 2 not on 64-column tiles, 3 only on them
     {"conv.stack", {0}},            // runs of small split-K layers in one persistent launch (gan_conv_stack_*): OFF - measured 13-16 % slower than the launches it replaces
     {"conv.stack_blocks", {256}},   // ... its resident grid (multiple of 8; at most 2 workgroups per CU fit)
+    {"conv.reduce_stats_rg", {16}}, // split-K slab reduce emitting statistics partials: at most this many row groups per workgroup (1: one chunk per group, as before round 5)
     {"conv.norm_fuse", {1}},        // GanNormFuse: small split-K layers finished by their slab-reduce kernel
     {"conv.thin_fused", {1}},       // thin-N layers with <= 2 output channels in one kernel (Z through LDS instead of memory)
     {"conv.thin", {7}},             // bit 0: streaming kernels at all, bit 1: thin-N, bit 2: thin-K

@@ -397,6 +397,8 @@ const char* gan_version(void);
  * wgrad.pingpong_min_rows (0 = automatic), wgrad.pingpong_128 (1), wgrad.pingpong_min_gflop (30),
  * wgrad.split_target (512), wgrad.fold_split_target (512), wgrad.reduce_adam (1),
  * wgrad.reduce_adam_min_params (1048576: smaller kernels keep the flat slab reduce and the caller's multi-tensor Adam pass),
+ * conv.reduce_stats_rg (16: the slab reduce of a split-K launch that also emits the statistics partials walks up to this many row groups
+ * per workgroup, one chunk each - keeps the chunk count of a 4,096-row 512-channel layer under ~512 so that the fused path is taken),
  * wgrad.dead_taps (1: a fused-Adam wgrad launch skips the taps that never meet the map at its shape - 12 of 16 for a 2x2 -> 1x1
  * layer - where their moments are zero: the update is the identity there), diag.launch_log (0: see gan_launch_log below). */
 int gan_set_option(const char* key, int32_t value);

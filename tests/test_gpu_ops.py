@@ -204,7 +204,10 @@ CONVT_CASES = [  # (N, h, Cin, Cout)
                                   ('convT_fwd', 4, 64, 128, 128, 4),
                                   # split-K layers: the slab-reduce kernel emits the partials
                                   ('conv_fwd', 4, 16, 128, 256, 2), ('convT_fwd', 4, 8, 512, 256, 2), ('conv_fwd', 16, 4, 512, 512, 1),
-                                  ('conv_fwd', 4, 4, 512, 512, 4)])
+                                  ('conv_fwd', 4, 4, 512, 512, 4),
+                                  # ... of several row groups per workgroup (round 5): G.down3 / up3 / up4 forward at batch 16 - 4,096 rows x 512
+                                  # channels was 2,048 chunks of two rows and fell back to a separate statistics pass
+                                  ('conv_fwd', 16, 32, 256, 512, 1), ('convT_fwd', 16, 8, 1024, 512, 1), ('convT_fwd', 16, 16, 1024, 256, 2)])
 def test_conv_epilogue_statistics_partials(ctx, case):
     """Fused normalisation statistics (GanConvDesc.stats_partial): per-channel (sum, sum of squares) of the STORED
     output, summed over the chunks the plan reports, per statistics group (tile partials from the epilogue, or row-block
@@ -271,6 +274,8 @@ FUSE_CASES = [  # (op, N, H of dy, channels of dy, channels of the produced grad
     ('convT_dgrad', 4, 8, 512, 1024, 1, 'relu+mask', 512, False),   # split-K: the slab-reduce kernel carries it
     ('conv_dgrad', 4, 4, 512, 512, 4, 'lrelu', 512, True),          # split-K, InstanceNorm, skip gradient
     ('conv_dgrad', 4, 4, 512, 64, 0, 'act', 64, False),             # split-K, activation only
+    ('convT_dgrad', 16, 32, 256, 1024, 1, 'relu', 512, False),      # G.up4's dgrad at batch 16 (4,096 rows x 1,024 channels, split K): several row groups per chunk
+    ('conv_dgrad', 16, 8, 512, 512, 1, 'lrelu', 512, True),         # G.down4's dgrad: 1,024 x 4 rows, split K, skip gradient
 ]
 
 
