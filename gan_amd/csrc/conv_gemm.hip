@@ -23,6 +23,7 @@
 #include "common.h"
 #include <type_traits>
 #include "conv_params.h"
+#include "splitk_norm.h"
 
 #ifdef GAN_DIAG   // diagnostic build only (tools/diag_build.sh): in-kernel wall-clock stamps per block, 100 MHz ticks
 static unsigned long long* g_diag = nullptr;
@@ -65,17 +66,6 @@ __device__ __forceinline__ void store_out(const GemmParams& p, size_t pix_off, i
   v = apply_act(v, p.act, p.slope);
   if (p.out_f32) ((float*)p.y)[pix_off + n] = v;
   else st_f((T*)p.y + pix_off + n, v);
-}
-
-__device__ __forceinline__ size_t out_pixel_index(const GemmParams& p, int m, int py, int px) {
-  const unsigned t = fdiv((unsigned)m, p.divWg);
-  const int gx = m - t * p.Wg;
-  const unsigned img = fdiv(t, p.divHg);
-  const int gy = t - img * p.Hg;
-  return (size_t)(img * p.Ho + gy * p.OS + py) * p.Wo + (gx * p.OS + px);
-}
-__device__ __forceinline__ size_t out_pixel_offset(const GemmParams& p, int m, int py, int px) {
-  return out_pixel_index(p, m, py, px) * (size_t)p.ypitch;
 }
 
 // Fused backward epilogue (GanBwdFuse): bf_mode = 1 norm+LeakyReLU, 2 norm+ReLU, 3 norm+ReLU+dropout mask, 4 LeakyReLU on the
@@ -126,48 +116,6 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned char* lds_wave
 }
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-
-// Cross-workgroup exchange INSIDE one launch (conv_stack_kernel): the L2s of the 8 XCDs are not coherent with each other, so data
-// that another workgroup reads later in the same kernel is written through (sc0 sc1 stores) and read around the L2 (sc0 sc1 loads)
-// - measured coherent without any cache maintenance (tools/probes/gridbar_probe.hip).  Buffer instructions so that the compiler
-// tracks the stores' data registers (an inline-asm store re-used them too early).  COH = false: plain accesses.
-typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
-typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
-struct CohBuf { __amdgpu_buffer_rsrc_t r; const unsigned char* base; };
-__device__ __forceinline__ CohBuf coh_buf(const void* base) {
-  CohBuf b;
-  b.r = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0xfffffff0u, 0x00020000);
-  b.base = (const unsigned char*)base;
-  return b;
-}
-template <bool COH> __device__ __forceinline__ f32x4 ld_f4(const CohBuf& b, const float* ptr) {
-  if constexpr (COH) {
-    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(b.r, (unsigned)((const unsigned char*)ptr - b.base), 0, 0x11);
-    return f32x4{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
-  } else {
-    return *(const f32x4*)ptr;
-  }
-}
-template <bool COH> __device__ __forceinline__ void st_f4(const CohBuf& b, float* ptr, const f32x4& v) {
-  if constexpr (COH) {
-    const u32x4_t u = u32x4_t{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
-    __builtin_amdgcn_raw_buffer_store_b128(u, b.r, (unsigned)((const unsigned char*)ptr - b.base), 0, 0x11);
-  } else {
-    *(f32x4*)ptr = v;
-  }
-}
-template <bool COH> __device__ __forceinline__ uint2 ld_u2(const CohBuf& b, const void* ptr) {
-  if constexpr (COH) {
-    const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(b.r, (unsigned)((const unsigned char*)ptr - b.base), 0, 0x11);
-    return make_uint2(v.x, v.y);
-  } else {
-    return *(const uint2*)ptr;
-  }
-}
-template <bool COH> __device__ __forceinline__ void st_u2(const CohBuf& b, void* ptr, const uint2& v) {
-  if constexpr (COH) __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{v.x, v.y}, b.r, (unsigned)((const unsigned char*)ptr - b.base), 0, 0x11);
-  else *(uint2*)ptr = v;
-}
 
 // Epilogue shared by the GEMM kernels.  The MFMAs ran with the weights as the "A" operand, so the accumulators hold
 // the transposed tile: acc[i][j][e] = Y[pixel row i*16 + (lane & 15)][channel j*16 + (lane >> 4)*4 + e] - four
@@ -1744,235 +1692,6 @@ __global__ __launch_bounds__(256) void splitk_reduce4_kernel(const GemmParams p,
   }
 }
 
-// ------------------------------------------------------------------------------------------------
-// Slab reduce of a SMALL split-K layer that also finishes the layer (GanNormFuse): a workgroup owns 8 channels of every row of
-// a statistics group (<= 1024 rows: 128 row slots x <= 8 rows per thread, kept in registers), so summing the K slabs, the
-// normalisation statistics and the apply pass need no second launch and no second read.
-//   MODE 1 (forward):  y = sum of slabs (stored); mean, rstd (+ moving averages); out = act(dropout(gamma*(y-mean)*rstd+beta))
-//   MODE 2 (backward): da = sum of slabs (+ add); dz = da * act'(z) * mask with z from the saved y (bf_ref);
-//                      out = gamma*rstd*(dz - sum(dz)/R - xhat*sum(dz*xhat)/R); dgamma, dbeta; channels >= bf_cols: y = da
-// Arithmetic per element = splitk_reduce4_kernel + stats_finalize / bwd_finalize + norm_act_fwd / norm_act_bwd (norm.hip); the
-// per-channel sums are taken in a different (fixed) order.  gridDim.y == groups: one group per workgroup; gridDim.y == 1: the
-// workgroup walks the groups in order (moving averages of successive BatchNormalization calls; dgamma / dbeta over the groups).
-// bx / by / gy: the block coordinates and the y extent of the grid of the stand-alone kernel.  COH (conv_stack_kernel): the slabs and the skip
-// gradient were written earlier in the same launch by other workgroups and the outputs are read later in it: loads around / stores through
-// the L2 (sc0 sc1).
-template <typename T, int MODE, int KR, bool COH>       // KR: rows per thread (1, 2, 4, 8): 128 * KR >= rows per group
-__device__ __forceinline__ void splitk_norm_body(const GemmParams& p, int P, int bx, int by, int gy) {
-  constexpr int RS = 128, UNR = 16 / KR;         // 16 slab loads in flight per thread (a row at a time the kernel is latency-bound)
-  __shared__ double red[4][8][2];
-  __shared__ float bc[8][4];
-  const int tid = threadIdx.x, cv = tid & 1, rs = tid >> 1, lane = tid & 63, wave = tid >> 6;
-  const int n = bx * 8 + cv * 4;
-  const int groups = p.skn_groups, Mg = p.M / groups, Rg = P * Mg;
-  const size_t sstride = (size_t)p.M * p.NslabPitch;
-  const int g0 = gy > 1 ? by : 0, g1 = gy > 1 ? g0 + 1 : groups;
-  const CohBuf cslab = coh_buf(p.slab), cout = coh_buf(p.skn_out), cy = coh_buf(p.y), cadd = coh_buf(p.bf_add);
-  auto ld4 = [](const void* base, size_t off, float* out) {
-    if constexpr (sizeof(T) == 4) { const f32x4 q = *(const f32x4*)((const float*)base + off); out[0] = q[0]; out[1] = q[1]; out[2] = q[2]; out[3] = q[3]; }
-    else { float t8[8]; const uint2 q = *(const uint2*)((const T*)base + off); unpack16<T>(make_uint4(q.x, q.y, 0u, 0u), t8); out[0] = t8[0]; out[1] = t8[1]; out[2] = t8[2]; out[3] = t8[3]; }
-  };
-  auto ld4c = [](const CohBuf& cbuf, const void* base, size_t off, float* out) {     // the same through the coherent path (COH)
-    if constexpr (sizeof(T) == 4) { const f32x4 q = ld_f4<COH>(cbuf, (const float*)base + off); out[0] = q[0]; out[1] = q[1]; out[2] = q[2]; out[3] = q[3]; }
-    else { float t8[8]; const uint2 q = ld_u2<COH>(cbuf, (const T*)base + off); unpack16<T>(make_uint4(q.x, q.y, 0u, 0u), t8); out[0] = t8[0]; out[1] = t8[1]; out[2] = t8[2]; out[3] = t8[3]; }
-  };
-  auto st4 = [](const CohBuf& cbuf, void* base, size_t off, const float* v, bool f32) {
-    if (f32 || sizeof(T) == 4) st_f4<COH>(cbuf, (float*)base + off, f32x4{v[0], v[1], v[2], v[3]});
-    else st_u2<COH>(cbuf, (T*)base + off, make_uint2(pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3])));
-  };
-  // slabs of this kernel's launches: [parity * splits + split][8-channel slice][row][8] (gemm_epilogue, p.skn)
-  auto slab_sum = [&](int par, int m, float* v) {
-    const float* src = p.slab + (size_t)par * p.splits * sstride + ((size_t)bx * p.M + m) * 8 + cv * 4;
-    f32x4 sacc = f32x4{0.f, 0.f, 0.f, 0.f};
-    int k = 0;
-    for (; k + 4 <= p.splits; k += 4) {
-      const f32x4 a = ld_f4<COH>(cslab, src + (size_t)k * sstride), b = ld_f4<COH>(cslab, src + (size_t)(k + 1) * sstride);
-      const f32x4 c = ld_f4<COH>(cslab, src + (size_t)(k + 2) * sstride), d = ld_f4<COH>(cslab, src + (size_t)(k + 3) * sstride);
-      sacc += a; sacc += b; sacc += c; sacc += d;
-    }
-    for (; k < p.splits; ++k) sacc += ld_f4<COH>(cslab, src + (size_t)k * sstride);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = (p.out_f32 || sizeof(T) == 4) ? sacc[e] : (float)(T)sacc[e];      // as stored
-  };
-  // sum of two values per channel over the workgroup's row slots: lanes of equal cv inside a wave, then the 4 waves
-  // (a thread's <= 8 rows are summed in fp32, everything across threads in double, like the finalize kernels of norm.hip)
-  auto block_sums = [&](const float (&f1)[4], const float (&f2)[4], double* t1, double* t2) {     // t1/t2: totals of channel (tid & 7), all threads
-    double s1[4], s2[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      s1[e] = (double)f1[e]; s2[e] = (double)f2[e];
-#pragma unroll
-      for (int o = 2; o < 64; o <<= 1) { s1[e] += __shfl_xor(s1[e], o, 64); s2[e] += __shfl_xor(s2[e], o, 64); }
-    }
-    __syncthreads();                                          // (red is re-used group after group)
-    if (lane < 2) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { red[wave][lane * 4 + e][0] = s1[e]; red[wave][lane * 4 + e][1] = s2[e]; }
-    }
-    __syncthreads();
-    const int c = tid & 7;
-    *t1 = red[0][c][0] + red[1][c][0] + red[2][c][0] + red[3][c][0];
-    *t2 = red[0][c][1] + red[1][c][1] + red[2][c][1] + red[3][c][1];
-  };
-  if (MODE == 2 && bx * 8 >= p.bf_cols) {                     // skip half of a decoder concat: plain gradient
-    for (int row = rs; row < P * p.M; row += RS) {
-      const int par = row / p.M, m = row - par * p.M;
-      float v[4];
-      slab_sum(par, m, v);
-      st4(cy, p.y, out_pixel_index(p, m, par >> 1, par & 1) * (size_t)p.ypitch + n, v, p.out_f32);
-    }
-    return;
-  }
-  double tg = 0, tb = 0;                                       // MODE 2: dgamma / dbeta of channel (tid & 7) over the groups
-  for (int g = g0; g < g1; ++g) {
-    float va[KR][4], vb[KR][4];                                // MODE 1: y | MODE 2: dz, xhat
-    size_t pix[KR];
-    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-    float mu[4], rsd[4], ga[4], be[4];
-    if (MODE == 2) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        mu[e] = p.bf_mean[g * p.bf_cols + n + e]; rsd[e] = p.bf_rstd[g * p.bf_cols + n + e];
-        ga[e] = p.bf_gamma[n + e]; be[e] = p.bf_beta[n + e];
-      }
-    }
-    // slab sums of the thread's KR rows: 16 loads in flight per thread (a row at a time the kernel was latency-bound: 24 us for
-    // 256 KB per workgroup); the splits of a row are added in order, as splitk_reduce4_kernel adds them
-    {
-      const float* src[KR];
-#pragma unroll
-      for (int k = 0; k < KR; ++k) {
-        int row = rs + RS * k;
-        if (row >= Rg) row = rs < Rg ? rs : 0;                 // (clamped: loaded, never used)
-        const int par = row / Mg, m = g * Mg + (row - par * Mg);
-        pix[k] = out_pixel_index(p, m, par >> 1, par & 1);
-        src[k] = p.slab + (size_t)par * p.splits * sstride + ((size_t)bx * p.M + m) * 8 + cv * 4;
-      }
-      f32x4 sacc[KR];
-#pragma unroll
-      for (int k = 0; k < KR; ++k) sacc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-      int sp = 0;
-      for (; sp + UNR <= p.splits; sp += UNR) {
-        f32x4 t[UNR][KR];
-#pragma unroll
-        for (int u = 0; u < UNR; ++u)
-#pragma unroll
-          for (int k = 0; k < KR; ++k) t[u][k] = ld_f4<COH>(cslab, src[k] + (size_t)(sp + u) * sstride);
-#pragma unroll
-        for (int u = 0; u < UNR; ++u)
-#pragma unroll
-          for (int k = 0; k < KR; ++k) sacc[k] += t[u][k];
-      }
-      for (; sp < p.splits; ++sp) {
-#pragma unroll
-        for (int k = 0; k < KR; ++k) sacc[k] += ld_f4<COH>(cslab, src[k] + (size_t)sp * sstride);
-      }
-#pragma unroll
-      for (int k = 0; k < KR; ++k)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) va[k][e] = (p.out_f32 || sizeof(T) == 4) ? sacc[k][e] : (float)(T)sacc[k][e];      // as stored
-    }
-#pragma unroll
-    for (int k = 0; k < KR; ++k) {
-      const int row = rs + RS * k;
-      if (row < Rg) {
-        if (MODE == 1) {
-          st4(cy, p.y, pix[k] * (size_t)p.ypitch + n, va[k], p.out_f32);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) { s1[e] += va[k][e]; s2[e] = fmaf(va[k][e], va[k][e], s2[e]); }
-        } else {
-          float rf[4], a2[4];
-          if (p.bf_add) {
-            ld4c(cadd, p.bf_add, pix[k] * (size_t)p.bf_addpitch + n, a2);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) va[k][e] += a2[e];
-          }
-          ld4(p.bf_ref, pix[k] * (size_t)p.bf_refpitch + n, rf);
-          float mk[4] = {1.f, 1.f, 1.f, 1.f};
-          if (p.bf_mode == 3) {
-            const uint32_t w = *(const uint32_t*)(p.bf_mask + pix[k] * (size_t)p.bf_maskpitch + n);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) mk[e] = 2.f * (float)((w >> (8 * e)) & 0xff);
-          }
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float xh = (rf[e] - mu[e]) * rsd[e];
-            const float z = fmaf(ga[e], xh, be[e]);
-            const float zd = z * mk[e];
-            float d = va[k][e] * mk[e];
-            d = zd > 0.f ? d : (p.bf_mode == 1 ? d * p.bf_slope : 0.f);
-            va[k][e] = d; vb[k][e] = xh;
-            s1[e] += d; s2[e] = fmaf(d, xh, s2[e]);
-          }
-        }
-      }
-    }
-    double t1, t2;
-    block_sums(s1, s2, &t1, &t2);
-    const int c = tid & 7, cn = bx * 8 + c;
-    if (MODE == 1) {
-      if (tid < 8) {
-        const double rows = (double)Rg;
-        const double m = t1 / rows;
-        double var = t2 / rows - m * m;
-        if (var < 0) var = 0;
-        const float r = 1.0f / sqrtf((float)var + p.skn_eps);
-        p.skn_mean[g * p.Cout + cn] = (float)m; p.skn_rstd[g * p.Cout + cn] = r;
-        if (p.skn_mmean) {
-          const double adj = rows / (double)(Rg > 1 ? Rg - 1 : 1);
-          p.skn_mmean[cn] += ((float)m - p.skn_mmean[cn]) * (1.f - p.skn_momentum);
-          p.skn_mvar[cn] += ((float)(var * adj) - p.skn_mvar[cn]) * (1.f - p.skn_momentum);
-        }
-        bc[c][0] = (float)m; bc[c][1] = p.skn_gamma[cn] * r; bc[c][2] = p.skn_beta[cn];
-      }
-      __syncthreads();
-      float mu1[4], A[4], b1[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { mu1[e] = bc[cv * 4 + e][0]; A[e] = bc[cv * 4 + e][1]; b1[e] = bc[cv * 4 + e][2]; }
-#pragma unroll
-      for (int k = 0; k < KR; ++k) {
-        if (rs + RS * k < Rg) {
-          float o[4];
-          float mk[4] = {1.f, 1.f, 1.f, 1.f};
-          if (p.skn_mask) {
-            const uint32_t w = *(const uint32_t*)(p.skn_mask + pix[k] * (size_t)p.Cout + n);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) mk[e] = 2.f * (float)((w >> (8 * e)) & 0xff);
-          }
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float z = fmaf(va[k][e] - mu1[e], A[e], b1[e]);
-            if (p.skn_mask) z *= mk[e];
-            o[e] = apply_act(z, p.skn_act, p.skn_slope);
-          }
-          st4(cout, p.skn_out, pix[k] * (size_t)p.skn_outpitch + n, o, false);
-        }
-      }
-    } else {
-      if (tid < 8) {
-        const float A = p.bf_gamma[cn] * p.bf_rstd[g * p.bf_cols + cn], invR = 1.0f / (float)Rg;
-        bc[c][0] = A; bc[c][1] = -A * ((float)t1 * invR); bc[c][2] = -A * ((float)t2 * invR);
-        tb += t1; tg += t2;
-      }
-      __syncthreads();
-#pragma unroll
-      for (int k = 0; k < KR; ++k) {
-        if (rs + RS * k < Rg) {
-          float o[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = fmaf(va[k][e], bc[cv * 4 + e][0], fmaf(vb[k][e], bc[cv * 4 + e][2], bc[cv * 4 + e][1]));
-          st4(cout, p.skn_out, pix[k] * (size_t)p.skn_outpitch + n, o, false);
-        }
-      }
-    }
-  }
-  if (MODE == 2 && tid < 8) {
-    const int cn = bx * 8 + tid;
-    if (p.skn_dgamma) p.skn_dgamma[cn] = (p.skn_accumulate ? p.skn_dgamma[cn] : 0.f) + (float)tg;
-    if (p.skn_dbeta) p.skn_dbeta[cn] = (p.skn_accumulate ? p.skn_dbeta[cn] : 0.f) + (float)tb;
-  }
-}
-
 template <typename T, int MODE, int KR>
 __global__ __launch_bounds__(256) void splitk_norm_kernel(const GemmParams p, int P) {
   splitk_norm_body<T, MODE, KR, false>(p, P, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.y);
@@ -1999,6 +1718,7 @@ struct GemmPlan {
   int ps_sh;               // > 0: on the tap-shared ping-pong kernel, taps per staged A tile (2 | 4)
   bool ps_table;           // ... in its table-driven form (conv_gemm_pt_kernel)
   int par_npw;             // > 0: parity-patch kernel (all four parities of 256 grid positions per block), patch pieces per wave
+  bool own;                // column-owner kernel (conv_own.hip): the whole GanNormFuse layer in one launch, no slabs
   bool bf_requested;       // the caller asked for a fused backward epilogue (carried iff p.bf_mode != 0)
   dim3 grid;
   size_t slab_bytes;
@@ -2222,6 +1942,7 @@ static int plan_gemm(const GanConvDesc* d, int op, GemmPlan* pl) {
   pl->BM = BM; pl->BN = BN;
   pl->grid = dim3((unsigned)(tilesM * tilesN * (pl->par_npw ? 1 : P)), 1, (unsigned)splits);
   pl->slab_bytes = splits > 1 ? (size_t)P * splits * (size_t)M * p.NslabPitch * sizeof(float) : 0;
+  pl->own = conv_own_eligible(p, P, d->dtype);
   return 0;
 }
 
@@ -2487,6 +2208,7 @@ static int run_gemm(const GanConvDesc* d, int op, gan_stream_t stream) {
   if (!fam && pl.p.stats && pl.stats_chunks > 0 && (size_t)d->stats_groups * pl.stats_chunks * pl.p.stats_C * 2 * sizeof(float) > d->stats_partial_bytes)
     return GAN_E_WORKSPACE;                                            // the caller's partial-sums region is too small for this plan
   if (fam) return thin_launch(fam, d, pl.p, st);   // <= 8-channel streaming layers
+  if (pl.own) return conv_own_launch(pl.p, pl.P, d->dtype, st);
   if (pl.slab_bytes > d->workspace_bytes || (pl.slab_bytes && !d->workspace)) return GAN_E_WORKSPACE;
   return d->dtype == GAN_F32 ? launch_gemm<float>(pl, st) : d->dtype == GAN_F16 ? launch_gemm<f16_t>(pl, st) : launch_gemm<bf16_t>(pl, st);
 }
@@ -2510,7 +2232,8 @@ int gan_conv_plan_info(const GanConvDesc* d, int op, int32_t* info /*[5]: BM, BN
   int rc = plan_gemm(&t, op, &pl);
   if (rc) return rc;
   info[0] = pl.par_npw ? 4 * pl.BM : pl.BM;      // parity-patch kernel: 1024 output pixels (4 parities x 256 positions) per block
-  info[1] = pl.BN; info[2] = pl.p.splits; info[3] = pl.P;
+  info[1] = pl.BN; info[2] = pl.own ? 1 : pl.p.splits; info[3] = pl.P;
+  if (pl.own) { info[0] = 0; info[1] = 8; }          // column-owner kernel: 8 channels of every row per workgroup
   info[4] = pl.stats_chunks;          // > 0: this launch can emit normalisation-statistics partials (chunks per group)
   if (const int fam = thin_family(&t, op, pl.p)) { info[0] = 0; info[1] = fam; info[2] = 1; info[4] = 0; }   // thin.hip kernels
   return 0;

@@ -35,6 +35,10 @@ struct GemmParams {
 
 };
 
+// conv_own.hip: column-owner kernel - a layer of <= 64 rows per parity that plan_gemm lets its slab reduce finish (p.skn) in ONE launch
+bool conv_own_eligible(const GemmParams& p, int P, int dtype);
+int conv_own_launch(const GemmParams& p, int P, int dtype, hipStream_t st);
+
 // thin.hip: streaming kernels for the layers with <= 8 channels on one side (HBM-bound, no LDS tiling).
 // thin_family(): 0 = use the tiled implicit GEMM, 1 = "thin-N" (few output channels), 2 = "thin-K" (8-channel input)
 int thin_family(const GanConvDesc* d, int op, const GemmParams& p);

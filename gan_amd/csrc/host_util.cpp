@@ -45,6 +45,8 @@ Opt g_opts[] = {
     {"conv.stack", {0}},            // runs of small split-K layers in one persistent launch (gan_conv_stack_*): OFF - measured 13-16 % slower than the launches it replaces
     {"conv.stack_blocks", {256}},   // ... its resident grid (multiple of 8; at most 2 workgroups per CU fit)
     {"conv.reduce_stats_rg", {16}}, // split-K slab reduce emitting statistics partials: at most this many row groups per workgroup (1: one chunk per group, as before round 5)
+    {"conv.own_max_kb", {192}},     // ... and at most this many KB of operands per workgroup (live taps x (8 weight rows + the layer's rows))
+    {"conv.own_max_rows", {16}},    // column-owner kernel (conv_own.hip) for GanNormFuse layers with at most this many rows per parity (<= 64; 0: never)
     {"conv.norm_fuse", {1}},        // GanNormFuse: small split-K layers finished by their slab-reduce kernel
     {"conv.thin_fused", {1}},       // thin-N layers with <= 2 output channels in one kernel (Z through LDS instead of memory)
     {"conv.thin", {7}},             // bit 0: streaming kernels at all, bit 1: thin-N, bit 2: thin-K

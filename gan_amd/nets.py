@@ -529,6 +529,7 @@ class _Builder:
         M = x.n * (x.h * x.w if info[3] == 4 else y.h * y.w)
         flops = 2.0 * M * info[3] * T * y.c * creal
         kname = (f"conv_gemm<{self.ctx.dtype},{info[0]},{info[1]}>" if info[0] else
+                 f"conv_own<{self.ctx.dtype}>" if info[1] == 8 else                     # csrc/conv_own.hip: the whole layer in one launch
                  f"conv_thin_{'n' if info[1] == 1 else 'k'}<{self.ctx.dtype}>")        # csrc/thin.hip streaming kernels
         if info[0] and info[2] > 1:
             kname += "+splitK"          # two kernels per call (GEMM into fp32 slabs + the slab-reduce kernel): timed as their own class

@@ -533,11 +533,9 @@ NORMFUSE_CASES = [  # (op, N, H of x, Cin, Cout, groups, act, dropout)
 ]
 
 
-@pytest.mark.parametrize("case", NORMFUSE_CASES)
-def test_split_k_layer_finished_by_its_slab_reduce(ctx, case, planner_options):
-    """GanNormFuse, forward: conv -> BN|IN -> [dropout] -> activation (base_gan.py:77-87, :106-120) of a small split-K layer in
-    two launches (GEMM + slab reduce that also normalises) equals the four-launch path (slab reduce, statistics finalize,
-    apply), which the tests above check against the oracle."""
+def _normfuse_fwd(ctx, case, planner_options, variants):
+    """One GanNormFuse forward layer under each option set of `variants` ({option: value}; 'conv.norm_fuse' = 0: the four-launch path):
+    (y, activation, mean, rstd, moving mean, moving variance, pad channels) per variant."""
     from gan_amd import _lib as L
     from gan_amd.nets import Buf
     op, N, H, ci, co, G, act, drop = case
@@ -555,8 +553,11 @@ def test_split_k_layer_finished_by_its_slab_reduce(ctx, case, planner_options):
     opi = 0 if op == 'conv_fwd' else 2
     info = (C.c_int32 * 5)()
     res = []
-    for fuse in (1, 0):
-        planner_options('conv.norm_fuse', fuse)
+    for opts in variants:
+        fuse = opts.get('conv.norm_fuse', 1)
+        own = opts.get('conv.own_max_rows', 0)
+        for k, v in opts.items():
+            planner_options(k, v)
         yb, ab = Buf(ctx, N, Ho, Ho, co), Buf(ctx, N, Ho, Ho, co + 8)
         mean, rstd = torch.zeros(G * co, dtype=f32, device=ctx.device), torch.zeros(G * co, dtype=f32, device=ctx.device)
         mm, mv = torch.zeros(co, dtype=f32, device=ctx.device), torch.ones(co, dtype=f32, device=ctx.device)
@@ -566,7 +567,10 @@ def test_split_k_layer_finished_by_its_slab_reduce(ctx, case, planner_options):
         d = L.GanConvDesc(ctx.dt, 2, xv, yb.view(), (tr if op == 'conv_fwd' else nat).data_ptr(), co, None, 0, 0.3, 0, ctx.ws_ptr, ctx.ws_bytes,
                           part.data_ptr(), G, part.numel() * 4, None, C.addressof(nf))
         assert ctx.lib.gan_conv_plan_info(C.byref(d), opi, info) == 0
-        assert info[2] > 1, "shape chosen to be split-K"
+        if own:
+            assert info[0] == 0 and info[1] == 8 and info[2] == 1 and info[4] == -1, ("shape chosen for the column-owner kernel", list(info))
+        else:
+            assert info[2] > 1, "shape chosen to be split-K"
         assert (info[4] == -1) == bool(fuse), list(info)
         if not fuse:          # a request the plan cannot honour is refused (the caller would otherwise skip the layer's normalisation)
             assert fn(C.byref(d), ctx.stream()) == L.E_SHAPE
@@ -583,7 +587,15 @@ def test_split_k_layer_finished_by_its_slab_reduce(ctx, case, planner_options):
             assert ctx.lib.gan_norm_act_fwd(C.byref(nd), ctx.stream()) == 0
         torch.cuda.synchronize()
         res.append((host(yb), host(ab, 8, co), mean.cpu().numpy(), rstd.cpu().numpy(), mm.cpu().numpy(), mv.cpu().numpy(), host(ab, 0, 8)))
-    a, b = res
+    return res
+
+
+@pytest.mark.parametrize("case", NORMFUSE_CASES)
+def test_split_k_layer_finished_by_its_slab_reduce(ctx, case, planner_options):
+    """GanNormFuse, forward: conv -> BN|IN -> [dropout] -> activation (base_gan.py:77-87, :106-120) of a small split-K layer in
+    two launches (GEMM + slab reduce that also normalises) equals the four-launch path (slab reduce, statistics finalize,
+    apply), which the tests above check against the oracle."""
+    a, b = _normfuse_fwd(ctx, case, planner_options, [{'conv.norm_fuse': 1, 'conv.own_max_rows': 0}, {'conv.norm_fuse': 0, 'conv.own_max_rows': 0}])
     assert np.array_equal(a[0], b[0])                       # y: the same slab sums
     assert rel(a[2], b[2].astype(np.float64)) < 1e-5 and rel(a[3], b[3].astype(np.float64)) < 1e-5
     assert rel(a[4], b[4].astype(np.float64)) < 1e-5 and rel(a[5], b[5].astype(np.float64)) < 1e-5
@@ -591,8 +603,36 @@ def test_split_k_layer_finished_by_its_slab_reduce(ctx, case, planner_options):
     assert np.all(a[6] == 0)
 
 
+OWN_FWD_CASES = [  # (op, N, H of x, Cin, Cout, groups, act, dropout)
+    ('conv_fwd', 16, 2, 512, 512, 1, 'lrelu', False),     # generator down7 at batch 16: 2x2 -> 1x1, M = 16, 12 of the 16 taps never meet the map
+    ('conv_fwd', 16, 4, 512, 512, 1, 'lrelu', False),     # down6: M = 64
+    ('convT_fwd', 16, 1, 512, 512, 1, 'relu', True),      # up0: 1x1 -> 2x2, four parities of 16 rows, one live tap each, dropout
+    ('convT_fwd', 16, 2, 1024, 512, 1, 'relu', True),     # up1: four parities of 64 rows
+    ('conv_fwd', 4, 4, 512, 256, 4, 'lrelu', False),      # InstanceNorm: 4 groups of 4 rows
+    ('conv_fwd', 3, 4, 64, 64, 1, 'lrelu', False),        # ragged M = 12; 2 K steps per tap (fewer than waves)
+    ('convT_fwd', 1, 2, 256, 128, 1, 'relu', False),      # CycleGAN at batch 1: four parities of 4 rows
+    ('convT_fwd', 2, 2, 512, 512, 2, 'relu', False),      # two BatchNorm calls batched (moving averages in call order)
+]
+
+
+@pytest.mark.parametrize("case", OWN_FWD_CASES)
+def test_column_owner_kernel_equals_split_k_forward(ctx, case, planner_options):
+    """conv_own_kernel (one launch: a workgroup owns 8 output channels of every row - gather GEMM straight from global memory, K split
+    over its waves, statistics, moving averages, normalise, dropout, activation) against the split-K GEMM + finishing slab reduce on
+    the same data: the same products in another summation order."""
+    if ctx.dtype == 'f32':
+        pytest.skip("column-owner kernel: 16-bit storage only")
+    a, b = _normfuse_fwd(ctx, case, planner_options, [{'conv.own_max_rows': 64, 'conv.own_max_kb': 1 << 20}, {'conv.own_max_rows': 0}])
+    tol = {'bf16': 1e-2, 'f16': 2e-3}[ctx.dtype]
+    assert float(np.abs(b[1]).max()) > 0.1
+    assert rel(a[0], b[0]) < tol and rel(a[1], b[1]) < 2 * tol
+    for k in (2, 3, 4, 5):
+        assert rel(a[k], b[k].astype(np.float64)) < tol, k
+    assert np.all(a[6] == 0)
+
+
 @pytest.mark.parametrize("N,G", [(16, 1), (2, 2), (4, 4)])
-def test_layer_stack_equals_separate_launches(ctx, N, G):
+def test_layer_stack_equals_separate_launches(ctx, N, G, planner_options):
     """gan_conv_stack_*: three consecutive small split-K layers (conv s2 -> conv s2 -> transposed conv, each finished by its slab
     reduce: statistics, moving averages, normalise, [dropout,] activation) from ONE persistent launch - grid barriers between the
     phases, slabs and activations exchanged around the per-XCD L2s - against the same three layers as separate launches: y, the
@@ -600,6 +640,7 @@ def test_layer_stack_equals_separate_launches(ctx, N, G):
     (G = 1), two BatchNorm invocations batched along N (G = 2), InstanceNorm (G = N)."""
     from gan_amd import _lib as L
     from gan_amd.nets import Buf
+    planner_options('conv.own_max_rows', 0)        # (the stack is made of split-K layers)
     rng = np.random.default_rng(31)
     c = 512
     x = q(ctx, rng.standard_normal((N, 8, 8, c)))
@@ -664,12 +705,8 @@ def test_layer_stack_equals_separate_launches(ctx, N, G):
         assert np.all(pad == 0)                               # channel slices outside the views untouched
 
 
-@pytest.mark.parametrize("case", [('convT_dgrad', 16, 16, 512, 1024, 1, 'relu+mask', 512), ('convT_dgrad', 16, 4, 512, 1024, 1, 'relu', 512),
-                                  ('conv_dgrad', 16, 4, 512, 512, 1, 'lrelu', 512), ('conv_dgrad', 2, 4, 512, 512, 2, 'lrelu', 512),
-                                  ('convT_dgrad', 2, 16, 512, 512, 2, 'relu', 512)])
-def test_split_k_dgrad_finishes_the_layer_below(ctx, case, planner_options):
-    """GanNormFuse, backward: the slab reduce of a small split-K dgrad writes dy of the layer below (and dgamma, dbeta; the skip
-    half of a decoder concat unchanged) = the fused-epilogue path (dz + partial sums, finalize, apply) checked above."""
+def _normfuse_bwd(ctx, case, planner_options, variants):
+    """One GanNormFuse dgrad under each option set of `variants`: (dy of the layer below, dgamma, dbeta, skip half of dz) per variant."""
     from gan_amd import _lib as L
     from gan_amd.nets import Buf
     op, N, H, cdy, cg, G, kind, cols = case
@@ -699,8 +736,11 @@ def test_split_k_dgrad_finishes_the_layer_below(ctx, case, planner_options):
                       cols, L.ACTS[act], 0.3, cols)
     info = (C.c_int32 * 5)()
     res = []
-    for fuse in (1, 0):
-        planner_options('conv.norm_fuse', fuse)
+    for opts in variants:
+        fuse = opts.get('conv.norm_fuse', 1)
+        own = opts.get('conv.own_max_rows', 0)
+        for k, v in opts.items():
+            planner_options(k, v)
         dzb, outb = Buf(ctx, N, Hg, Hg, cg), Buf(ctx, N, Hg, Hg, cols)
         dg, db = torch.full((cols,), 0.5, dtype=f32, device=ctx.device), torch.full((cols,), -0.25, dtype=f32, device=ctx.device)
         part = torch.zeros(4 << 20, dtype=f32, device=ctx.device)
@@ -708,7 +748,7 @@ def test_split_k_dgrad_finishes_the_layer_below(ctx, case, planner_options):
         d = L.GanConvDesc(ctx.dt, 2, dyv, dzb.view(), wt.data_ptr(), cg, None, 0, 0.3, 0, ctx.ws_ptr, ctx.ws_bytes,
                           part.data_ptr(), G, part.numel() * 4, C.addressof(bf), C.addressof(nf))
         assert ctx.lib.gan_conv_plan_info(C.byref(d), opi, info) == 0
-        assert info[2] > 1 and (info[4] == -1) == bool(fuse) and info[4] != 0, list(info)
+        assert (info[2] == 1 and info[1] == 8 if own else info[2] > 1) and (info[4] == -1) == bool(fuse) and info[4] != 0, list(info)
         if not fuse:
             assert fn(C.byref(d), ctx.stream()) == L.E_SHAPE
             d.norm_fuse = None
@@ -719,12 +759,41 @@ def test_split_k_dgrad_finishes_the_layer_below(ctx, case, planner_options):
             assert ctx.lib.gan_norm_act_bwd_fused(C.byref(fd), info[4], ctx.stream()) == 0
         torch.cuda.synchronize()
         res.append((host(outb), dg.cpu().numpy().astype(np.float64), db.cpu().numpy().astype(np.float64), host(dzb, cols) if cols < cg else None))
-    a, b = res
+    return res, cols < cg
+
+
+@pytest.mark.parametrize("case", [('convT_dgrad', 16, 16, 512, 1024, 1, 'relu+mask', 512), ('convT_dgrad', 16, 4, 512, 1024, 1, 'relu', 512),
+                                  ('conv_dgrad', 16, 4, 512, 512, 1, 'lrelu', 512), ('conv_dgrad', 2, 4, 512, 512, 2, 'lrelu', 512),
+                                  ('convT_dgrad', 2, 16, 512, 512, 2, 'relu', 512)])
+def test_split_k_dgrad_finishes_the_layer_below(ctx, case, planner_options):
+    """GanNormFuse, backward: the slab reduce of a small split-K dgrad writes dy of the layer below (and dgamma, dbeta; the skip
+    half of a decoder concat unchanged) = the fused-epilogue path (dz + partial sums, finalize, apply) checked above."""
+    (a, b), skip = _normfuse_bwd(ctx, case, planner_options, [{'conv.norm_fuse': 1, 'conv.own_max_rows': 0}, {'conv.norm_fuse': 0, 'conv.own_max_rows': 0}])
     tol = {'f32': 2e-5, 'bf16': 2e-2, 'f16': 3e-3}[ctx.dtype]
     assert rel(a[0], b[0]) < tol
     assert rel(a[1], b[1]) < max(tol, 1e-4) and rel(a[2], b[2]) < max(tol, 1e-4)
-    if cols < cg:
+    if skip:
         assert np.array_equal(a[3], b[3])                   # skip half: the plain gradient
+
+
+@pytest.mark.parametrize("case", [('convT_dgrad', 16, 4, 512, 1024, 1, 'relu', 512),       # up1's dgrad -> up0's backward (skip half: plain gradient), M = 64
+                                  ('convT_dgrad', 16, 2, 512, 512, 1, 'lrelu', 512),       # up0's dgrad -> down7's backward: M = 16, 4 live taps
+                                  ('conv_dgrad', 16, 1, 512, 512, 1, 'lrelu', 512),        # down7's dgrad: four parities of 16 rows, one live tap each
+                                  ('conv_dgrad', 16, 2, 512, 512, 1, 'relu+mask', 512),    # four parities of 64 rows, dropout mask
+                                  ('conv_dgrad', 2, 2, 256, 128, 2, 'lrelu', 128),         # two statistics groups
+                                  ('convT_dgrad', 3, 4, 64, 64, 1, 'relu', 64)])           # ragged M = 12
+def test_column_owner_kernel_equals_split_k_backward(ctx, case, planner_options):
+    """conv_own_kernel carrying the whole normalisation backward of the layer below (dz, dgamma, dbeta, dy; the skip half of a decoder
+    concat as the plain gradient) against the split-K dgrad + finishing slab reduce."""
+    if ctx.dtype == 'f32':
+        pytest.skip("column-owner kernel: 16-bit storage only")
+    (a, b), skip = _normfuse_bwd(ctx, case, planner_options, [{'conv.own_max_rows': 64, 'conv.own_max_kb': 1 << 20}, {'conv.own_max_rows': 0}])
+    tol = {'bf16': 2e-2, 'f16': 3e-3}[ctx.dtype]
+    assert float(np.abs(b[0]).max()) > 1e-3
+    assert rel(a[0], b[0]) < tol
+    assert rel(a[1], b[1]) < tol and rel(a[2], b[2]) < tol
+    if skip:
+        assert rel(a[3], b[3]) < tol / 2
 
 
 def test_wgrad_tr_read_matches_plain(ctx, monkeypatch):

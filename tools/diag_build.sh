@@ -4,7 +4,7 @@
 set -e
 cd "$(dirname "$0")/../gan_amd/csrc"
 mkdir -p /tmp/gan_diag
-for f in conv_gemm thin wgrad norm elementwise; do
+for f in conv_gemm conv_own thin wgrad norm elementwise; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -DGAN_DIAG -Wno-unused-variable -Wno-unused-function -c $f.hip -o /tmp/gan_diag/$f.o &
 done
 wait

@@ -35,9 +35,13 @@ for _ in range(3):
     assert fn(C.byref(d), ctx.stream()) == 0
 torch.cuda.synchronize()
 flush = torch.empty(512 << 20, dtype=torch.uint8, device='cuda')
-for cold in (0, 1):
-    if cold:
+small = torch.empty(64 << 20, dtype=torch.uint8, device='cuda')
+for cold in (0, 1, 2):       # 2: "MALL-warm" - operands read once after the flush, then the L2s (4 MB x 8) flushed by a 64-MB fill that leaves
+    if cold:                 #    the 256-MB memory-side cache holding them
         flush.zero_()
+    if cold == 2:
+        (w.float().sum() + x.t.float().sum()).item()
+        small.zero_()
     lib.gan_diag_set(diag.data_ptr()); diag.zero_()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(); fn(C.byref(d), ctx.stream()); e1.record()
@@ -53,7 +57,7 @@ for cold in (0, 1):
     t = t[:, :5].astype(np.float64) * 0.01    # us
     t0 = t[:, 0].min()
     seg = np.diff(t, axis=1)
-    print(f"{op} N{N} H{H} {ci}->{co} s{s} tile {info[0]}x{info[1]} splits {info[2]} blocks {len(t)} {'cold' if cold else 'warm'}: event {e0.elapsed_time(e1)*1e3:.1f} us, "
+    print(f"{op} N{N} H{H} {ci}->{co} s{s} tile {info[0]}x{info[1]} splits {info[2]} blocks {len(t)} {['warm', 'cold', 'mall'][cold]}: event {e0.elapsed_time(e1)*1e3:.1f} us, "
           f"kernel span {t[:, 4].max() - t0:.1f} us")
     print(f"   block start spread {t[:, 0].max() - t0:.2f} us; mean per block: setup {seg[:, 0].mean():.2f}  first-fill {seg[:, 1].mean():.2f}  "
           f"loop {seg[:, 2].mean():.2f}  epilogue {seg[:, 3].mean():.2f} (max {seg[:, 3].max():.2f})  total {(t[:, 4] - t[:, 0]).mean():.2f} us")
