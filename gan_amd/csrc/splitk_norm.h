@@ -75,7 +75,7 @@ template <bool COH> __device__ __forceinline__ void st_u2(const CohBuf& b, void*
 template <typename T, int MODE, int KR, bool COH, int SRC = 0>       // KR: rows per thread (1, 2, 4, 8): 128 * KR >= rows per group
 __device__ __forceinline__ void splitk_norm_body(const GemmParams& p, int P, int bx, int by, int gy, const float* part = nullptr, int nparts = 0,
                                                  int mpad = 0) {
-  constexpr int RS = 128, UNR = 16 / KR;         // 16 slab loads in flight per thread (a row at a time the kernel is latency-bound)
+  constexpr int RS = 128, UNR = 16 / KR;         // 16 slab loads in flight per thread (a row at a time the kernel is latency-bound; 32 in flight: no faster, measured)
   __shared__ double red[4][8][2];
   __shared__ float bc[8][4];
   const int tid = threadIdx.x, cv = tid & 1, rs = tid >> 1, lane = tid & 63, wave = tid >> 6;
@@ -91,6 +91,23 @@ __device__ __forceinline__ void splitk_norm_body(const GemmParams& p, int P, int
   auto ld4c = [](const CohBuf& cbuf, const void* base, size_t off, float* out) {     // the same through the coherent path (COH)
     if constexpr (sizeof(T) == 4) { const f32x4 q = ld_f4<COH>(cbuf, (const float*)base + off); out[0] = q[0]; out[1] = q[1]; out[2] = q[2]; out[3] = q[3]; }
     else { float t8[8]; const uint2 q = ld_u2<COH>(cbuf, (const T*)base + off); unpack16<T>(make_uint4(q.x, q.y, 0u, 0u), t8); out[0] = t8[0]; out[1] = t8[1]; out[2] = t8[2]; out[3] = t8[3]; }
+  };
+  // the same in two halves - issue (raw) early, unpack where the value is needed: the loads of one row slot are independent of the slab
+  // sums, and a dependent round trip costs 2-4.5 us here (cold lines, 64-128 workgroups: latency-bound, not bandwidth-bound)
+  struct Raw4 { f32x4 f; uint2 h; };
+  auto ld4raw = [](const void* base, size_t off) {
+    Raw4 q;
+    if constexpr (sizeof(T) == 4) q.f = *(const f32x4*)((const float*)base + off); else q.h = *(const uint2*)((const T*)base + off);
+    return q;
+  };
+  auto ld4craw = [](const CohBuf& cbuf, const void* base, size_t off) {
+    Raw4 q;
+    if constexpr (sizeof(T) == 4) q.f = ld_f4<COH>(cbuf, (const float*)base + off); else q.h = ld_u2<COH>(cbuf, (const T*)base + off);
+    return q;
+  };
+  auto unraw = [](const Raw4& q, float* out) {
+    if constexpr (sizeof(T) == 4) { out[0] = q.f[0]; out[1] = q.f[1]; out[2] = q.f[2]; out[3] = q.f[3]; }
+    else { float t8[8]; unpack16<T>(make_uint4(q.h.x, q.h.y, 0u, 0u), t8); out[0] = t8[0]; out[1] = t8[1]; out[2] = t8[2]; out[3] = t8[3]; }
   };
   auto st4 = [](const CohBuf& cbuf, void* base, size_t off, const float* v, bool f32) {
     if (f32 || sizeof(T) == 4) st_f4<COH>(cbuf, (float*)base + off, f32x4{v[0], v[1], v[2], v[3]});
@@ -165,6 +182,30 @@ __device__ __forceinline__ void splitk_norm_body(const GemmParams& p, int P, int
         ga[e] = p.bf_gamma[n + e]; be[e] = p.bf_beta[n + e];
       }
     }
+    // the thread's rows, and everything of them that does not depend on the slab sums, requested first
+    Raw4 rraw[KR], araw[KR];
+    uint32_t mraw[KR];
+    float cgam = 0.f, cbet = 0.f, cmm = 0.f, cmv = 0.f;         // MODE 1, tid < 8: this channel's gamma, beta, moving statistics
+#pragma unroll
+    for (int k = 0; k < KR; ++k) {
+      int row = rs + RS * k;
+      if (row >= Rg) row = rs < Rg ? rs : 0;                   // (clamped: loaded, never used)
+      const int par = row / Mg, m = g * Mg + (row - par * Mg);
+      pix[k] = out_pixel_index(p, m, par >> 1, par & 1);
+      mraw[k] = 0u;
+      if (MODE == 2) {
+        if (p.bf_add) araw[k] = ld4craw(cadd, p.bf_add, pix[k] * (size_t)p.bf_addpitch + n);
+        rraw[k] = ld4raw(p.bf_ref, pix[k] * (size_t)p.bf_refpitch + n);
+        if (p.bf_mode == 3) mraw[k] = *(const uint32_t*)(p.bf_mask + pix[k] * (size_t)p.bf_maskpitch + n);
+      } else if (p.skn_mask) {
+        mraw[k] = *(const uint32_t*)(p.skn_mask + pix[k] * (size_t)p.Cout + n);
+      }
+    }
+    if (MODE == 1 && tid < 8) {
+      const int cn0 = bx * 8 + tid;
+      cgam = p.skn_gamma[cn0]; cbet = p.skn_beta[cn0];
+      if (p.skn_mmean) { cmm = p.skn_mmean[cn0]; cmv = p.skn_mvar[cn0]; }
+    }
     // slab sums of the thread's KR rows: 16 loads in flight per thread (a row at a time the kernel was latency-bound: 24 us for
     // 256 KB per workgroup); the splits of a row are added in order, as splitk_reduce4_kernel adds them
     if constexpr (SRC == 1) {
@@ -173,7 +214,6 @@ __device__ __forceinline__ void splitk_norm_body(const GemmParams& p, int P, int
         int row = rs + RS * k;
         if (row >= Rg) row = rs < Rg ? rs : 0;                 // (clamped: read, never used)
         const int par = row / Mg, m = g * Mg + (row - par * Mg);
-        pix[k] = out_pixel_index(p, m, par >> 1, par & 1);
         const f32x4 sacc = lds_sum(par, m);
 #pragma unroll
         for (int e = 0; e < 4; ++e) va[k][e] = (p.out_f32 || sizeof(T) == 4) ? sacc[e] : (float)(T)sacc[e];      // as stored
@@ -185,7 +225,6 @@ __device__ __forceinline__ void splitk_norm_body(const GemmParams& p, int P, int
         int row = rs + RS * k;
         if (row >= Rg) row = rs < Rg ? rs : 0;                 // (clamped: loaded, never used)
         const int par = row / Mg, m = g * Mg + (row - par * Mg);
-        pix[k] = out_pixel_index(p, m, par >> 1, par & 1);
         src[k] = p.slab + (size_t)par * p.splits * sstride + ((size_t)bx * p.M + m) * 8 + cv * 4;
       }
       f32x4 sacc[KR];
@@ -223,14 +262,14 @@ __device__ __forceinline__ void splitk_norm_body(const GemmParams& p, int P, int
         } else {
           float rf[4], a2[4];
           if (p.bf_add) {
-            ld4c(cadd, p.bf_add, pix[k] * (size_t)p.bf_addpitch + n, a2);
+            unraw(araw[k], a2);
 #pragma unroll
             for (int e = 0; e < 4; ++e) va[k][e] += a2[e];
           }
-          ld4(p.bf_ref, pix[k] * (size_t)p.bf_refpitch + n, rf);
+          unraw(rraw[k], rf);
           float mk[4] = {1.f, 1.f, 1.f, 1.f};
           if (p.bf_mode == 3) {
-            const uint32_t w = *(const uint32_t*)(p.bf_mask + pix[k] * (size_t)p.bf_maskpitch + n);
+            const uint32_t w = mraw[k];
 #pragma unroll
             for (int e = 0; e < 4; ++e) mk[e] = 2.f * (float)((w >> (8 * e)) & 0xff);
           }
@@ -260,10 +299,10 @@ __device__ __forceinline__ void splitk_norm_body(const GemmParams& p, int P, int
         p.skn_mean[g * p.Cout + cn] = (float)m; p.skn_rstd[g * p.Cout + cn] = r;
         if (p.skn_mmean) {
           const double adj = rows / (double)(Rg > 1 ? Rg - 1 : 1);
-          p.skn_mmean[cn] += ((float)m - p.skn_mmean[cn]) * (1.f - p.skn_momentum);
-          p.skn_mvar[cn] += ((float)(var * adj) - p.skn_mvar[cn]) * (1.f - p.skn_momentum);
+          p.skn_mmean[cn] = cmm + ((float)m - cmm) * (1.f - p.skn_momentum);
+          p.skn_mvar[cn] = cmv + ((float)(var * adj) - cmv) * (1.f - p.skn_momentum);
         }
-        bc[c][0] = (float)m; bc[c][1] = p.skn_gamma[cn] * r; bc[c][2] = p.skn_beta[cn];
+        bc[c][0] = (float)m; bc[c][1] = cgam * r; bc[c][2] = cbet;
       }
       __syncthreads();
       float mu1[4], A[4], b1[4];
@@ -275,7 +314,7 @@ __device__ __forceinline__ void splitk_norm_body(const GemmParams& p, int P, int
           float o[4];
           float mk[4] = {1.f, 1.f, 1.f, 1.f};
           if (p.skn_mask) {
-            const uint32_t w = *(const uint32_t*)(p.skn_mask + pix[k] * (size_t)p.Cout + n);
+            const uint32_t w = mraw[k];
 #pragma unroll
             for (int e = 0; e < 4; ++e) mk[e] = 2.f * (float)((w >> (8 * e)) & 0xff);
           }
