@@ -1574,94 +1574,144 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p, 
   store_out<T>(p, out_pixel_offset(p, m, par >> 1, par & 1), n, s);
 }
 
-// 4 channels per thread: float4 slab reads (4 splits in flight), one 8/16-byte store.  Needs Cout % 4 == 0 and
-// a 4-element aligned destination (vec_store layers).
-template <typename T>
-__global__ __launch_bounds__(256) void splitk_reduce4_kernel(const GemmParams p, int P) {
+// 4 channels per thread: float4 slab reads, one 8/16-byte store.  Needs Cout % 4 == 0 and a 4-element aligned destination
+// (vec_store layers).  rg_arg: row groups per workgroup of a launch that emits statistics partials (an argument, not a GemmParams
+// field: one more int in the struct cost conv_gemm_kernel<64,128> 16 more spilled SGPRs and 20 % of its speed).
+template <typename T, int U>       // U: row groups walked at a time (<= the row groups per workgroup)
+__global__ __launch_bounds__(256) void splitk_reduce4_kernel(const GemmParams p, int P, int rg_arg) {
   const int c4 = p.Cout >> 2;
   const long long total = (long long)P * p.M * c4;
   // With fused statistics a workgroup walks RG consecutive groups of RB = 256 / c4 whole rows (all of one parity and one statistics group:
   // the planner guarantees it) and emits ONE chunk of partial sums for them: RG = 1 gave one chunk per 2 rows of a 512-channel layer,
-  // thousands per launch, and the planner then left the statistics to a separate pass over the tensor (round 5).
-  const int RG = p.stats ? p.stats_rg : 1;
+  // thousands per launch, and the planner then left the statistics to a separate pass over the tensor (round 5).  The row groups are
+  // walked U at a time with every load of the U groups requested before the first is used: one group after the other was a chain of
+  // up to 16 dependent round trips (25 us for a launch that moves 50 MB).
+  const int RG = p.stats ? rg_arg : 1;
+  struct Raw4 { f32x4 f; uint2 h; };
+  auto ld4raw = [](const void* base, size_t off) {
+    Raw4 q;
+    if constexpr (sizeof(T) == 4) q.f = *(const f32x4*)((const float*)base + off); else q.h = *(const uint2*)((const T*)base + off);
+    return q;
+  };
+  auto unraw = [](const Raw4& q, float* out) {
+    if constexpr (sizeof(T) == 4) { out[0] = q.f[0]; out[1] = q.f[1]; out[2] = q.f[2]; out[3] = q.f[3]; }
+    else { float t8[8]; unpack16<T>(make_uint4(q.h.x, q.h.y, 0u, 0u), t8); out[0] = t8[0]; out[1] = t8[1]; out[2] = t8[2]; out[3] = t8[3]; }
+  };
   float acc8[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) acc8[e] = 0.f;
-  int m_first = 0, par_first = 0;
-  for (int it = 0; it < RG; ++it) {
-  const long long idx = ((long long)blockIdx.x * RG + it) * 256 + threadIdx.x;
-  if (idx >= total) { if (p.stats) break; return; }
-  const int n = (int)(idx % c4) * 4;
-  long long t = idx / c4;
-  const int m = (int)(t % p.M);
-  const int par = (int)(t / p.M);
+  const long long idx0 = (long long)blockIdx.x * RG * 256 + threadIdx.x;
+  if (idx0 >= total && !p.stats) return;
+  const int n = (int)(idx0 % c4) * 4;                          // the same for every row group of the thread (256 % c4 == 0 where RG > 1)
+  const int m_first = (int)((idx0 / c4) % p.M), par_first = (int)((idx0 / c4) / p.M);
   const size_t sstride = (size_t)p.M * p.NslabPitch;
-  const float* src = p.slab + ((size_t)par * p.splits * p.M + m) * p.NslabPitch + n;
-  f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
-  int k = 0;
-  for (; k + 4 <= p.splits; k += 4) {
-    const f32x4 a = *(const f32x4*)(src + (size_t)k * sstride), b = *(const f32x4*)(src + (size_t)(k + 1) * sstride);
-    const f32x4 c = *(const f32x4*)(src + (size_t)(k + 2) * sstride), d = *(const f32x4*)(src + (size_t)(k + 3) * sstride);
-    s += a; s += b; s += c; s += d;
-  }
-  for (; k < p.splits; ++k) s += *(const f32x4*)(src + (size_t)k * sstride);
-  float v[4];
-#pragma unroll
-  for (int e = 0; e < 4; ++e) v[e] = apply_act(s[e] + (p.bias ? p.bias[n + e] : 0.f), p.act, p.slope);
-  const size_t pix = out_pixel_index(p, m, par >> 1, par & 1);
-  const size_t o = pix * (size_t)p.ypitch + n;
-  float sx[4] = {0.f, 0.f, 0.f, 0.f};       // fused backward epilogue: dz * xhat
   const bool bf = p.bf_mode && n < p.bf_cols;
-  if (bf) {                                  // GanBwdFuse on 4 channels of one pixel (same arithmetic as bwd_fuse_vec)
-    auto ld4 = [](const void* base, size_t off, float* out) {
-      if constexpr (sizeof(T) == 4) { const f32x4 q = *(const f32x4*)((const float*)base + off); out[0] = q[0]; out[1] = q[1]; out[2] = q[2]; out[3] = q[3]; }
-      else { float t8[8]; const uint2 q = *(const uint2*)((const T*)base + off); unpack16<T>(make_uint4(q.x, q.y, 0u, 0u), t8); out[0] = t8[0]; out[1] = t8[1]; out[2] = t8[2]; out[3] = t8[3]; }
-    };
-    float rf[4], a2[4];
-    if (!p.out_f32) {
+  const bool bfn = bf && p.bf_mode != 4;
+  f32x4 mu = f32x4{0.f, 0.f, 0.f, 0.f}, rs = mu, ga = mu, be = mu;
+  f32x4 bias4 = mu;
+  if (bfn && idx0 < total) {                                    // one statistics group per workgroup: its constants once
+    const int RBq = (256 / c4) * RG, grp = (m_first / RBq) / p.stats_tpg;
+    mu = *(const f32x4*)(p.bf_mean + grp * p.bf_cols + n); rs = *(const f32x4*)(p.bf_rstd + grp * p.bf_cols + n);
+    ga = *(const f32x4*)(p.bf_gamma + n); be = *(const f32x4*)(p.bf_beta + n);
+  }
+  if (p.bias && idx0 < total) bias4 = f32x4{p.bias[n], p.bias[n + 1], p.bias[n + 2], p.bias[n + 3]};
+  for (int it0 = 0; it0 < RG; it0 += U) {
+    bool ok[U];
+    size_t pix[U];
+    const float* src[U];
+    Raw4 rraw[U], araw[U];
+    uint32_t mraw[U];
+    f32x4 sacc[U];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = (float)(T)v[e];     // da as the unfused path would have stored and re-read it
-    }
-    if (p.bf_add) {
-      ld4(p.bf_add, pix * (size_t)p.bf_addpitch + n, a2);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] += a2[e];
-    }
-    ld4(p.bf_ref, pix * (size_t)p.bf_refpitch + n, rf);
-    if (p.bf_mode == 4) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = rf[e] > 0.f ? v[e] : v[e] * p.bf_slope;
-    } else {
-      const int RBq = (256 / c4) * RG, grp = (m / RBq) / p.stats_tpg;
-      float mk[4] = {1.f, 1.f, 1.f, 1.f};
-      if (p.bf_mode == 3) {
-        const uint32_t w = *(const uint32_t*)(p.bf_mask + pix * (size_t)p.bf_maskpitch + n);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) mk[e] = 2.f * (float)((w >> (8 * e)) & 0xff);
-      }
-      const f32x4 mu = *(const f32x4*)(p.bf_mean + grp * p.bf_cols + n), rs = *(const f32x4*)(p.bf_rstd + grp * p.bf_cols + n);
-      const f32x4 ga = *(const f32x4*)(p.bf_gamma + n), be = *(const f32x4*)(p.bf_beta + n);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float xh = (rf[e] - mu[e]) * rs[e];
-        const float z = fmaf(ga[e], xh, be[e]);
-        const float zd = z * mk[e];
-        float d = v[e] * mk[e];
-        d = zd > 0.f ? d : (p.bf_mode == 1 ? d * p.bf_slope : 0.f);
-        v[e] = d; sx[e] = d * xh;
+    for (int u = 0; u < U; ++u) {
+      const long long idx = idx0 + (long long)(it0 + u) * 256;
+      ok[u] = it0 + u < RG && idx < total;
+      const long long t = (ok[u] ? idx : (idx0 < total ? idx0 : 0)) / c4;     // a row that is not this thread's: a valid row read again, nothing stored
+                                                                               // (unconditional loads: a branch per row serialised them)
+      const int m = (int)(t % p.M), par = (int)(t / p.M);
+      src[u] = p.slab + ((size_t)par * p.splits * p.M + m) * p.NslabPitch + n;
+      pix[u] = out_pixel_index(p, m, par >> 1, par & 1);
+      sacc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      mraw[u] = 0u;
+      if (bf) {
+        if (p.bf_add) araw[u] = ld4raw(p.bf_add, pix[u] * (size_t)p.bf_addpitch + n);
+        rraw[u] = ld4raw(p.bf_ref, pix[u] * (size_t)p.bf_refpitch + n);
+        if (p.bf_mode == 3) mraw[u] = *(const uint32_t*)(p.bf_mask + pix[u] * (size_t)p.bf_maskpitch + n);
       }
     }
-  }
-  if (p.out_f32) *(f32x4*)((float*)p.y + o) = f32x4{v[0], v[1], v[2], v[3]};
-  else *(uint2*)((T*)p.y + o) = make_uint2(pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]));
-  if (it == 0) { m_first = m; par_first = par; }
-  if (p.stats) {
+    int k = 0;
+    for (; k + 4 <= p.splits; k += 4) {                         // 16 slab loads in flight
+      f32x4 a[U], b[U], c[U], d[U];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float w = p.out_f32 ? v[e] : (float)(T)v[e];                  // as stored (bf16-rounded on the fast path)
-      acc8[2 * e] += p.bf_mode ? v[e] : w; acc8[2 * e + 1] += p.bf_mode ? sx[e] : w * w;
+      for (int u = 0; u < U; ++u) {
+        a[u] = *(const f32x4*)(src[u] + (size_t)k * sstride); b[u] = *(const f32x4*)(src[u] + (size_t)(k + 1) * sstride);
+        c[u] = *(const f32x4*)(src[u] + (size_t)(k + 2) * sstride); d[u] = *(const f32x4*)(src[u] + (size_t)(k + 3) * sstride);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) { sacc[u] += a[u]; sacc[u] += b[u]; sacc[u] += c[u]; sacc[u] += d[u]; }
     }
-  }
+    for (; k + 2 <= p.splits; k += 2) {
+      f32x4 a[U], b[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) { a[u] = *(const f32x4*)(src[u] + (size_t)k * sstride); b[u] = *(const f32x4*)(src[u] + (size_t)(k + 1) * sstride); }
+#pragma unroll
+      for (int u = 0; u < U; ++u) { sacc[u] += a[u]; sacc[u] += b[u]; }
+    }
+    for (; k < p.splits; ++k) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) sacc[u] += *(const f32x4*)(src[u] + (size_t)k * sstride);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (!ok[u]) continue;
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = apply_act(sacc[u][e] + bias4[e], p.act, p.slope);
+      const size_t o = pix[u] * (size_t)p.ypitch + n;
+      float sx[4] = {0.f, 0.f, 0.f, 0.f};       // fused backward epilogue: dz * xhat
+      if (bf) {                                  // GanBwdFuse on 4 channels of one pixel (same arithmetic as bwd_fuse_vec)
+        float rf[4], a2[4];
+        if (!p.out_f32) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = (float)(T)v[e];     // da as the unfused path would have stored and re-read it
+        }
+        if (p.bf_add) {
+          unraw(araw[u], a2);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += a2[e];
+        }
+        unraw(rraw[u], rf);
+        if (p.bf_mode == 4) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = rf[e] > 0.f ? v[e] : v[e] * p.bf_slope;
+        } else {
+          float mk[4] = {1.f, 1.f, 1.f, 1.f};
+          if (p.bf_mode == 3) {
+            const uint32_t w = mraw[u];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) mk[e] = 2.f * (float)((w >> (8 * e)) & 0xff);
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float xh = (rf[e] - mu[e]) * rs[e];
+            const float z = fmaf(ga[e], xh, be[e]);
+            const float zd = z * mk[e];
+            float d = v[e] * mk[e];
+            d = zd > 0.f ? d : (p.bf_mode == 1 ? d * p.bf_slope : 0.f);
+            v[e] = d; sx[e] = d * xh;
+          }
+        }
+      }
+      if (p.out_f32) *(f32x4*)((float*)p.y + o) = f32x4{v[0], v[1], v[2], v[3]};
+      else *(uint2*)((T*)p.y + o) = make_uint2(pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]));
+      if (p.stats) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float w = p.out_f32 ? v[e] : (float)(T)v[e];                  // as stored (bf16-rounded on the fast path)
+          acc8[2 * e] += p.bf_mode ? v[e] : w; acc8[2 * e + 1] += p.bf_mode ? sx[e] : w * w;
+        }
+      }
+    }
   }   // row groups
   if (p.stats) {
     // fused normalisation statistics of a split-K layer: per-channel (sum, sum^2) of the STORED values over the workgroup's RG * RB rows
@@ -1714,6 +1764,7 @@ static constexpr int cfg_ns(int BM, int BN) {
 struct GemmPlan {
   GemmParams p;
   int BM, BN, P, stats_chunks;
+  int stats_rg;            // split-K slab reduce emitting the partials: row groups (of 256 / (Cout / 4) rows) per workgroup = per chunk
   bool pp;                 // 256-row tile on the ping-pong kernel
   int ps_sh;               // > 0: on the tap-shared ping-pong kernel, taps per staged A tile (2 | 4)
   bool ps_table;           // ... in its table-driven form (conv_gemm_pt_kernel)
@@ -1819,7 +1870,7 @@ static int plan_gemm(const GanConvDesc* d, int op, GemmPlan* pl) {
     if (splits > maxsp) splits = maxsp;
   }
   p.splits = splits;
-  p.stats = nullptr; p.stats_tpg = 0; p.stats_C = y.c; p.stats_rg = 1;
+  p.stats = nullptr; p.stats_tpg = 0; p.stats_C = y.c; pl->stats_rg = 1;
   pl->stats_chunks = 0;
   // fused backward epilogue request (GanBwdFuse): validated here, honoured below if this launch shape can carry it
   const GanBwdFuse* bf = d->bwd_fuse;
@@ -1897,7 +1948,7 @@ static int plan_gemm(const GanConvDesc* d, int op, GemmPlan* pl) {
       const int rgmax = gan_opt("conv.reduce_stats_rg");
       while (rg < rgmax && rpg / (rb * rg) * P > 512 && rpg % (rb * rg * 2) == 0) rg *= 2;
       if (rpg / (rb * rg) * P <= 1024) {
-        p.stats_tpg = (int)(rpg / (rb * rg)); p.stats_rg = rg;
+        p.stats_tpg = (int)(rpg / (rb * rg)); pl->stats_rg = rg;
         pl->stats_chunks = p.stats_tpg * P;
         p.stats = d->stats_partial;
       }
@@ -2096,8 +2147,12 @@ static int launch_gemm(const GemmPlan& pl, hipStream_t st) {
 #undef SKN_LAUNCH
     } else if (pl.p.vec_store && pl.p.Cout % 4 == 0 && (pl.p.out_f32 || sizeof(T) == 2)) {
       long long total = (long long)pl.P * pl.p.M * (pl.p.Cout / 4);
-      const long long per_wg = 256LL * (pl.p.stats ? pl.p.stats_rg : 1);
-      GAN_LAUNCH(splitk_reduce4_kernel<T>, dim3((unsigned)((total + per_wg - 1) / per_wg)), dim3(256), 0, st, pl.p, pl.P);
+      const long long per_wg = 256LL * (pl.p.stats ? pl.stats_rg : 1);
+      const dim3 rgrid((unsigned)((total + per_wg - 1) / per_wg));
+      const int rgs = pl.p.stats ? pl.stats_rg : 1;
+      if (rgs >= 4) GAN_LAUNCH((splitk_reduce4_kernel<T, 4>), rgrid, dim3(256), 0, st, pl.p, pl.P, pl.stats_rg);
+      else if (rgs >= 2) GAN_LAUNCH((splitk_reduce4_kernel<T, 2>), rgrid, dim3(256), 0, st, pl.p, pl.P, pl.stats_rg);
+      else GAN_LAUNCH((splitk_reduce4_kernel<T, 1>), rgrid, dim3(256), 0, st, pl.p, pl.P, pl.stats_rg);
     } else {
       long long total = (long long)pl.P * pl.p.M * pl.p.Cout;
       GAN_LAUNCH(splitk_reduce_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, pl.p, pl.P);

@@ -16,7 +16,6 @@ struct GemmParams {
   int act; float slope; int out_f32; int vec_store;
   unsigned xbytes, wbytes;   // extents for the buffer descriptors (out-of-range offsets read zeros)
   float* stats; int stats_tpg, stats_C;   // fused per-channel (sum, sum^2) partials: tiles per group, channel count
-  int stats_rg;                           // split-K slab reduce emitting the partials: row groups (of 256 / (Cout / 4) rows) per workgroup = per chunk
   FastDiv divWg, divHg;      // GEMM-grid width / height (row -> (image, gy, gx) decode)
   // fused backward epilogue of a dgrad launch (GanBwdFuse, include/gan_amd.h): the stored value becomes
   // dz = (da + add) * act'(.) [* 2*dropmask] for channels < bf_cols; with bf_mean the (sum dz, sum dz*xhat) partials go to `stats`
