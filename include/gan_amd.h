@@ -129,8 +129,8 @@ int gan_convT2d_fwd(const GanConvDesc* d, gan_stream_t stream);
 int gan_convT2d_dgrad(const GanConvDesc* d, gan_stream_t stream);
 size_t gan_conv_workspace_bytes(const GanConvDesc* d, int op /*0 conv_fwd,1 conv_dgrad,2 convT_fwd,3 convT_dgrad*/);
 /* launch plan the library picks for this problem: info[5] = {BM, BN, splitK, parities, fused-stats chunks per group}
- * (BM = 0: streaming kernel family BN; BM = 1024: parity-patch kernel; info[4] = -1: norm_fuse is honoured, the launch
- * finishes the layer) */
+ * (BM = 0: streaming kernel family BN = 1 | 2, or BN = 8: the column-owner kernel - one launch, 8 output channels of every row per
+ * workgroup, only with norm_fuse; BM = 1024: parity-patch kernel; info[4] = -1: norm_fuse is honoured, the launch finishes the layer) */
 int gan_conv_plan_info(const GanConvDesc* d, int op, int32_t* info);
 /* Which main loop a 256-row tile of this launch takes: 0 = one staged A tile per tap (conv_gemm_pp_kernel), 2 | 4 = the taps of a
  * kernel row that read the same pixels one grid column apart share one staged A tile (conv_gemm_ps_kernel; option conv.tap_share).
@@ -399,6 +399,9 @@ const char* gan_version(void);
  * wgrad.reduce_adam_min_params (1048576: smaller kernels keep the flat slab reduce and the caller's multi-tensor Adam pass),
  * conv.reduce_stats_rg (16: the slab reduce of a split-K launch that also emits the statistics partials walks up to this many row groups
  * per workgroup, one chunk each - keeps the chunk count of a 4,096-row 512-channel layer under ~512 so that the fused path is taken),
+ * conv.own_max_rows (16) / conv.own_max_kb (192): a norm_fuse layer of at most this many GEMM rows per parity (<= 64; 0: never) whose
+ * live taps x (8 weight rows + its rows) stay under this many KB per workgroup runs on the column-owner kernel (csrc/conv_own.hip)
+ * instead of split-K GEMM + finishing slab reduce - same products, another fixed summation order,
  * wgrad.dead_taps (1: a fused-Adam wgrad launch skips the taps that never meet the map at its shape - 12 of 16 for a 2x2 -> 1x1
  * layer - where their moments are zero: the update is the identity there), diag.launch_log (0: see gan_launch_log below). */
 int gan_set_option(const char* key, int32_t value);
