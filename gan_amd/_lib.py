@@ -74,7 +74,7 @@ class GanNormDesc(_Desc):
                 ("gamma", C.c_void_p), ("beta", C.c_void_p), ("mean", C.c_void_p), ("rstd", C.c_void_p),
                 ("moving_mean", C.c_void_p), ("moving_var", C.c_void_p), ("momentum", C.c_float),
                 ("dropmask", C.c_void_p), ("act", C.c_int32), ("slope", C.c_float), ("workspace", C.c_void_p),
-                ("workspace_bytes", C.c_size_t)]
+                ("workspace_bytes", C.c_size_t), ("sync", C.c_void_p)]
 
 
 class GanNormBwdDesc(_Desc):
@@ -82,7 +82,7 @@ class GanNormBwdDesc(_Desc):
                 ("groups", C.c_int32), ("gamma", C.c_void_p), ("beta", C.c_void_p), ("mean", C.c_void_p),
                 ("rstd", C.c_void_p), ("dropmask", C.c_void_p), ("act", C.c_int32), ("slope", C.c_float),
                 ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("accumulate", C.c_int32), ("workspace", C.c_void_p),
-                ("workspace_bytes", C.c_size_t)]
+                ("workspace_bytes", C.c_size_t), ("sync", C.c_void_p)]
 
 
 class GanActBwdDesc(_Desc):
@@ -118,6 +118,10 @@ SYMBOLS = {
     "gan_norm_stats_finalize": (C.c_int, [C.POINTER(GanNormDesc), C.c_int32, C.c_void_p]),
     "gan_norm_act_fwd": (C.c_int, [C.POINTER(GanNormDesc), C.c_void_p]),
     "gan_norm_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int64]),
+    "gan_norm_stats_partial": (C.c_int, [C.POINTER(GanNormDesc), C.c_void_p]),
+    "gan_norm_finalize_act_fwd": (C.c_int, [C.POINTER(GanNormDesc), C.c_int32, C.c_void_p]),
+    "gan_norm_sync_bytes": (C.c_size_t, []),
+    "gan_norm_sync_error_offset": (C.c_size_t, []),
     "gan_norm_act_bwd": (C.c_int, [C.POINTER(GanNormBwdDesc), C.c_void_p]),
     "gan_norm_act_bwd_fused": (C.c_int, [C.POINTER(GanNormBwdDesc), C.c_int32, C.c_void_p]),
     "gan_act_bwd": (C.c_int, [C.POINTER(GanActBwdDesc), C.c_void_p]),

@@ -62,6 +62,7 @@ Opt g_opts[] = {
     {"wgrad.reduce_adam", {1}},     // GanAdamFuse on split launches: the slab reduce ends in the optimiser step
     {"wgrad.adam_halves_max_rows", {0}},   // GanAdamFuse epilogue: launches with at most this many reduction rows put the two halves of a tile on two workgroups
     {"wgrad.dead_taps", {1}},       // GanAdamFuse epilogue: blocks of taps that never meet the map (2x2 -> 1x1 layers) skip the update where m == v == 0
+    {"norm.fin_in_apply", {0}},     // descriptors with a sync area: the finalize of a normalisation layer inside its apply launch (one launch less per layer and direction). OFF: measured 2 % slower on the step (the in-launch publish / wait / re-read chain is three cold round trips, 8-9 us against 5 + a boundary)
     {"diag.launch_log", {0}},       // record the kernel symbol of every launch (gan_launch_log; profiling tools)
 };
 Opt* find_opt(const char* key) {

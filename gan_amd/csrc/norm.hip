@@ -4,6 +4,7 @@
 // load-compute chain), per-channel parameters fetched as float4.  Reductions are two-stage and
 // deterministic: block partials [group][chunk][C][2] -> a chunk-parallel finalize in double precision.
 #include "common.h"
+#include "splitk_norm.h"      // CohBuf / ld_f4 / st_f4: accesses that are coherent across the XCDs' L2s inside one launch
 
 struct RedGeom {
   int C, cvecs;            // channels, 16-byte vectors per row
@@ -168,14 +169,78 @@ __device__ __forceinline__ void chunk_sum(const float* partial, int g, int chunk
   __syncthreads();
 }
 
+// ---- finalize carried by the apply launch (GanNormDesc.sync / GanNormBwdDesc.sync) -------------------------------------------
+// A finalize launch between the pass that wrote the partials and the apply pass is 4.8 us of kernel for a few KB of work and - on the
+// step - 8 us each (marginal cost measured by leaving them out, tools/marginal.py): the launch boundary is the cost.  With a
+// sync area the apply launch does it itself: its first `nfin` workgroups (always dispatched first, they wait for nobody) run the
+// finalize body, publish mean / rstd (or the backward sums) with write-through stores and count themselves in; every workgroup has
+// its rows' loads in flight by then, waits for the count, reads the constants around the L2 and goes on.  Same arithmetic, same
+// summation order as the stand-alone finalize kernels: bit-identical.  The sync area cleans itself: every workgroup takes a
+// departure ticket after the wait (32 sub-counters, a cache line each, so that 4,096 workgroups do not queue on one address); the
+// last one out zeroes the counters for the next launch that uses the area (launches sharing an area must be stream-ordered).
+// Every wait is bounded (2 s): a launch whose first workgroups never publish sets the error word and runs on with stale constants.
+constexpr int SYNC_ARRIVE = 0, SYNC_ERR = 8, SYNC_TOP = 16, SYNC_SUB = 32, SYNC_WORDS = 32 + 16 * 32;
+struct FinP {
+  const float* partial; unsigned* sync;
+  int G, chunks, cb, nfin;                  // cb: channel blocks of FC; nfin = finalize work units = first workgroups that do them
+  long long rows; float eps, momentum; float* mean; float* rstd; float* mmean; float* mvar;      // forward
+  float* sums; float* dgamma; float* dbeta; int accumulate;                                        // backward
+};
+template <bool COH> __device__ __forceinline__ void st_f1(const CohBuf& b, float* ptr, float v) {
+  if constexpr (COH) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), b.r, (unsigned)((const unsigned char*)ptr - b.base), 0, 0x11);
+  else *ptr = v;
+}
+template <int VEC, bool COH> __device__ __forceinline__ void ldp_c(const CohBuf& b, const float* base, float* out) {
+#pragma unroll
+  for (int i = 0; i < VEC / 4; ++i) {
+    const f32x4 v = ld_f4<COH>(b, base + 4 * i);
+    out[4 * i] = v[0]; out[4 * i + 1] = v[1]; out[4 * i + 2] = v[2]; out[4 * i + 3] = v[3];
+  }
+}
+__device__ __forceinline__ void fin_arrive(unsigned* sync) {
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");          // this wave's write-through stores have been acknowledged
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_fetch_add(sync + SYNC_ARRIVE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// every thread of the workgroup; returns thread 0's departure ticket
+__device__ __forceinline__ unsigned fin_wait(unsigned* sync, int nfin) {
+  unsigned t = 0;
+  if (threadIdx.x == 0) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__hip_atomic_load(sync + SYNC_ARRIVE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)nfin) {
+      __builtin_amdgcn_s_sleep(1);
+      if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) {      // 2 s at 100 MHz: give up, never hang
+        __hip_atomic_store(sync + SYNC_ERR, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+    }
+    t = __hip_atomic_fetch_add(sync + SYNC_SUB + 16 * (blockIdx.x & 31u), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  return t;
+}
+__device__ __forceinline__ void fin_depart(unsigned* sync, unsigned ticket) {
+  if (threadIdx.x == 0) {
+    const unsigned grid = gridDim.x, i = blockIdx.x & 31u, cnt = (grid - i + 31u) >> 5;      // workgroups with this residue
+    if (ticket == cnt - 1) {
+      __hip_atomic_store(sync + SYNC_SUB + 16 * i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned ng = grid < 32u ? grid : 32u;
+      if (__hip_atomic_fetch_add(sync + SYNC_TOP, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ng - 1) {      // everybody has passed the wait
+        __hip_atomic_store(sync + SYNC_TOP, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(sync + SYNC_ARRIVE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
+}
+
 // groups are processed in order inside a block when moving averages are updated (two successive
-// BatchNormalization calls update them one after the other); otherwise gridDim.y = groups.
-__global__ __launch_bounds__(256) void stats_finalize_kernel(const float* partial, int G, int chunks, int C, long long rows,
-                                                             float eps, float* mean, float* rstd, float* mmean, float* mvar,
-                                                             float momentum) {
-  __shared__ double red[FL * FC * 2];
-  const int c = blockIdx.x * FC + threadIdx.x % FC, kl = threadIdx.x / FC;
-  const int g0 = mmean ? 0 : blockIdx.y, g1 = mmean ? G : blockIdx.y + 1;
+// BatchNormalization calls update them one after the other); otherwise by = the group (gridDim.y = groups).
+template <bool COH>
+__device__ __forceinline__ void stats_finalize_body(const float* partial, int G, int chunks, int C, long long rows, float eps, float* mean,
+                                                    float* rstd, float* mmean, float* mvar, float momentum, int bx, int by, double* red) {
+  const int c = bx * FC + threadIdx.x % FC, kl = threadIdx.x / FC;
+  const int g0 = mmean ? 0 : by, g1 = mmean ? G : by + 1;
+  const CohBuf cm = coh_buf(mean), cr = coh_buf(rstd);
   for (int g = g0; g < g1; ++g) {
     double s, s2;
     chunk_sum(partial, g, chunks, C, c, kl, red, s, s2);
@@ -183,8 +248,8 @@ __global__ __launch_bounds__(256) void stats_finalize_kernel(const float* partia
       double m = s / (double)rows;
       double var = s2 / (double)rows - m * m;
       if (var < 0) var = 0;
-      mean[g * C + c] = (float)m;
-      rstd[g * C + c] = 1.0f / sqrtf((float)var + eps);
+      st_f1<COH>(cm, mean + g * C + c, (float)m);
+      st_f1<COH>(cr, rstd + g * C + c, 1.0f / sqrtf((float)var + eps));
       if (mmean) {
         double adj = (double)rows / (double)(rows > 1 ? rows - 1 : 1);
         mmean[c] += ((float)m - mmean[c]) * (1.f - momentum);
@@ -193,17 +258,24 @@ __global__ __launch_bounds__(256) void stats_finalize_kernel(const float* partia
     }
   }
 }
-
-__global__ __launch_bounds__(256) void bwd_finalize_kernel(const float* partial, int G, int chunks, int C, float* sums,
-                                                           float* dgamma, float* dbeta, int accumulate) {
+__global__ __launch_bounds__(256) void stats_finalize_kernel(const float* partial, int G, int chunks, int C, long long rows,
+                                                             float eps, float* mean, float* rstd, float* mmean, float* mvar,
+                                                             float momentum) {
   __shared__ double red[FL * FC * 2];
-  const int c = blockIdx.x * FC + threadIdx.x % FC, kl = threadIdx.x / FC;
+  stats_finalize_body<false>(partial, G, chunks, C, rows, eps, mean, rstd, mmean, mvar, momentum, blockIdx.x, blockIdx.y, red);
+}
+
+template <bool COH>
+__device__ __forceinline__ void bwd_finalize_body(const float* partial, int G, int chunks, int C, float* sums, float* dgamma, float* dbeta,
+                                                  int accumulate, int bx, double* red) {
+  const int c = bx * FC + threadIdx.x % FC, kl = threadIdx.x / FC;
+  const CohBuf cs = coh_buf(sums);
   double tg = 0, tb = 0;
   for (int g = 0; g < G; ++g) {
     double s1, s2;
     chunk_sum(partial, g, chunks, C, c, kl, red, s1, s2);
     if (kl == 0 && c < C) {
-      if (sums) { sums[(g * C + c) * 2] = (float)s1; sums[(g * C + c) * 2 + 1] = (float)s2; }
+      if (sums) { st_f1<COH>(cs, sums + (g * C + c) * 2, (float)s1); st_f1<COH>(cs, sums + (g * C + c) * 2 + 1, (float)s2); }
       tb += s1; tg += s2;
     }
   }
@@ -212,61 +284,82 @@ __global__ __launch_bounds__(256) void bwd_finalize_kernel(const float* partial,
     if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)tb;
   }
 }
+__global__ __launch_bounds__(256) void bwd_finalize_kernel(const float* partial, int G, int chunks, int C, float* sums,
+                                                           float* dgamma, float* dbeta, int accumulate) {
+  __shared__ double red[FL * FC * 2];
+  bwd_finalize_body<false>(partial, G, chunks, C, sums, dgamma, dbeta, accumulate, blockIdx.x, red);
+}
 
 // forward: a = act(dropout(gamma*(y-mean)*rstd + beta)) = act(mk * ((y-mean)*A + beta)); each thread: one channel vector x 4 rows.
 // The per-(group, channel) constants are loaded once when the thread's rows lie in one statistics group (always,
-// except at group boundaries / 1x1 InstanceNorm maps).
-template <typename T, int ACT, bool MASK>
-__global__ __launch_bounds__(256) void norm_act_fwd_kernel(const NormP p, const RedGeom g, long long rows) {
+// except at group boundaries / 1x1 InstanceNorm maps).  FIN: the launch also finalizes the statistics (FinP above).
+template <typename T, int ACT, bool MASK, bool FIN>
+__global__ __launch_bounds__(256) void norm_act_fwd_kernel(const NormP p, const RedGeom g, long long rows, const FinP f) {
   constexpr int VEC = VecOf<T>::N;
   constexpr int U = 4;
   const unsigned idx = blockIdx.x * 256u + threadIdx.x;
   const int cv = (int)(idx & (unsigned)(g.cvecs - 1));
   const long long rb = (long long)(idx >> g.log2cv) * U;
-  if (rb >= rows) return;
+  const bool live = rb < rows;
+  if (!FIN && !live) return;
   uint4 vy[U];
 #pragma unroll
   for (int u = 0; u < U; ++u)
     vy[u] = rb + u < rows ? *(const uint4*)((const T*)p.y + (rb + u) * p.ypitch + cv * VEC) : make_uint4(0, 0, 0, 0);
-  float A[VEC], be[VEC], mu[VEC];        // z = (y - mu)*A + beta, subtraction first (no cancellation when |mu| >> sigma)
-  auto consts = [&](int grp) {
-    float ga[VEC], rs[VEC];
-    ldp<VEC>(p.gamma + cv * VEC, ga); ldp<VEC>(p.beta + cv * VEC, be);
-    ldp<VEC>(p.mean + grp * g.C + cv * VEC, mu); ldp<VEC>(p.rstd + grp * g.C + cv * VEC, rs);
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) A[e] = ga[e] * rs[e];
-  };
-  const long long rl = rb + U - 1 < rows ? rb + U - 1 : rows - 1;
-  const int g0 = (int)fdiv((unsigned)rb, g.divRpg), gl = (int)fdiv((unsigned)rl, g.divRpg);
-  const bool uni = g0 == gl;
-  if (uni) consts(g0);
-#pragma unroll
-  for (int u = 0; u < U; ++u) {
-    const long long row = rb + u;
-    if (row >= rows) break;
-    if (!uni) consts((int)fdiv((unsigned)row, g.divRpg));
-    float v[VEC], o[VEC], mk[VEC];
-    unpack16<T>(vy[u], v);
-    if (MASK) ld_mask<VEC>(p.mask + row * g.C + cv * VEC, mk);
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) {
-      float z = fmaf(v[e] - mu[e], A[e], be[e]);
-      if (MASK) z *= mk[e];
-      o[e] = act_c<ACT>(z, p.slope);
+  unsigned ticket = 0;
+  if constexpr (FIN) {
+    __shared__ double red[FL * FC * 2];
+    if (blockIdx.x < (unsigned)f.nfin) {
+      stats_finalize_body<true>(f.partial, f.G, f.chunks, g.C, f.rows, f.eps, f.mean, f.rstd, f.mmean, f.mvar, f.momentum,
+                                (int)(blockIdx.x % (unsigned)f.cb), (int)(blockIdx.x / (unsigned)f.cb), red);
+      fin_arrive(f.sync);
     }
-    *(uint4*)((T*)p.out + row * p.outpitch + cv * VEC) = pack16<T>(o);
+    ticket = fin_wait(f.sync, f.nfin);
   }
+  if (live) {
+    float A[VEC], be[VEC], mu[VEC];        // z = (y - mu)*A + beta, subtraction first (no cancellation when |mu| >> sigma)
+    const CohBuf cm = coh_buf(p.mean), cr = coh_buf(p.rstd);
+    auto consts = [&](int grp) {
+      float ga[VEC], rs[VEC];
+      ldp<VEC>(p.gamma + cv * VEC, ga); ldp<VEC>(p.beta + cv * VEC, be);
+      ldp_c<VEC, FIN>(cm, p.mean + grp * g.C + cv * VEC, mu); ldp_c<VEC, FIN>(cr, p.rstd + grp * g.C + cv * VEC, rs);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) A[e] = ga[e] * rs[e];
+    };
+    const long long rl = rb + U - 1 < rows ? rb + U - 1 : rows - 1;
+    const int g0 = (int)fdiv((unsigned)rb, g.divRpg), gl = (int)fdiv((unsigned)rl, g.divRpg);
+    const bool uni = g0 == gl;
+    if (uni) consts(g0);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long long row = rb + u;
+      if (row >= rows) break;
+      if (!uni) consts((int)fdiv((unsigned)row, g.divRpg));
+      float v[VEC], o[VEC], mk[VEC];
+      unpack16<T>(vy[u], v);
+      if (MASK) ld_mask<VEC>(p.mask + row * g.C + cv * VEC, mk);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        float z = fmaf(v[e] - mu[e], A[e], be[e]);
+        if (MASK) z *= mk[e];
+        o[e] = act_c<ACT>(z, p.slope);
+      }
+      *(uint4*)((T*)p.out + row * p.outpitch + cv * VEC) = pack16<T>(o);
+    }
+  }
+  if constexpr (FIN) fin_depart(f.sync, ticket);
 }
 
-// backward apply: dy = gamma*rstd*(dz - S1/R - xhat*S2/R) = dz*A + xhat*N2 + N1
-template <typename T, int ACT, bool MASK>
-__global__ __launch_bounds__(256) void norm_act_bwd_kernel(const NormP p, const RedGeom g, long long rows) {
+// backward apply: dy = gamma*rstd*(dz - S1/R - xhat*S2/R) = dz*A + xhat*N2 + N1.  FIN: the launch also finalizes the sums.
+template <typename T, int ACT, bool MASK, bool FIN>
+__global__ __launch_bounds__(256) void norm_act_bwd_kernel(const NormP p, const RedGeom g, long long rows, const FinP f) {
   constexpr int VEC = VecOf<T>::N;
   constexpr int U = 4;
   const unsigned idx = blockIdx.x * 256u + threadIdx.x;
   const int cv = (int)(idx & (unsigned)(g.cvecs - 1));
   const long long rb = (long long)(idx >> g.log2cv) * U;
-  if (rb >= rows) return;
+  const bool live = rb < rows;
+  if (!FIN && !live) return;
   uint4 vy[U], vd[U], v2[U];
 #pragma unroll
   for (int u = 0; u < U; ++u) {
@@ -275,46 +368,59 @@ __global__ __launch_bounds__(256) void norm_act_bwd_kernel(const NormP p, const 
     vd[u] = ok ? *(const uint4*)((const T*)p.da + (rb + u) * p.dapitch + cv * VEC) : make_uint4(0, 0, 0, 0);
     v2[u] = (ok && p.da2) ? *(const uint4*)((const T*)p.da2 + (rb + u) * p.da2pitch + cv * VEC) : make_uint4(0, 0, 0, 0);
   }
-  float ga[VEC], be[VEC], rs[VEC], mu[VEC], A[VEC], N1[VEC], N2[VEC];
-  const float invR = 1.0f / (float)g.rows_per_group;
-  auto consts = [&](int grp) {
-    float t[2 * VEC];
-    ldp<VEC>(p.gamma + cv * VEC, ga); ldp<VEC>(p.beta + cv * VEC, be);
-    ldp<VEC>(p.mean + grp * g.C + cv * VEC, mu); ldp<VEC>(p.rstd + grp * g.C + cv * VEC, rs);
-    ldp<2 * VEC>(p.sums + ((size_t)grp * g.C + cv * VEC) * 2, t);
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) {
-      A[e] = ga[e] * rs[e];
-      N1[e] = -A[e] * (t[2 * e] * invR);
-      N2[e] = -A[e] * (t[2 * e + 1] * invR);
+  unsigned ticket = 0;
+  if constexpr (FIN) {
+    __shared__ double red[FL * FC * 2];
+    if (blockIdx.x < (unsigned)f.nfin) {
+      bwd_finalize_body<true>(f.partial, f.G, f.chunks, g.C, f.sums, f.dgamma, f.dbeta, f.accumulate, (int)blockIdx.x, red);
+      fin_arrive(f.sync);
     }
-  };
-  const long long rl = rb + U - 1 < rows ? rb + U - 1 : rows - 1;
-  const int g0 = (int)fdiv((unsigned)rb, g.divRpg), gl = (int)fdiv((unsigned)rl, g.divRpg);
-  const bool uni = g0 == gl;
-  if (uni) consts(g0);
-#pragma unroll
-  for (int u = 0; u < U; ++u) {
-    const long long row = rb + u;
-    if (row >= rows) break;
-    if (!uni) consts((int)fdiv((unsigned)row, g.divRpg));
-    float yv[VEC], dv[VEC], d2[VEC], o[VEC], mk[VEC];
-    unpack16<T>(vy[u], yv); unpack16<T>(vd[u], dv);
-    if (p.da2) {
-      unpack16<T>(v2[u], d2);
-#pragma unroll
-      for (int e = 0; e < VEC; ++e) dv[e] += d2[e];
-    }
-    if (MASK) ld_mask<VEC>(p.mask + row * g.C + cv * VEC, mk);
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) {
-      const float xh = (yv[e] - mu[e]) * rs[e];
-      const float z = fmaf(ga[e], xh, be[e]);
-      const float dz = dz_c<ACT, MASK>(dv[e], z, MASK ? mk[e] : 1.f, p.slope);
-      o[e] = fmaf(dz, A[e], fmaf(xh, N2[e], N1[e]));
-    }
-    *(uint4*)((T*)p.out + row * p.outpitch + cv * VEC) = pack16<T>(o);
+    ticket = fin_wait(f.sync, f.nfin);
   }
+  if (live) {
+    float ga[VEC], be[VEC], rs[VEC], mu[VEC], A[VEC], N1[VEC], N2[VEC];
+    const float invR = 1.0f / (float)g.rows_per_group;
+    const CohBuf cs = coh_buf(p.sums);
+    auto consts = [&](int grp) {
+      float t[2 * VEC];
+      ldp<VEC>(p.gamma + cv * VEC, ga); ldp<VEC>(p.beta + cv * VEC, be);
+      ldp<VEC>(p.mean + grp * g.C + cv * VEC, mu); ldp<VEC>(p.rstd + grp * g.C + cv * VEC, rs);
+      ldp_c<2 * VEC, FIN>(cs, p.sums + ((size_t)grp * g.C + cv * VEC) * 2, t);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        A[e] = ga[e] * rs[e];
+        N1[e] = -A[e] * (t[2 * e] * invR);
+        N2[e] = -A[e] * (t[2 * e + 1] * invR);
+      }
+    };
+    const long long rl = rb + U - 1 < rows ? rb + U - 1 : rows - 1;
+    const int g0 = (int)fdiv((unsigned)rb, g.divRpg), gl = (int)fdiv((unsigned)rl, g.divRpg);
+    const bool uni = g0 == gl;
+    if (uni) consts(g0);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long long row = rb + u;
+      if (row >= rows) break;
+      if (!uni) consts((int)fdiv((unsigned)row, g.divRpg));
+      float yv[VEC], dv[VEC], d2[VEC], o[VEC], mk[VEC];
+      unpack16<T>(vy[u], yv); unpack16<T>(vd[u], dv);
+      if (p.da2) {
+        unpack16<T>(v2[u], d2);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) dv[e] += d2[e];
+      }
+      if (MASK) ld_mask<VEC>(p.mask + row * g.C + cv * VEC, mk);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        const float xh = (yv[e] - mu[e]) * rs[e];
+        const float z = fmaf(ga[e], xh, be[e]);
+        const float dz = dz_c<ACT, MASK>(dv[e], z, MASK ? mk[e] : 1.f, p.slope);
+        o[e] = fmaf(dz, A[e], fmaf(xh, N2[e], N1[e]));
+      }
+      *(uint4*)((T*)p.out + row * p.outpitch + cv * VEC) = pack16<T>(o);
+    }
+  }
+  if constexpr (FIN) fin_depart(f.sync, ticket);
 }
 
 // activation-only backward on the saved activation a: dy = (da + da2) * act'(a)
@@ -392,12 +498,24 @@ static int launch_partial(const NormP& p, const RedGeom& g, int groups, float* p
   return 0;
 }
 
+static long long apply_blocks(const RedGeom& g, long long rows) {
+  return ((rows + 3) / 4 * g.cvecs + 255) / 256;
+}
 template <typename K>
 static int launch_rows(K kern, const NormP& p, const RedGeom& g, long long rows, hipStream_t st) {
-  long long threads = (rows + 3) / 4 * g.cvecs;
-  GAN_LAUNCH(kern, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, p, g, rows);
+  GAN_LAUNCH(kern, dim3((unsigned)apply_blocks(g, rows)), dim3(256), 0, st, p, g, rows);
   GAN_CHECK_LAUNCH();
   return 0;
+}
+template <typename K>
+static int launch_rows_fin(K kern, const NormP& p, const RedGeom& g, long long rows, const FinP& f, hipStream_t st) {
+  GAN_LAUNCH(kern, dim3((unsigned)apply_blocks(g, rows)), dim3(256), 0, st, p, g, rows, f);
+  GAN_CHECK_LAUNCH();
+  return 0;
+}
+// the apply launch can carry the finalize: a sync area, the option, and at least as many workgroups as finalize work units
+static bool fin_fits(const void* sync, const RedGeom& g, long long rows, int nfin) {
+  return sync && gan_opt("norm.fin_in_apply") && (long long)nfin <= apply_blocks(g, rows);
 }
 
 // run F<ACT, MASK>() for the run-time (act, mask) pair
@@ -413,15 +531,28 @@ static int launch_rows(K kern, const NormP& p, const RedGeom& g, long long rows,
     default: return F(GAN_ACT_NONE, false);                                                                 \
   }
 
+// fin != nullptr: the launch also finalizes (FinP)
 template <typename T>
-static int launch_fwd(const NormP& p, const RedGeom& g, long long rows, hipStream_t st) {
-#define F(A, M) launch_rows(norm_act_fwd_kernel<T, A, M>, p, g, rows, st)
+static int launch_fwd(const NormP& p, const RedGeom& g, long long rows, const FinP* fin, hipStream_t st) {
+  if (fin) {
+#define F(A, M) launch_rows_fin(norm_act_fwd_kernel<T, A, M, true>, p, g, rows, *fin, st)
+    GAN_ACT_MASK_SWITCH(p.act, p.mask != nullptr, F)
+#undef F
+  }
+  const FinP none = {};
+#define F(A, M) launch_rows_fin(norm_act_fwd_kernel<T, A, M, false>, p, g, rows, none, st)
   GAN_ACT_MASK_SWITCH(p.act, p.mask != nullptr, F)
 #undef F
 }
 template <typename T>
-static int launch_bwd_apply(const NormP& p, const RedGeom& g, long long rows, hipStream_t st) {
-#define F(A, M) launch_rows(norm_act_bwd_kernel<T, A, M>, p, g, rows, st)
+static int launch_bwd_apply(const NormP& p, const RedGeom& g, long long rows, const FinP* fin, hipStream_t st) {
+  if (fin) {
+#define F(A, M) launch_rows_fin(norm_act_bwd_kernel<T, A, M, true>, p, g, rows, *fin, st)
+    GAN_ACT_MASK_SWITCH(p.act, p.mask != nullptr, F)
+#undef F
+  }
+  const FinP none = {};
+#define F(A, M) launch_rows_fin(norm_act_bwd_kernel<T, A, M, false>, p, g, rows, none, st)
   GAN_ACT_MASK_SWITCH(p.act, p.mask != nullptr, F)
 #undef F
 }
@@ -441,6 +572,24 @@ static int launch_act_bwd(const NormP& p, const RedGeom& g, long long rows, hipS
   }
 }
 
+// finalize (sums, dgamma, dbeta) + apply of a normalisation backward: inside the apply launch when the descriptor has a sync area
+// and the grid can carry it, a finalize launch in front of it otherwise
+static int bwd_finalize_apply(const GanNormBwdDesc* d, const NormP& p, const RedGeom& g, long long rows, const float* partial, int chunks,
+                              float* sums, hipStream_t st) {
+  FinP f = {};
+  f.partial = partial; f.sync = d->sync; f.G = d->groups; f.chunks = chunks; f.cb = (g.C + FC - 1) / FC; f.nfin = f.cb;
+  f.sums = sums; f.dgamma = d->dgamma; f.dbeta = d->dbeta; f.accumulate = d->accumulate;
+  const FinP* fin = nullptr;
+  if (fin_fits(d->sync, g, rows, f.nfin)) {
+    fin = &f;
+  } else {
+    GAN_LAUNCH(bwd_finalize_kernel, dim3(f.cb), dim3(256), 0, st, partial, d->groups, chunks, g.C, sums, d->dgamma, d->dbeta, d->accumulate);
+    GAN_CHECK_LAUNCH();
+  }
+  return d->dtype == GAN_F32 ? launch_bwd_apply<float>(p, g, rows, fin, st) : d->dtype == GAN_F16 ? launch_bwd_apply<f16_t>(p, g, rows, fin, st)
+                                                                                                 : launch_bwd_apply<bf16_t>(p, g, rows, fin, st);
+}
+
 extern "C" {
 
 size_t gan_norm_workspace_bytes(int32_t groups, int32_t c, int64_t rows_per_group) {
@@ -448,26 +597,38 @@ size_t gan_norm_workspace_bytes(int32_t groups, int32_t c, int64_t rows_per_grou
   return red_ws_bytes(groups, pick_chunks(rows_per_group, 256 / cvecs, groups), c);
 }
 
-int gan_norm_stats(const GanNormDesc* d, gan_stream_t stream) {
+static int norm_stats_partial(const GanNormDesc* d, RedGeom* g, hipStream_t st) {
   if (!d || d->struct_size != sizeof(GanNormDesc) || !d->y.ptr || !d->mean || !d->rstd || !d->workspace) return GAN_E_ARG;
-  RedGeom g;
-  int rc = red_geom(d->y, d->groups, d->dtype, &g);
+  int rc = red_geom(d->y, d->groups, d->dtype, g);
   if (rc) return rc;
-  if (red_ws_bytes(d->groups, g.chunks, g.C) > d->workspace_bytes) return GAN_E_WORKSPACE;
+  if (red_ws_bytes(d->groups, g->chunks, g->C) > d->workspace_bytes) return GAN_E_WORKSPACE;
   NormP p = {};
   p.y = d->y.ptr; p.ypitch = d->y.pitch;
-  hipStream_t st = (hipStream_t)stream;
   float* partial = (float*)d->workspace;
-  rc = d->dtype == GAN_F32 ? launch_partial<float, 0>(p, g, d->groups, partial, st)
-       : d->dtype == GAN_F16 ? launch_partial<f16_t, 0>(p, g, d->groups, partial, st)
-                             : launch_partial<bf16_t, 0>(p, g, d->groups, partial, st);
+  return d->dtype == GAN_F32 ? launch_partial<float, 0>(p, *g, d->groups, partial, st)
+       : d->dtype == GAN_F16 ? launch_partial<f16_t, 0>(p, *g, d->groups, partial, st)
+                             : launch_partial<bf16_t, 0>(p, *g, d->groups, partial, st);
+}
+
+int gan_norm_stats(const GanNormDesc* d, gan_stream_t stream) {
+  RedGeom g;
+  hipStream_t st = (hipStream_t)stream;
+  int rc = norm_stats_partial(d, &g, st);
   if (rc) return rc;
   GAN_LAUNCH(stats_finalize_kernel, dim3((g.C + FC - 1) / FC, d->moving_mean ? 1 : d->groups), dim3(256), 0, st,
-                     (const float*)partial, d->groups, g.chunks, g.C, g.rows_per_group, d->eps, d->mean, d->rstd,
+                     (const float*)d->workspace, d->groups, g.chunks, g.C, g.rows_per_group, d->eps, d->mean, d->rstd,
                      d->moving_mean, d->moving_var, d->momentum);
   GAN_CHECK_LAUNCH();
   return 0;
 }
+
+int gan_norm_stats_partial(const GanNormDesc* d, gan_stream_t stream) {
+  RedGeom g;
+  return norm_stats_partial(d, &g, (hipStream_t)stream);
+}
+
+size_t gan_norm_sync_bytes(void) { return (size_t)SYNC_WORDS * sizeof(unsigned); }
+size_t gan_norm_sync_error_offset(void) { return (size_t)SYNC_ERR * sizeof(unsigned); }
 
 int gan_norm_stats_finalize(const GanNormDesc* d, int32_t chunks, gan_stream_t stream) {
   if (!d || d->struct_size != sizeof(GanNormDesc) || !d->y.ptr || !d->mean || !d->rstd || !d->workspace || chunks <= 0) return GAN_E_ARG;
@@ -482,7 +643,7 @@ int gan_norm_stats_finalize(const GanNormDesc* d, int32_t chunks, gan_stream_t s
   return 0;
 }
 
-int gan_norm_act_fwd(const GanNormDesc* d, gan_stream_t stream) {
+static int norm_act_fwd_impl(const GanNormDesc* d, const FinP* fin_in, int32_t chunks, hipStream_t st) {
   if (!d || d->struct_size != sizeof(GanNormDesc) || !d->y.ptr || !d->a.ptr || !d->mean || !d->rstd || !d->gamma || !d->beta) return GAN_E_ARG;
   RedGeom g;
   int rc = red_geom(d->y, d->groups, d->dtype, &g);
@@ -493,8 +654,34 @@ int gan_norm_act_fwd(const GanNormDesc* d, gan_stream_t stream) {
   p.gamma = d->gamma; p.beta = d->beta; p.mean = d->mean; p.rstd = d->rstd; p.mask = d->dropmask;
   p.act = d->act; p.slope = d->slope;
   long long rows = (long long)d->y.n * g.hw;
-  hipStream_t st = (hipStream_t)stream;
-  return d->dtype == GAN_F32 ? launch_fwd<float>(p, g, rows, st) : d->dtype == GAN_F16 ? launch_fwd<f16_t>(p, g, rows, st) : launch_fwd<bf16_t>(p, g, rows, st);
+  FinP f = {};
+  const FinP* fin = nullptr;
+  if (fin_in) {              // finalize + apply: one launch when the apply grid can carry the finalize, two otherwise
+    if (!d->workspace) return GAN_E_ARG;
+    if (chunks <= 0) chunks = g.chunks;        // the partials gan_norm_stats_partial() wrote
+    if ((size_t)d->groups * chunks * g.C * 2 * sizeof(float) > d->workspace_bytes) return GAN_E_WORKSPACE;
+    f.partial = (const float*)d->workspace; f.sync = d->sync; f.G = d->groups; f.chunks = chunks;
+    f.cb = (g.C + FC - 1) / FC; f.nfin = f.cb * (d->moving_mean ? 1 : d->groups);
+    f.rows = g.rows_per_group; f.eps = d->eps; f.momentum = d->momentum; f.mean = d->mean; f.rstd = d->rstd;
+    f.mmean = d->moving_mean; f.mvar = d->moving_var;
+    if (fin_fits(d->sync, g, rows, f.nfin)) {
+      fin = &f;
+    } else {
+      GAN_LAUNCH(stats_finalize_kernel, dim3(f.cb, d->moving_mean ? 1 : d->groups), dim3(256), 0, st, f.partial, d->groups, chunks, g.C,
+                 g.rows_per_group, d->eps, d->mean, d->rstd, d->moving_mean, d->moving_var, d->momentum);
+      GAN_CHECK_LAUNCH();
+    }
+  }
+  return d->dtype == GAN_F32 ? launch_fwd<float>(p, g, rows, fin, st) : d->dtype == GAN_F16 ? launch_fwd<f16_t>(p, g, rows, fin, st) : launch_fwd<bf16_t>(p, g, rows, fin, st);
+}
+
+int gan_norm_act_fwd(const GanNormDesc* d, gan_stream_t stream) {
+  return norm_act_fwd_impl(d, nullptr, 0, (hipStream_t)stream);
+}
+
+int gan_norm_finalize_act_fwd(const GanNormDesc* d, int32_t chunks, gan_stream_t stream) {
+  const FinP want = {};
+  return norm_act_fwd_impl(d, &want, chunks, (hipStream_t)stream);
 }
 
 int gan_norm_act_bwd(const GanNormBwdDesc* d, gan_stream_t stream) {
@@ -519,11 +706,8 @@ int gan_norm_act_bwd(const GanNormBwdDesc* d, gan_stream_t stream) {
        : d->dtype == GAN_F16 ? launch_bwd_partial<f16_t>(p, g, d->groups, partial, st)
                              : launch_bwd_partial<bf16_t>(p, g, d->groups, partial, st);
   if (rc) return rc;
-  GAN_LAUNCH(bwd_finalize_kernel, dim3((g.C + FC - 1) / FC), dim3(256), 0, st, (const float*)partial, d->groups,
-                     g.chunks, g.C, sums, d->dgamma, d->dbeta, d->accumulate);
-  GAN_CHECK_LAUNCH();
   long long rows = (long long)d->y.n * g.hw;
-  return d->dtype == GAN_F32 ? launch_bwd_apply<float>(p, g, rows, st) : d->dtype == GAN_F16 ? launch_bwd_apply<f16_t>(p, g, rows, st) : launch_bwd_apply<bf16_t>(p, g, rows, st);
+  return bwd_finalize_apply(d, p, g, rows, partial, g.chunks, sums, st);
 }
 
 /* Second half of a normalisation backward whose first half ran in the producing dgrad's epilogue (GanBwdFuse): d->da holds
@@ -545,14 +729,8 @@ int gan_norm_act_bwd_fused(const GanNormBwdDesc* d, int32_t chunks, gan_stream_t
   float* partial = (float*)d->workspace;
   float* sums = partial + (size_t)d->groups * chunks * g.C * 2;
   p.sums = sums;
-  hipStream_t st = (hipStream_t)stream;
-  GAN_LAUNCH(bwd_finalize_kernel, dim3((g.C + FC - 1) / FC), dim3(256), 0, st, (const float*)partial, d->groups,
-                     chunks, g.C, sums, d->dgamma, d->dbeta, d->accumulate);
-  GAN_CHECK_LAUNCH();
   long long rows = (long long)d->y.n * g.hw;
-  return d->dtype == GAN_F32 ? launch_rows(norm_act_bwd_kernel<float, GAN_ACT_NONE, false>, p, g, rows, st)
-       : d->dtype == GAN_F16 ? launch_rows(norm_act_bwd_kernel<f16_t, GAN_ACT_NONE, false>, p, g, rows, st)
-                             : launch_rows(norm_act_bwd_kernel<bf16_t, GAN_ACT_NONE, false>, p, g, rows, st);
+  return bwd_finalize_apply(d, p, g, rows, partial, chunks, sums, (hipStream_t)stream);
 }
 
 static int bias_grad_impl(int32_t dtype, const GanTensor& dy, float* dbias, int32_t accumulate, void* workspace,

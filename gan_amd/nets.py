@@ -25,6 +25,7 @@ BN_EPS, IN_EPS, BN_MOMENTUM = 1e-3, 1e-5, 0.99       # Keras BatchNormalization 
 
 
 FUSE_BWD = True              # dgrad epilogues start the backward of the layer below (GanBwdFuse)
+NORM_SYNC_SLOTS = 2048       # sync areas (2,176 B each) for normalisation launches that carry their own finalize: Ctx.new_sync()
 STATS_RESERVE = 8 << 20      # room kept behind a conv's split-K slabs for its fused statistics partials
 
 
@@ -102,9 +103,23 @@ class Ctx:
         # layer stacks (gan_conv_stack_*): one timeout flag for all of them - a grid barrier that could not complete sets it
         self.stack_err = torch.zeros(1, dtype=torch.int32, device=self.device)
         self.use_stacks = bool(L.get_option('conv.stack'))
+        # sync areas of the normalisation launches that carry their own finalize (GanNormDesc.sync, include/gan_amd.h): one per
+        # layer invocation and direction, handed out when the op lists are built, zero now and self-cleaning afterwards
+        self.fin_in_apply = bool(L.get_option('norm.fin_in_apply'))
+        self._sync_words = self.lib.gan_norm_sync_bytes() // 4
+        self._sync_err = self.lib.gan_norm_sync_error_offset() // 4
+        self.norm_sync = torch.zeros(NORM_SYNC_SLOTS, self._sync_words, dtype=torch.int32, device=self.device)
+        self._sync_next = 0
 
     def stream(self):
         return torch.cuda.current_stream(self.device).cuda_stream
+
+    def new_sync(self):
+        """Device pointer of an unused sync area, or None (option off / pool used up: the layer keeps its finalize launch)."""
+        if not self.fin_in_apply or self._sync_next >= NORM_SYNC_SLOTS:
+            return None
+        self._sync_next += 1
+        return self.norm_sync.data_ptr() + (self._sync_next - 1) * self._sync_words * 4
 
     def join(self, waiter, lane):
         """`waiter` waits for everything queued on `lane` (the join of a fork made with lane.wait_stream)."""
@@ -168,6 +183,8 @@ class Ctx:
         flag instead of hanging the GPU (its results are then garbage)."""
         if int(self.stack_err.item()):
             raise L.GanAmdError("a layer-stack kernel timed out at a grid barrier (more than two of them running at once?)")
+        if self._sync_next and bool(self.norm_sync[:self._sync_next, self._sync_err].any().item()):
+            raise L.GanAmdError("a normalisation launch timed out waiting for its own finalize workgroups")
 
     def run_on(self, ops, stream):
         """All ops in program order on one explicit stream."""
@@ -587,13 +604,20 @@ class _Builder:
             mv = self.P.state[name + '.moving_variance'].data_ptr()
         d = L.GanNormDesc(self.ctx.dt, y, a, groups, eps, self.P.ptr(name + gk), self.P.ptr(name + bk),
                           mean.data_ptr(), rstd.data_ptr(), mm, mv, BN_MOMENTUM, mask_ptr, L.ACTS[act], LEAKY_ALPHA,
-                          self.ws_ptr, self.ws_bytes)
+                          self.ws_ptr, self.ws_bytes, self.ctx.new_sync())
         r = self._desc(d)
+        one = bool(d.sync)     # finalize + apply as one call (one launch where the apply grid can carry the finalize)
         if fused_chunks:       # the producing convolution (epilogue or split-K reduce) already wrote the partials
             df = L.GanNormDesc.from_buffer_copy(d)
             df.workspace = fused_ptr or self.ws_ptr
+            if one:
+                df.workspace_bytes = self.ws_bytes - (df.workspace - self.ws_ptr)
+                return [(self.lib.gan_norm_finalize_act_fwd, (self._desc(df), fused_chunks), f"norm_fin_act_fwd({name})")]
             return [(self.lib.gan_norm_stats_finalize, (self._desc(df), fused_chunks), f"norm_stats_finalize({name})"),
                     (self.lib.gan_norm_act_fwd, (r,), f"norm_act_fwd({name})")]
+        if one:
+            return [(self.lib.gan_norm_stats_partial, (r,), f"norm_stats_partial({name})"),
+                    (self.lib.gan_norm_finalize_act_fwd, (r, 0), f"norm_fin_act_fwd({name})")]
         return [(self.lib.gan_norm_stats, (r,), f"norm_stats({name})"),
                 (self.lib.gan_norm_act_fwd, (r,), f"norm_act_fwd({name})")]
 
@@ -605,7 +629,7 @@ class _Builder:
                              L.ACTS[act], LEAKY_ALPHA,
                              self.P.ptr(name + gk, 'grad') if want_param_grads else None,
                              self.P.ptr(name + bk, 'grad') if want_param_grads else None,
-                             int(accumulate), self.ws_ptr, self.ws_bytes)
+                             int(accumulate), self.ws_ptr, self.ws_bytes, self.ctx.new_sync())
         return (self.lib.gan_norm_act_bwd, (self._desc(d),), f"norm_act_bwd({name})")
 
     def norm_bwd_fused(self, name, y, dz, dy, groups, mean_ptr, rstd_ptr, chunks, partial_ptr, want_param_grads, accumulate):
@@ -616,7 +640,7 @@ class _Builder:
                              L.ACTS[None], LEAKY_ALPHA,
                              self.P.ptr(name + gk, 'grad') if want_param_grads else None,
                              self.P.ptr(name + bk, 'grad') if want_param_grads else None,
-                             int(accumulate), partial_ptr, self.ws_bytes - (partial_ptr - self.ws_ptr))
+                             int(accumulate), partial_ptr, self.ws_bytes - (partial_ptr - self.ws_ptr), self.ctx.new_sync())
         return (self.lib.gan_norm_act_bwd_fused, (self._desc(d), chunks), f"norm_act_bwd_fused({name})")
 
     def act_bwd(self, a, da, da2, dy, act):

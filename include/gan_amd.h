@@ -255,12 +255,28 @@ typedef struct GanNormDesc {
   float slope;
   void* workspace;          /* >= gan_norm_workspace_bytes() */
   size_t workspace_bytes;
+  uint32_t* sync;           /* optional: gan_norm_sync_bytes() of device memory, zero when first used and owned by this
+                               layer invocation (launches that share an area must be stream-ordered; the area zeroes
+                               itself again): lets gan_norm_finalize_act_fwd() run as ONE launch */
 } GanNormDesc;
 int gan_norm_stats(const GanNormDesc* d, gan_stream_t stream);
 /* finalize only: d->workspace already holds `chunks` partials per group written by a convolution epilogue */
 int gan_norm_stats_finalize(const GanNormDesc* d, int32_t chunks, gan_stream_t stream);
 int gan_norm_act_fwd(const GanNormDesc* d, gan_stream_t stream);
 size_t gan_norm_workspace_bytes(int32_t groups, int32_t c, int64_t rows_per_group);
+/* The same Keras layer call (base_gan.py:83-87, 113-120, 151-155; utils.py:26-30) in two steps whose second one is a single
+ * launch: gan_norm_stats_partial() = the partial sums of gan_norm_stats() without its finalize launch;
+ * gan_norm_finalize_act_fwd() = gan_norm_stats_finalize(d, chunks) + gan_norm_act_fwd(d), bit-identical to that pair
+ * (chunks <= 0: the partials gan_norm_stats_partial() wrote).  With d->sync the finalize rides inside the apply launch:
+ * its first workgroups finalize and publish mean / rstd (+ the moving averages), the others wait for them with their rows'
+ * loads already in flight (option norm.fin_in_apply, default 1; without a sync area, or when the apply grid has fewer
+ * workgroups than the finalize has work units: two launches).  Every wait is bounded; gan_norm_sync_error_offset() locates the flag a
+ * timed-out wait leaves in the area. */
+int gan_norm_stats_partial(const GanNormDesc* d, gan_stream_t stream);
+int gan_norm_finalize_act_fwd(const GanNormDesc* d, int32_t chunks, gan_stream_t stream);
+size_t gan_norm_sync_bytes(void);
+/* byte offset, inside a sync area, of the 32-bit word that is non-zero after a wait timed out (host reads it after a sync) */
+size_t gan_norm_sync_error_offset(void);
 
 typedef struct GanNormBwdDesc {
   uint32_t struct_size;  /* sizeof(GanNormBwdDesc) of the caller's build */
@@ -282,6 +298,8 @@ typedef struct GanNormBwdDesc {
   int32_t accumulate;       /* dgamma/dbeta += */
   void* workspace;
   size_t workspace_bytes;
+  uint32_t* sync;           /* optional sync area (GanNormDesc.sync): the apply launch of gan_norm_act_bwd() /
+                               gan_norm_act_bwd_fused() then also finalizes the sums, dgamma and dbeta (one launch less) */
 } GanNormBwdDesc;
 int gan_norm_act_bwd(const GanNormBwdDesc* d, gan_stream_t stream);
 /* The same layer backward when its first half already ran in the producing dgrad's epilogue (GanBwdFuse above): d->da holds

@@ -1038,6 +1038,59 @@ def test_norm_act_fwd_bwd(ctx, kind, groups_of, act, drop):
     assert rel(dg.cpu().numpy(), dgs) < max(tol, 1e-4) and rel(db.cpu().numpy(), dbs) < max(tol, 1e-4)
 
 
+@pytest.mark.parametrize("kind,groups_of", [('batchnorm', lambda n: 1), ('batchnorm', lambda n: 2), ('instancenorm', lambda n: n)])
+@pytest.mark.parametrize("shape", [(4, 8, 64), (4, 30, 128), (2, 64, 256), (2, 2, 512)])
+def test_norm_finalize_inside_apply_equals_separate_launches(ctx, kind, groups_of, shape):
+    """GanNormDesc.sync / GanNormBwdDesc.sync: the apply launch finalizes the statistics (forward) / the sums, dgamma, dbeta (backward)
+    itself - its first workgroups do it, the rest wait for them.  Bit-identical to the separate finalize launch; the sync area zeroes
+    itself (three launches in a row on one area); (2, 2, 512): fewer apply workgroups than finalize work units -> two launches."""
+    from gan_amd import _lib as L
+    from gan_amd.nets import Buf
+    N, H, c = shape
+    G = groups_of(N)
+    act, drop = ('relu', True) if c == 128 else ('lrelu', False)
+    rng = np.random.default_rng(11)
+    y = q(ctx, rng.standard_normal((N, H, H, c)) * 1.5 + 0.3)
+    f32 = torch.float32
+    tg = torch.from_numpy((1 + 0.2 * rng.standard_normal(c)).astype(np.float32)).to(ctx.device)
+    tb = torch.from_numpy((0.2 * rng.standard_normal(c)).astype(np.float32)).to(ctx.device)
+    tm = torch.from_numpy((rng.random((N, H, H, c)) > 0.5).astype(np.uint8)).to(ctx.device) if drop else None
+    yb, yv = dev(ctx, y)
+    da = q(ctx, rng.standard_normal((N, H, H, c)))
+    dab, dav = dev(ctx, da, pitch=c + 8)
+    bn = kind == 'batchnorm'
+    eps = 1e-3 if bn else 1e-5
+    words = ctx.lib.gan_norm_sync_bytes() // 4
+    sync = torch.zeros(2, words, dtype=torch.int32, device=ctx.device)
+    res = {}
+    for how in ('separate', 'inside'):
+        ab, dyb = Buf(ctx, N, H, H, c), Buf(ctx, N, H, H, c)
+        mean, rstd = torch.zeros(G * c, dtype=f32, device=ctx.device), torch.zeros(G * c, dtype=f32, device=ctx.device)
+        mm, mv = torch.zeros(c, dtype=f32, device=ctx.device), torch.ones(c, dtype=f32, device=ctx.device)
+        dg, db = torch.zeros(c, dtype=f32, device=ctx.device), torch.zeros(c, dtype=f32, device=ctx.device)
+        sp = (sync[0].data_ptr(), sync[1].data_ptr()) if how == 'inside' else (None, None)
+        d = L.GanNormDesc(ctx.dt, yv, ab.view(), G, eps, tg.data_ptr(), tb.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                          mm.data_ptr() if bn else None, mv.data_ptr() if bn else None, 0.99, tm.data_ptr() if drop else None,
+                          L.ACTS[act], 0.3, ctx.ws_ptr, ctx.ws_bytes, sp[0])
+        bd = L.GanNormBwdDesc(ctx.dt, yv, dav, L.GanTensor(None, 0, 0, 0, 0, 0), dyb.view(), G, tg.data_ptr(), tb.data_ptr(), mean.data_ptr(),
+                              rstd.data_ptr(), tm.data_ptr() if drop else None, L.ACTS[act], 0.3, dg.data_ptr(), db.data_ptr(), 0,
+                              ctx.ws_ptr, ctx.ws_bytes, sp[1])
+        for it in range(3):                      # (the moving averages move three times either way)
+            if how == 'separate':
+                assert ctx.lib.gan_norm_stats(C.byref(d), ctx.stream()) == 0
+                assert ctx.lib.gan_norm_act_fwd(C.byref(d), ctx.stream()) == 0
+            else:
+                assert ctx.lib.gan_norm_stats_partial(C.byref(d), ctx.stream()) == 0
+                assert ctx.lib.gan_norm_finalize_act_fwd(C.byref(d), 0, ctx.stream()) == 0
+            assert ctx.lib.gan_norm_act_bwd(C.byref(bd), ctx.stream()) == 0
+        torch.cuda.synchronize()
+        res[how] = [t.clone() for t in (ab.t, dyb.t, mean, rstd, mm, mv, dg, db)]
+    assert int(sync.abs().sum()) == 0            # every counter back at zero, no timeout flag
+    for a_, b_, what in zip(res['separate'], res['inside'], ('a', 'dy', 'mean', 'rstd', 'moving_mean', 'moving_var', 'dgamma', 'dbeta')):
+        assert torch.equal(a_, b_), what
+    assert float(res['inside'][1].float().abs().max()) > 0
+
+
 def test_act_bwd_bias_grad_losses(ctx):
     from gan_amd import _lib as L
     from gan_amd.nets import Buf
