@@ -41,7 +41,7 @@ def gemm_profile(step, inputs, reps=5):
     def timed_run(ops, lane=0):
         st = ctx.stream()
         for op in ops:
-            meta = op[3] if len(op) > 3 else None
+            meta = op[3] if len(op) > 3 and op[3].get('kind') == 'gemm' else None
             if meta is None:
                 rc = op[0](*op[1], st)
             else:

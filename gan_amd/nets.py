@@ -649,10 +649,12 @@ class _Builder:
                             self.ws_ptr, self.ws_bytes)
         return (self.lib.gan_act_bwd, (self._desc(d),), "act_bwd")
 
-    def bias_grad(self, dy, dbias_ptr, accumulate):
+    def bias_grad(self, dy, dbias_ptr, accumulate, side=False):
+        """side: a side-stream op like the wgrad GEMMs (it only feeds Adam): scratch in the wgrad lane's workspace."""
         self.keep.append(dy)
-        return (self.lib.gan_bias_grad, (self.ctx.dt, C.byref(dy), dbias_ptr, int(accumulate), self.ws_ptr,
-                                         self.ws_bytes), "bias_grad")
+        op = (self.lib.gan_bias_grad, (self.ctx.dt, C.byref(dy), dbias_ptr, int(accumulate), self.ws_side_ptr if side else self.ws_ptr,
+                                       self.ws_bytes), "bias_grad")
+        return op + (dict(kind='side', kernel='bias_grad', flops=0.0, shape='bias'), True) if side else op
 
 
 class _Stack:
@@ -884,7 +886,7 @@ class GenCall:
         ops.append(bd.act_bwd(self.out.view(), self.dgen.view(), self.dgen2.view() if use_dgen2 else None,
                               self.dpre.view(), 'tanh'))
         wgrad(W(self.dpre).view(), W(self.cat[6]).view(), 'last.kernel', C_, 128, 2)
-        ops.append(bd.bias_grad(self.dpre.view(), P.ptr('last.bias', 'grad'), accumulate))
+        ops.append(bd.bias_grad(self.dpre.view(), P.ptr('last.bias', 'grad'), accumulate, side=bool(getattr(self, 'bias_grad_on_side', False))))
 
         def up_spec(j):         # backward of up j (ReLU [+ dropout] after the norm) on the leading G_UP[j] channels of dcat[j]
             mean, rstd = self.stats[f'up{j}']
@@ -1060,7 +1062,7 @@ class GenCall:
             self._bwd_cache[key] = self._build_bwd(use_dgen2, need_dx, accumulate, wgrads, adam, wire)
         ops = self._bwd_cache[key]
         is_w = lambda o: len(o) > 4 and o[4]
-        idx = [i for i, o in enumerate(ops) if is_w(o)]
+        idx = [i for i, o in enumerate(ops) if is_w(o) and o[2] == 'conv_wgrad']     # (other side ops ride in the stage they fall into)
         bounds = [0] + [idx[c] for c in cuts if 0 < c < len(idx)] + [len(ops)]
         skey = ('stages', key, tuple(bounds))          # (cached: merged layer stacks hold device plans, built outside any capture)
         if skey not in self._bwd_cache:

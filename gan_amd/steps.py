@@ -236,6 +236,10 @@ class Pix2PixStep(_StepBase):
     wgrad_alt = ('down3.kernel', 'down2.kernel', 'down1.kernel', 'down0.kernel')   # kernels of G whose wgrad launches run on a SECOND wgrad lane
                                  # (lane 4, own slab workspace): the last stage's GEMMs beside the optimiser-carrying (HBM-bound) launches of the
                                  # stage before instead of behind them: +1.0 % (5,363 -> 5,421 img/s, two interleaved pairs)
+    adam_begin_early = True      # G's gan_adam_begin (step count, lr_t: one tiny launch) at the head of D(real)'s lane instead of on the main chain
+                                 # in front of G's backward
+    bias_grad_on_side = True     # the bias gradient of G's head (two launches that only feed Adam) as a side-stream op of the first wgrad stage,
+                                 # off the dgrad chain
     ddp_buckets = True           # data parallel, bf16/f32: the bucketed schedule (False: the phased one)
     ddp_graphs = 4               # bucketed schedule: compute graphs per step (4, 3 or 2)
     ddp_late_comm = True         # a boundary's collectives are issued after the NEXT compute graph has been enqueued
@@ -265,6 +269,7 @@ class Pix2PixStep(_StepBase):
     def _prebuild_fused_adam(self):
         if not self.g._bwd_cache:
             self.g.alt_wgrad = frozenset(self.wgrad_alt)
+            self.g.bias_grad_on_side = bool(self.bias_grad_on_side and self.ctx.lanes)
         if self._wgrad_adam_ok() and not self.early_adam:
             adam = (self.b1, self.b2)
             self.g.bwd_stages(list(self.wgrad_cuts), use_dgen2=True, adam=adam)       # (op lists, layer-stack plans, device tables)
@@ -281,6 +286,7 @@ class Pix2PixStep(_StepBase):
         B, Cc, g, d = self.B, self.C, self.g, self.d
         if not g._bwd_cache:
             g.alt_wgrad = frozenset(self.wgrad_alt)       # (settled before the first backward op list is built)
+            g.bias_grad_on_side = bool(self.bias_grad_on_side and self.ctx.lanes)
             if not d._cache:
                 d._bd2.wgrad_concurrent = int(self.d_wgrad_concurrent)
         if phase == 2:
@@ -311,11 +317,17 @@ class Pix2PixStep(_StepBase):
             # BatchNormalization call order (real, then fake) as pix2pix.py:202-203.
             main_, lane2_ = self.ctx.lane_stream(0), self.ctx.lane_stream(2)
 
+            # (the optimiser-carrying wgrad launches of G's backward need this step's lr_t: nothing before them reads it)
+            begin_early = bool(self.adam_begin_early and training and phase == 0 and self._wgrad_adam_ok() and getattr(self, '_capturing', False)
+                               and getattr(self, '_updating', False) and not self.early_adam)
+            self._adam_begun = begin_early
+
             def start_dreal():
                 if head_split:
                     main_.wait_event(head_ev)                        # masks (and the packs) are in place before the decoder needs them
                 lane2_.wait_stream(main_)
-                self.ctx.run_on(d.forward_part_ops(0, lane=2), lane2_)
+                pre = self.G.params.adam_begin_ops(self.lr, self.b1, self.b2) if begin_early else []
+                self.ctx.run_on(pre + d.forward_part_ops(0, lane=2), lane2_)
             if head_split:
                 g.forward(inner_hook=start_dreal, masks_done=masks_side)
             else:
@@ -397,7 +409,8 @@ class Pix2PixStep(_StepBase):
                     # lr_t of this step must exist before the first fused wgrad; a stage's wgrads start after every dgrad of its
                     # layers has been enqueued (staged order), so rewriting those layers' weights there is safe
                     adam = (self.b1, self.b2)
-                    self.ctx.run(self.G.params.adam_begin_ops(self.lr, self.b1, self.b2))
+                    if not (dreal and getattr(self, '_adam_begun', False)):
+                        self.ctx.run(self.G.params.adam_begin_ops(self.lr, self.b1, self.b2))
                     g.backward(use_dgen2=True, defer_wgrads='staged', adam=adam)
                     self._adam_wfused = {self.G: g.adam_fused[(True, False, False, 'own', adam)]}
                 else:
