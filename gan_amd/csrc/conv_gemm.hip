@@ -1931,8 +1931,10 @@ static int plan_gemm(const GanConvDesc* d, int op, GemmPlan* pl) {
   } else
   if (want_stats && splits == 1 && p.vec_store && BN <= 64 * 8 && x.n % d->stats_groups == 0) {
     const long long rpg = M / d->stats_groups;            // GEMM rows per statistics group (per parity)
-    if (rpg % BM == 0 && (BM == 256 ? 512 : 256) >= BN) {
-      p.stats_tpg = (int)(rpg / BM);
+    // groups are whole numbers of M tiles - or there is ONE group, whose last tile may be ragged (the epilogue sums rows < M only):
+    // PatchGAN's 31 x 31 layer (base_gan.py:146-151) with D(real) and D(fake) as separate launches
+    if ((rpg % BM == 0 || d->stats_groups == 1) && (BM == 256 ? 512 : 256) >= BN) {
+      p.stats_tpg = (int)((rpg + BM - 1) / BM);
       pl->stats_chunks = p.stats_tpg * P;
       p.stats = d->stats_partial;
     }

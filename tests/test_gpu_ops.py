@@ -207,7 +207,10 @@ CONVT_CASES = [  # (N, h, Cin, Cout)
                                   ('conv_fwd', 4, 4, 512, 512, 4),
                                   # ... of several row groups per workgroup (round 5): G.down3 / up3 / up4 forward at batch 16 - 4,096 rows x 512
                                   # channels was 2,048 chunks of two rows and fell back to a separate statistics pass
-                                  ('conv_fwd', 16, 32, 256, 512, 1), ('convT_fwd', 16, 8, 1024, 512, 1), ('convT_fwd', 16, 16, 1024, 256, 2)])
+                                  ('conv_fwd', 16, 32, 256, 512, 1), ('convT_fwd', 16, 8, 1024, 512, 1), ('convT_fwd', 16, 16, 1024, 256, 2),
+                                  # ONE group whose last 256-row tile is ragged (16 x 31 x 31 = 15,376 rows: the PatchGAN 31 x 31 layer's row count)
+                                  # on the table-driven 256x128 tile and (stride 1, 8 x 63 x 63 rows) on the tap-shared 256x256 tile
+                                  ('conv_fwd', 16, 62, 128, 512, 1), ('conv_s1', 8, 64, 256, 512, 1)])
 def test_conv_epilogue_statistics_partials(ctx, case):
     """Fused normalisation statistics (GanConvDesc.stats_partial): per-channel (sum, sum of squares) of the STORED
     output, summed over the chunks the plan reports, per statistics group (tile partials from the epilogue, or row-block
@@ -217,13 +220,16 @@ def test_conv_epilogue_statistics_partials(ctx, case):
     op, N, H, ci, co, groups = case
     rng = np.random.default_rng(7)
     x = q(ctx, rng.standard_normal((N, H, H, ci)))
+    stride = 1 if op == 'conv_s1' else 2             # 'conv_s1': ZeroPadding2D + Conv2D(strides=1), base_gan.py:145-147 (H -> H - 1)
+    if op == 'conv_s1':
+        op = 'conv_fwd'
     w = q(ctx, 0.05 * rng.standard_normal((4, 4, ci, co) if op == 'conv_fwd' else (4, 4, co, ci)))
     xb, xv = dev(ctx, x)
     nat, tr = prep(ctx, w)
-    Ho = H // 2 if op == 'conv_fwd' else 2 * H
+    Ho = H - 1 if stride == 1 else (H // 2 if op == 'conv_fwd' else 2 * H)
     yb = Buf(ctx, N, Ho, Ho, co)
     part = torch.full((4 << 20,), 9.0, dtype=torch.float32, device=ctx.device)
-    d = L.GanConvDesc(ctx.dt, 2, xv, yb.view(), (tr if op == 'conv_fwd' else nat).data_ptr(), co, None, 0, 0.3, 0,
+    d = L.GanConvDesc(ctx.dt, stride, xv, yb.view(), (tr if op == 'conv_fwd' else nat).data_ptr(), co, None, 0, 0.3, 0,
                       ctx.ws_ptr, ctx.ws_bytes, part.data_ptr(), groups, part.numel() * 4)
     opi = 0 if op == 'conv_fwd' else 2
     info = (C.c_int32 * 5)()
