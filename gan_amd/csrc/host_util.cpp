@@ -49,6 +49,7 @@ Opt g_opts[] = {
     {"conv.own_max_rows", {16}},    // column-owner kernel (conv_own.hip) for GanNormFuse layers with at most this many rows per parity (<= 64; 0: never)
     {"conv.norm_fuse", {1}},        // GanNormFuse: small split-K layers finished by their slab-reduce kernel
     {"conv.thin_fused", {1}},       // thin-N layers with <= 2 output channels in one kernel (Z through LDS instead of memory)
+    {"conv.thin_k_blocks", {2048}}, // thin-K streaming kernel: grid cap (workgroups over all 64-channel groups)
     {"conv.thin", {7}},             // bit 0: streaming kernels at all, bit 1: thin-N, bit 2: thin-K
     {"wgrad.tile256", {0}},         // 256-row tiles in the 128x128 kernel family
     {"wgrad.pingpong", {1}},

@@ -21,6 +21,9 @@
 #include <type_traits>
 
 typedef __attribute__((ext_vector_type(8))) short s16x8;
+#ifndef THIN_ZS
+#define THIN_ZS 20          // floats per Z record of conv_thin_n_fused_kernel (16 taps + padding against LDS bank conflicts)
+#endif
 
 
 // ------------------------------------------------------------------------------------------------
@@ -203,7 +206,11 @@ __global__ __launch_bounds__(256) void conv_thin_n_fused_kernel(const ThinNFused
   constexpr int SH = TH + HB + HA, SW = TW + HB + HA, NPX = SH * SW, NT = (NPX + 15) / 16;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint4* wl = (uint4*)smem;                                  // [c][s][lane] weight fragments
-  float* zl = (float*)(smem + (size_t)p.CO * KS * 1024);     // [pixel][c][16 taps]
+  // Z records: [c][pixel][ZS floats], 16 taps + 4 floats of padding - the gather below reads one tap of 64 consecutive pixels per
+  // instruction: at a pixel stride of 16 floats that was a 16-way bank conflict (80 % of the kernel's LDS cycles in the SQ counters),
+  // at 20 floats it is 4-way and the 16-byte stores stay aligned
+  constexpr int ZS = THIN_ZS;
+  float* zl = (float*)(smem + (size_t)p.CO * KS * 1024);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n = lane & 15, q = lane >> 4;
   int b = blockIdx.x;
@@ -228,7 +235,7 @@ __global__ __launch_bounds__(256) void conv_thin_n_fused_kernel(const ThinNFused
       f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int s = 0; s < KS; ++s) acc = mma16<T>(wl[(c * KS + s) * 64 + lane], xf[s], acc);
-      if (e < NPX) *(f32x4*)(zl + ((size_t)e * p.CO + c) * 16 + q * 4) = acc;      // (pixels outside the map: x = 0, so Z = 0)
+      if (e < NPX) *(f32x4*)(zl + ((size_t)c * NPX + e) * ZS + q * 4) = acc;      // (pixels outside the map: x = 0, so Z = 0)
     }
   }
   __syncthreads();
@@ -255,7 +262,7 @@ __global__ __launch_bounds__(256) void conv_thin_n_fused_kernel(const ThinNFused
             for (int a = 0; a < 2; ++a)
 #pragma unroll
               for (int bb = 0; bb < 2; ++bb)     // y[2g+py] = sum_a x[g + py - a] * w[1 - py + 2a]
-                v += zl[((size_t)((ly + HB + py - a) * SW + (lx + HB + px - bb)) * p.CO + c) * 16 + (1 - py + 2 * a) * 4 + (1 - px + 2 * bb)];
+                v += zl[((size_t)c * NPX + (ly + HB + py - a) * SW + (lx + HB + px - bb)) * ZS + (1 - py + 2 * a) * 4 + (1 - px + 2 * bb)];
             store(2 * gy + py, 2 * gx + px, c, v);
           }
       }
@@ -267,7 +274,7 @@ __global__ __launch_bounds__(256) void conv_thin_n_fused_kernel(const ThinNFused
         for (int a = 0; a < 4; ++a)
 #pragma unroll
           for (int bb = 0; bb < 4; ++bb)         // y[g] = sum_a x[g - 1 + a] * w[a]
-            v += zl[((size_t)((ly + a) * SW + (lx + bb)) * p.CO + c) * 16 + a * 4 + bb];
+            v += zl[((size_t)c * NPX + (ly + a) * SW + (lx + bb)) * ZS + a * 4 + bb];
         store(gy, gx, c, v);
       }
     }
@@ -311,7 +318,8 @@ int thin_launch(int family, const GanConvDesc* d, const GemmParams& p, hipStream
     k.divWg = p.divWg; k.divHg = p.divHg;
     const int groups = y.c / 64;
     int gx = (k.tiles + 3) / 4;
-    const int cap = 2048 / groups > 256 ? 2048 / groups : 256;
+    const int capw = gan_opt("conv.thin_k_blocks");            // workgroups of 4 waves per 64-channel group (a wave walks tiles/4/blocks tiles)
+    const int cap = capw / groups > 256 ? capw / groups : 256;
     if (gx > cap) gx = cap;
     if (d->dtype == GAN_F16) GAN_LAUNCH(conv_thin_k_kernel<f16_t>, dim3((unsigned)gx, (unsigned)groups), dim3(256), 0, st, k);
     else GAN_LAUNCH(conv_thin_k_kernel<bf16_t>, dim3((unsigned)gx, (unsigned)groups), dim3(256), 0, st, k);
@@ -331,7 +339,7 @@ int thin_launch(int family, const GanConvDesc* d, const GemmParams& p, hipStream
       constexpr int TH = PAR ? 16 : 10, TW = 32;
       constexpr int NPX = (TH + (PAR ? 2 : 3)) * (TW + (PAR ? 2 : 3));
       f.tilesY = ((PAR ? p.Hs : p.Ho) + TH - 1) / TH; f.tilesX = ((PAR ? p.Ws : p.Wo) + TW - 1) / TW;
-      const size_t smem = (size_t)f.CO * KS * 1024 + (size_t)NPX * f.CO * 64;
+      const size_t smem = (size_t)f.CO * KS * 1024 + (size_t)NPX * f.CO * THIN_ZS * sizeof(float);
       const dim3 grid((unsigned)(x.n * f.tilesY * f.tilesX));
 #define THIN_F(KSV)                                                                                                                  \
       {                                                                                                                               \
