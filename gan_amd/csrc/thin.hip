@@ -38,7 +38,9 @@ struct ThinKParams {
   FastDiv divWg, divHg;
 };
 
-template <typename T>
+// ACT: the activation at compile time (GAN_ACT_NONE / GAN_ACT_LRELU: what the networks use on these layers), or -1 = p.act at run time -
+// the run-time form compiled to three scalar branches per output value (165 branches in the kernel, 48 taken-or-not per 16-pixel tile)
+template <typename T, int ACT>
 __global__ __launch_bounds__(256) void conv_thin_k_kernel(const ThinKParams p) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n = lane & 15, q = lane >> 4;
@@ -86,8 +88,13 @@ __global__ __launch_bounds__(256) void conv_thin_k_kernel(const ThinKParams p) {
         float v[8];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          v[i] = apply_act(acc[2 * pr][i] + bv[pr][i], p.act, p.slope);
-          v[4 + i] = apply_act(acc[2 * pr + 1][i] + bv[pr][4 + i], p.act, p.slope);
+          if constexpr (ACT >= 0) {
+            v[i] = act_c<ACT>(acc[2 * pr][i] + bv[pr][i], p.slope);
+            v[4 + i] = act_c<ACT>(acc[2 * pr + 1][i] + bv[pr][4 + i], p.slope);
+          } else {
+            v[i] = apply_act(acc[2 * pr][i] + bv[pr][i], p.act, p.slope);
+            v[4 + i] = apply_act(acc[2 * pr + 1][i] + bv[pr][4 + i], p.act, p.slope);
+          }
         }
         *(uint4*)(yp + pr * 32) = pack16<T>(v);
       }
@@ -321,8 +328,15 @@ int thin_launch(int family, const GanConvDesc* d, const GemmParams& p, hipStream
     const int capw = gan_opt("conv.thin_k_blocks");            // workgroups of 4 waves per 64-channel group (a wave walks tiles/4/blocks tiles)
     const int cap = capw / groups > 256 ? capw / groups : 256;
     if (gx > cap) gx = cap;
-    if (d->dtype == GAN_F16) GAN_LAUNCH(conv_thin_k_kernel<f16_t>, dim3((unsigned)gx, (unsigned)groups), dim3(256), 0, st, k);
-    else GAN_LAUNCH(conv_thin_k_kernel<bf16_t>, dim3((unsigned)gx, (unsigned)groups), dim3(256), 0, st, k);
+    const dim3 grid((unsigned)gx, (unsigned)groups);
+#define THIN_K(TT)                                                                                              \
+    do {                                                                                                        \
+      if (k.act == GAN_ACT_NONE) GAN_LAUNCH((conv_thin_k_kernel<TT, GAN_ACT_NONE>), grid, dim3(256), 0, st, k);         \
+      else if (k.act == GAN_ACT_LRELU) GAN_LAUNCH((conv_thin_k_kernel<TT, GAN_ACT_LRELU>), grid, dim3(256), 0, st, k);  \
+      else GAN_LAUNCH((conv_thin_k_kernel<TT, -1>), grid, dim3(256), 0, st, k);                                 \
+    } while (0)
+    if (d->dtype == GAN_F16) THIN_K(f16_t); else THIN_K(bf16_t);
+#undef THIN_K
     GAN_CHECK_LAUNCH();
     return 0;
   }
