@@ -1746,6 +1746,11 @@ template <typename T, int MODE, int KR>
 __global__ __launch_bounds__(256) void splitk_norm_kernel(const GemmParams p, int P) {
   splitk_norm_body<T, MODE, KR, false>(p, P, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.y);
 }
+// the same on 512 threads (256 row slots): groups of more than conv.skn512_min_rows rows - half the rows per thread
+template <typename T, int MODE, int KR>
+__global__ __launch_bounds__(512) void splitk_norm512_kernel(const GemmParams p, int P) {
+  splitk_norm_body<T, MODE, KR, false, 0, 512>(p, P, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.y);
+}
 
 // ------------------------------------------------------------------------------------------------
 // pipeline shape per tile (measured): 128-byte K rows and 2 stages for the 8-wave 256-row tiles (one block per CU),
@@ -2142,11 +2147,20 @@ static int launch_gemm(const GemmPlan& pl, hipStream_t st) {
     if (pl.p.skn) {
       const dim3 g((unsigned)(pl.p.Cout / 8), (unsigned)((pl.p.skn == 1 && !(pl.p.skn_mmean && pl.p.skn_groups > 1)) ? pl.p.skn_groups : 1));
       const long long rg = (long long)pl.P * (pl.p.M / pl.p.skn_groups);
+      const int min512 = gan_opt("conv.skn512_min_rows");
+      if (min512 > 0 && rg >= min512 && rg > 256) {            // 512 threads: 256 row slots
+        const int kr = rg <= 512 ? 2 : 4;
+#define SKN_LAUNCH(MODE, KRV) GAN_LAUNCH((splitk_norm512_kernel<T, MODE, KRV>), g, dim3(512), 0, st, pl.p, pl.P)
+        if (pl.p.skn == 1) { if (kr == 2) SKN_LAUNCH(1, 2); else SKN_LAUNCH(1, 4); }
+        else { if (kr == 2) SKN_LAUNCH(2, 2); else SKN_LAUNCH(2, 4); }
+#undef SKN_LAUNCH
+      } else {
       const int kr = rg <= 128 ? 1 : rg <= 256 ? 2 : rg <= 512 ? 4 : 8;
 #define SKN_LAUNCH(MODE, KRV) GAN_LAUNCH((splitk_norm_kernel<T, MODE, KRV>), g, dim3(256), 0, st, pl.p, pl.P)
       if (pl.p.skn == 1) { if (kr == 1) SKN_LAUNCH(1, 1); else if (kr == 2) SKN_LAUNCH(1, 2); else if (kr == 4) SKN_LAUNCH(1, 4); else SKN_LAUNCH(1, 8); }
       else { if (kr == 1) SKN_LAUNCH(2, 1); else if (kr == 2) SKN_LAUNCH(2, 2); else if (kr == 4) SKN_LAUNCH(2, 4); else SKN_LAUNCH(2, 8); }
 #undef SKN_LAUNCH
+      }
     } else if (pl.p.vec_store && pl.p.Cout % 4 == 0 && (pl.p.out_f32 || sizeof(T) == 2)) {
       long long total = (long long)pl.P * pl.p.M * (pl.p.Cout / 4);
       const long long per_wg = 256LL * (pl.p.stats ? pl.stats_rg : 1);

@@ -47,6 +47,7 @@ Opt g_opts[] = {
     {"conv.reduce_stats_rg", {16}}, // split-K slab reduce emitting statistics partials: at most this many row groups per workgroup (1: one chunk per group, as before round 5)
     {"conv.own_max_kb", {192}},     // ... and at most this many KB of operands per workgroup (live taps x (8 weight rows + the layer's rows))
     {"conv.own_max_rows", {16}},    // column-owner kernel (conv_own.hip) for GanNormFuse layers with at most this many rows per parity (<= 64; 0: never)
+    {"conv.skn512_min_rows", {0}},  // finishing slab reduce (GanNormFuse) on 512 threads for statistics groups of at least this many rows (> 256; 0: never)
     {"conv.norm_fuse", {1}},        // GanNormFuse: small split-K layers finished by their slab-reduce kernel
     {"conv.thin_fused", {1}},       // thin-N layers with <= 2 output channels in one kernel (Z through LDS instead of memory)
     {"conv.thin_k_blocks", {2048}}, // thin-K streaming kernel: grid cap (workgroups over all 64-channel groups)

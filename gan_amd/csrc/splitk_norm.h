@@ -72,11 +72,12 @@ template <bool COH> __device__ __forceinline__ void st_u2(const CohBuf& b, void*
 // the L2 (sc0 sc1).
 // SRC = 1 (conv_own_kernel): the layer's values are not in slabs but in the workgroup's LDS - `part` holds `nparts` partial sums
 // [part][parity * mpad + row][8] (fp32) of its 8 channels, added here in order.
-template <typename T, int MODE, int KR, bool COH, int SRC = 0>       // KR: rows per thread (1, 2, 4, 8): 128 * KR >= rows per group
+// NTH: threads of the workgroup that run the body (256, or 512 for the big groups: half the rows - and half the serial loads - per thread)
+template <typename T, int MODE, int KR, bool COH, int SRC = 0, int NTH = 256>       // KR: rows per thread (1, 2, 4, 8): (NTH / 2) * KR >= rows per group
 __device__ __forceinline__ void splitk_norm_body(const GemmParams& p, int P, int bx, int by, int gy, const float* part = nullptr, int nparts = 0,
                                                  int mpad = 0) {
-  constexpr int RS = 128, UNR = 16 / KR;         // 16 slab loads in flight per thread (a row at a time the kernel is latency-bound; 32 in flight: no faster, measured)
-  __shared__ double red[4][8][2];
+  constexpr int RS = NTH / 2, NWV = NTH / 64, UNR = 16 / KR;         // 16 slab loads in flight per thread (a row at a time the kernel is latency-bound; 32 in flight: no faster, measured)
+  __shared__ double red[NWV][8][2];
   __shared__ float bc[8][4];
   const int tid = threadIdx.x, cv = tid & 1, rs = tid >> 1, lane = tid & 63, wave = tid >> 6;
   const int n = bx * 8 + cv * 4;
@@ -157,8 +158,10 @@ __device__ __forceinline__ void splitk_norm_body(const GemmParams& p, int P, int
     }
     __syncthreads();
     const int c = tid & 7;
-    *t1 = red[0][c][0] + red[1][c][0] + red[2][c][0] + red[3][c][0];
-    *t2 = red[0][c][1] + red[1][c][1] + red[2][c][1] + red[3][c][1];
+    double a1 = red[0][c][0], a2 = red[0][c][1];
+#pragma unroll
+    for (int w = 1; w < NWV; ++w) { a1 += red[w][c][0]; a2 += red[w][c][1]; }
+    *t1 = a1; *t2 = a2;
   };
   if (MODE == 2 && bx * 8 >= p.bf_cols) {                     // skip half of a decoder concat: plain gradient
     for (int row = rs; row < P * p.M; row += RS) {

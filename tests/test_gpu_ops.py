@@ -782,6 +782,29 @@ def test_split_k_dgrad_finishes_the_layer_below(ctx, case, planner_options):
         assert np.array_equal(a[3], b[3])                   # skip half: the plain gradient
 
 
+@pytest.mark.parametrize("min_rows", [257, 513])
+def test_finishing_reduce_on_512_threads(ctx, min_rows, planner_options):
+    """conv.skn512_min_rows: the slab reduce that finishes a split-K layer (GanNormFuse) on 512 threads - half the rows per thread for
+    the 1,024-row (and, at 257, the 512-row) groups.  Same slab sums; the statistics are added in another (fixed) order."""
+    tol = {'f32': 2e-5, 'bf16': 2e-2, 'f16': 3e-3}[ctx.dtype]
+    for case in [('conv_fwd', 16, 16, 512, 512, 1, 'lrelu', False), ('convT_fwd', 4, 8, 1024, 512, 2, 'relu', False),
+                 ('convT_fwd', 16, 4, 512, 512, 1, 'relu', True)]:        # 1,024 rows; two groups of 4 x 128; four parities of 256 rows + dropout
+        a, b = _normfuse_fwd(ctx, case, planner_options, [{'conv.skn512_min_rows': min_rows, 'conv.own_max_rows': 0},
+                                                           {'conv.skn512_min_rows': 0, 'conv.own_max_rows': 0}])
+        assert np.array_equal(a[0], b[0])                   # y: the same slab sums
+        for i in (2, 3, 4, 5):
+            assert rel(a[i], b[i].astype(np.float64)) < 1e-5
+        assert rel(a[1], b[1]) < {'f32': 1e-5, 'bf16': 1e-2, 'f16': 2e-3}[ctx.dtype]
+    for case in [('convT_dgrad', 16, 16, 512, 1024, 1, 'relu+mask', 512), ('conv_dgrad', 16, 4, 512, 512, 1, 'lrelu', 512)]:       # 1,024 rows; four parities of 256
+        (a, b), skip = _normfuse_bwd(ctx, case, planner_options, [{'conv.skn512_min_rows': min_rows, 'conv.own_max_rows': 0},
+                                                                   {'conv.skn512_min_rows': 0, 'conv.own_max_rows': 0}])
+        assert float(np.abs(b[0]).max()) > 1e-3
+        assert rel(a[0], b[0]) < tol
+        assert rel(a[1], b[1]) < max(tol, 1e-4) and rel(a[2], b[2]) < max(tol, 1e-4)
+        if skip:
+            assert np.array_equal(a[3], b[3])
+
+
 @pytest.mark.parametrize("case", [('convT_dgrad', 16, 4, 512, 1024, 1, 'relu', 512),       # up1's dgrad -> up0's backward (skip half: plain gradient), M = 64
                                   ('convT_dgrad', 16, 2, 512, 512, 1, 'lrelu', 512),       # up0's dgrad -> down7's backward: M = 16, 4 live taps
                                   ('conv_dgrad', 16, 1, 512, 512, 1, 'lrelu', 512),        # down7's dgrad: four parities of 16 rows, one live tap each
